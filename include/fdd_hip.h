@@ -1,0 +1,184 @@
+/*
+ * fdd_hip.h -- C-ABI of libfdd_hip.so: the MI355X (gfx950) kernels of the
+ * preconditioned-CG hot path of the SEM Poisson solve, replacing the OCCA
+ * launch layer (occa::device / occa::memory / occa::kernel::operator()) of the
+ * reference.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - every entry returns int: 0 = ok, >0 = hipError_t, <0 = FDD_ERR_*;
+ *     fdd_last_error() gives the text of the last failure on this thread;
+ *   - all pointers named like reference kernel arguments are DEVICE pointers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *     kernel entry is asynchronous on it.  Only fdd_memcpy_h2d / _d2h,
+ *     fdd_stream_sync and fdd_device_sync block (occa::memory::copyFrom/copyTo
+ *     and occa::device::finish semantics);
+ *   - the caller owns all buffers, kernels never allocate;
+ *   - argument order follows the OKL kernel it replaces, then workspaces,
+ *     then `stream`;
+ *   - arithmetic is fp64 with int32 indices (csr_matrix.tpp:132-134), compiled
+ *     with -ffp-contract=off: element-wise kernels, thread-per-row and
+ *     LDS-staged SpMV and the tensor-product kernels keep the reference's
+ *     per-output operation order and are bit-identical to the OCCA-Serial
+ *     arithmetic; reductions use a different summation tree (tolerance stated
+ *     in tests/), and the fp64-MFMA kernels fuse multiply-add.
+ *
+ * Each entry cites the reference interface it replaces (file:line relative to
+ * the reference repository root).
+ */
+#ifndef FDD_HIP_H
+#define FDD_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDD_ERR_INVALID_ARGUMENT (-1)
+#define FDD_ERR_UNSUPPORTED (-2)
+#define FDD_ERR_NOT_INITIALIZED (-3)
+
+#define FDD_NUM_GEOM_FACTS 6      /* element.hpp:10-12 */
+#define FDD_REDUCE_MAX_BLOCKS 2048 /* partial sums any reduction entry may write into its workspace */
+
+/* ------------------------------------------------------------------ */
+/* runtime: replaces occa::device / occa::memory (config.hpp:52;        */
+/* usage inventory SURVEY.md section 8(b))                              */
+/* ------------------------------------------------------------------ */
+const char *fdd_version(void);
+const char *fdd_last_error(void);
+int fdd_device_count(int *count);
+int fdd_set_device(int device);                 /* occa::device::setup, poisson.cpp:137 */
+int fdd_get_device(int *device);
+int fdd_device_name(char *buf, size_t buf_len);
+int fdd_malloc(void **ptr, size_t bytes);       /* occa::device::malloc<T>(n) */
+int fdd_free(void *ptr);                        /* occa::memory::free() */
+int fdd_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream); /* occa::memory::copyFrom(host): blocking */
+int fdd_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream); /* occa::memory::copyTo(host): blocking */
+int fdd_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream); /* occa::memory::copyFrom/To(mem): async */
+int fdd_memset(void *dst, int value, size_t bytes, void *stream);
+int fdd_stream_create(void **stream);           /* cudaStreamCreate, subdomain.tpp:3475 */
+int fdd_stream_destroy(void *stream);
+int fdd_stream_sync(void *stream);
+int fdd_device_sync(void);                      /* occa::device::finish(), timer.tpp:50,59 */
+int fdd_event_create(void **event);
+int fdd_event_destroy(void *event);
+int fdd_event_record(void *event, void *stream);
+int fdd_event_elapsed_ms(float *ms, void *start, void *stop); /* synchronises on `stop` */
+
+/* ------------------------------------------------------------------ */
+/* csr_matrix.okl -- CSR y = A x                                        */
+/* ------------------------------------------------------------------ */
+/* csr_matrix.okl:5-18  multiply(Au, A_ptr, A_col, A_val, u, n); launched from csr_matrix.tpp:310 */
+int fdd_csr_multiply(double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, int n, void *stream);
+/* csr_matrix.okl:20-33 multiply_range(..., row_start, row_end) -- row_end INCLUSIVE; csr_matrix.tpp:328 */
+int fdd_csr_multiply_range(double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, int row_start, int row_end, void *stream);
+/* csr_matrix.okl:35-48 multiply_weight(..., weight, n); csr_matrix.tpp:340 */
+int fdd_csr_multiply_weight(double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const double *weight, int n, void *stream);
+
+/* Planned SpMV: the row partition CSR_Matrix::assemble (csr_matrix.tpp:94-180)
+ * can compute once while it still holds the host `ptr` array.  Rows are grouped
+ * into blocks of <= FDD_CSR_BLOCK_NNZ non-zeros that one workgroup streams
+ * coalesced through LDS; each row is then summed in column order by one lane,
+ * which keeps the reference's summation order.  Rows longer than a block are
+ * reduced by a whole workgroup (order differs; tolerance in tests/). */
+#define FDD_CSR_BLOCK_NNZ 2048
+typedef struct fdd_csr_plan fdd_csr_plan;
+int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows, int num_cols, int num_nnz);
+int fdd_csr_plan_destroy(fdd_csr_plan *plan);
+int fdd_csr_plan_num_blocks(const fdd_csr_plan *plan, int *num_blocks);
+int fdd_csr_plan_kind(const fdd_csr_plan *plan, int *kind); /* 0 = thread-per-row, 1 = LDS-staged row blocks */
+/* weight may be NULL (multiply) or a device vector of num_rows (multiply_weight) */
+int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const double *weight, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* math.okl -- BLAS-1                                                    */
+/* ------------------------------------------------------------------ */
+int fdd_set_to_value(double *u, double alpha, int n, int offset, void *stream);                                              /* math.okl:5-11,  math.tpp:48 */
+int fdd_invert_vector_elements(double *u, int n, void *stream);                                                              /* math.okl:13-19, math.tpp:54 */
+int fdd_vector_vector_addition(double *uv, double alpha, const double *u, double beta, const double *v, int n, void *stream); /* math.okl:21-27, math.tpp:60; uv may alias u or v */
+int fdd_vector_scaling(double *au, double alpha, const double *u, int n, void *stream);                                      /* math.okl:29-35, math.tpp:66 */
+
+/* ------------------------------------------------------------------ */
+/* domain.okl -- outer solver kernels                                   */
+/* ------------------------------------------------------------------ */
+/* Reference two-kernel form, one thread per GLL point, global scratch GDu.
+ * G / GDu are HOST arrays of device pointers (the reference keeps device
+ * pointer tables, domain.tpp:65-67, 221-224).  dim = 2 or 3. */
+int fdd_dom_stiffness_matrix_1(double *const GDu[3], const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], int num_points, int poly_degree, int dim, void *stream); /* domain.okl:5-52,  domain.tpp:605 */
+int fdd_dom_stiffness_matrix_2(double *Au, const double *const GDu[3], const double *D_hat, int num_points, int poly_degree, int dim, void *stream);                                           /* domain.okl:54-98, domain.tpp:606 */
+/* Fused Au = D^T G D u (both passes in one launch, slabs staged in LDS, no
+ * global scratch): 64 B/point.  3-D, poly_degree 1..15.  Replaces the pair of
+ * launches in Domain::stiffness_matrix (domain.tpp:602-607). */
+int fdd_dom_stiffness_matrix(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], int num_elements, int poly_degree, void *stream);
+
+int fdd_dom_initialize_arrays(double *u_k, double *r_k, const double *f, int num_points, void *stream); /* domain.okl:100-107, domain.tpp:618,734 */
+
+/* Reductions.  The reference kernels write one partial per 128-thread block
+ * and the host sums them after a D2H copy (domain.tpp:916-996).  Here `out`
+ * (device) receives the FINAL scalar(s); `ws` is a device workspace of
+ * fdd_reduce_workspace_doubles() doubles. */
+size_t fdd_reduce_workspace_doubles(void);
+int fdd_dom_residual_norm(double *out, double *ws, const double *r_k, const double *QQt_r_k, const double *dirichlet_mask, int num_points, void *stream);                  /* domain.okl:109-138; out[0] = sum r*QQt_r*mask (no sqrt) */
+int fdd_dom_projection_inner_products(double *out2, double *ws, const double *z_k, const double *r_k, const double *p_k, const double *q_k, int num_points, void *stream); /* domain.okl:140-184; out2 = {gamma, theta} */
+int fdd_dom_inner_product_flexible(double *out, double *ws, const double *r_k, const double *r_kp1, const double *z_k, int num_points, void *stream);                      /* domain.okl:195-224 */
+int fdd_dom_inner_product(double *out, double *ws, const double *u_k, const double *v_k, const double *dirichlet_mask, int num_points, void *stream);                      /* domain.okl:235-264 */
+
+int fdd_dom_solution_and_residual_update(double *u_k, double *r_kp1, const double *r_k, const double *p_k, const double *q_k, double alpha_k, int num_points, void *stream); /* domain.okl:186-193, domain.tpp:978 */
+int fdd_dom_residual_and_search_update(double *p_k, double *r_k, const double *z_k, const double *r_kp1, double beta_k, int num_points, void *stream);                      /* domain.okl:226-233, domain.tpp:720 */
+/* Same updates with the step length taken from device scalars (no host
+ * round trip between the dot products and the update):
+ *   alpha = num[0] / den[0];   beta = num[0] / den[0]. */
+int fdd_dom_solution_and_residual_update_dev(double *u_k, double *r_kp1, const double *r_k, const double *p_k, const double *q_k, const double *alpha_num, const double *alpha_den, int num_points, void *stream);
+int fdd_dom_residual_and_search_update_dev(double *p_k, double *r_k, const double *z_k, const double *r_kp1, const double *beta_num, const double *beta_den, int num_points, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* subdomain.okl -- FDD local-solve kernels                             */
+/* ------------------------------------------------------------------ */
+/* Reference form with per-point indirection (offset / vert / level int arrays,
+ * subdomain.tpp:1603-1630).  D_hat_ptr is a HOST array of num_levels device
+ * pointers; poly_degree is the HOST table injected as the JIT macro
+ * POLY_DEGREE (subdomain.tpp:3886-3890), num_levels <= 16. */
+int fdd_sub_stiffness_matrix_1(double *const GDu[3], const double *u, const double *const *D_hat_ptr, const int *offset, const int *vert, const int *level, const int *poly_degree, int num_levels, const double *const G[FDD_NUM_GEOM_FACTS], int num_points, int dim, void *stream); /* subdomain.okl:4-53,   subdomain.tpp:3953 */
+int fdd_sub_stiffness_matrix_2(double *Au, const double *const GDu[3], const double *const *D_hat_ptr, const int *offset, const int *vert, const int *level, const int *poly_degree, int num_levels, int num_points, int dim, void *stream);                                           /* subdomain.okl:55-101, subdomain.tpp:3961 */
+/* Fused, level-sorted form: one launch per polynomial level over the list of
+ * that level's elements; elem_offset[e] (device) is the first point of element
+ * e in u / Au / G (NULL => e * (N+1)^3). */
+int fdd_sub_stiffness_matrix(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
+
+int fdd_sub_inner_product(double *out, double *ws, const double *u, const double *v, int num_values, void *stream);                                                                                  /* subdomain.okl:103-132 */
+int fdd_sub_weighted_inner_product(double *out, double *ws, const double *u, const double *v, const double *w, int num_values, void *stream);                                                       /* subdomain.okl:134-163, subdomain.tpp:4302,4508 */
+int fdd_sub_projection_inner_products(double *out2, double *ws, const double *z_k, const double *r_k, const double *p_k, const double *q_k, const double *weight, int num_values, void *stream);    /* subdomain.okl:165-209, subdomain.tpp:4526 */
+int fdd_sub_search_update_inner_product(double *out, double *ws, const double *r_k, const double *r_kp1, const double *z_k, const double *weight, int num_points, void *stream);                    /* subdomain.okl:229-258, subdomain.tpp:4552 */
+int fdd_sub_initialize_arrays(double *u_k, double *r_k, const double *f, int num_values, void *stream);                                                                                             /* subdomain.okl:211-218, subdomain.tpp:4274 */
+int fdd_sub_solution_and_residual_update(double *u_k, double *r_kp1, const double *r_k, const double *p_k, const double *q_k, double alpha_k, int num_values, void *stream);                        /* subdomain.okl:220-227, subdomain.tpp:4541 */
+int fdd_sub_residual_and_search_update(double *p_k, double *r_k, const double *z_k, const double *r_kp1, double beta_k, int num_values, void *stream);                                              /* subdomain.okl:259-266, subdomain.tpp:4563 */
+/* precision-cast copies between outer (EType) and preconditioner (DType) data */
+int fdd_sub_copy_f64_f64(double *u, const double *v, int num_points, void *stream); /* subdomain.okl:268-282 with DType=EType=double */
+int fdd_sub_copy_f32_f64(float *u, const double *v, int num_points, void *stream);  /* subdomain.okl:268-274, DType=float */
+int fdd_sub_copy_f64_f32(double *u, const float *v, int num_points, void *stream);  /* subdomain.okl:276-282, DType=float */
+/* degree-tree restriction, reference three-launch form with global intermediates */
+int fdd_sub_restriction_1(double *Ju, const double *J_cf, const double *u, int num_points, int n_f, int n_c, int dim, void *stream); /* subdomain.okl:284-313, subdomain.tpp:4593,4601 */
+int fdd_sub_restriction_2(double *Ju, const double *J_cf, const double *u, int num_points, int n_f, int n_c, int dim, void *stream); /* subdomain.okl:315-344, subdomain.tpp:4596,4604 */
+int fdd_sub_restriction_3(double *Ju, const double *J_cf, const double *u, int num_points, int n_f, int n_c, void *stream);          /* subdomain.okl:346-366, subdomain.tpp:4607 */
+/* Fused J^T (x) J^T (x) J^T per element through LDS, 3-D: 8*(n_f^3+n_c^3) B/element */
+int fdd_sub_restriction(double *u_c, const double *J_cf, const double *u_f, int num_elements, int n_f, int n_c, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* AMG/kernels.cu + AMG/csr_matrix.cpp -- Chebyshev-smoothed V-cycle     */
+/* ------------------------------------------------------------------ */
+int fdd_amg_vector_set_to_value(double *data, double value, int size, void *stream);                                                   /* AMG/kernels.cu:11-23 */
+int fdd_amg_main_scaled_residual(double *Sr, double *w, const double *f_m_Au, const double *S, double alpha, int size, void *stream);   /* AMG/kernels.cu:25-41 */
+int fdd_amg_main_polynomial_evaluation(double *w, double *v, const double *r, const double *D_val, double alpha, int size, void *stream); /* AMG/kernels.cu:43-59 */
+int fdd_amg_main_update_field(double *u, const double *w, const double *D_val, int size, void *stream);                                /* AMG/kernels.cu:61-76 */
+int fdd_amg_vector_multiplication(double *uv, const double *u, const double *v, int size, void *stream);                               /* AMG/kernels.cu:79-94 */
+/* y = alpha*A*x + beta*y (cusparseSpMV CSR_ALG1 at AMG/csr_matrix.cpp:129-131); y must not alias x */
+int fdd_amg_matvec(double *y, const int *ptr, const int *col, const double *val, const double *x, double alpha, double beta, int num_rows, void *stream);
+/* cublasDdot replacement (AMG/vector.cpp:100,129): out[0] = sum x*y */
+int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int size, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FDD_HIP_H */

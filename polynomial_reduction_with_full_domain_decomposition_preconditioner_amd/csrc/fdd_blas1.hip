@@ -1,0 +1,463 @@
+// Element-wise streaming kernels (HBM-bound): math.okl, the fused vector
+// updates of domain.okl / subdomain.okl, the precision-cast copies and the
+// element-wise AMG smoother kernels of AMG/kernels.cu.
+//
+// One template drives them all: every lane moves 16 B per access (double2),
+// the grid is capped at 2048 workgroups of 256 lanes and strides over the
+// vector, so a 134 MB vector is 16 passes of fully coalesced 1 KiB
+// wave-accesses.  Pointers that are not 16-B aligned (occa::memory::slice
+// offsets, math.okl's `offset`) take the scalar 8-B path.
+//
+// Compiled with -ffp-contract=off: a*x + b*y is two multiplies and one add in
+// source order, bit-identical to the OCCA-Serial arithmetic.
+#include "fdd_common.h"
+
+namespace
+{
+
+constexpr int kBlock = 256;
+
+template <typename Op>
+__global__ __launch_bounds__(kBlock) void ew_vec2_kernel(Op op, long long n2, long long n)
+{
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) op.vec2(i);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) op.one(n - 1);
+}
+
+template <typename Op>
+__global__ __launch_bounds__(kBlock) void ew_scalar_kernel(Op op, long long n)
+{
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) op.one(i);
+}
+
+template <typename Op>
+int launch_ew(const Op &op, long long n, bool aligned, void *stream)
+{
+    if (n <= 0) return 0;
+    if (aligned && n >= 2)
+    {
+        long long n2 = n / 2;
+        int grid = fdd_stream_grid(n2, kBlock);
+        hipLaunchKernelGGL(ew_vec2_kernel<Op>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), op, n2, n);
+    }
+    else
+    {
+        int grid = fdd_stream_grid(n, kBlock);
+        hipLaunchKernelGGL(ew_scalar_kernel<Op>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), op, n);
+    }
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+__device__ __forceinline__ double2 ld2(const double *p, long long i) { return reinterpret_cast<const double2 *>(p)[i]; }
+__device__ __forceinline__ void st2(double *p, long long i, double2 v) { reinterpret_cast<double2 *>(p)[i] = v; }
+
+// ---------------------------------------------------------------- math.okl
+struct SetOp // math.okl:5-11
+{
+    double *u;
+    double alpha;
+    __device__ void vec2(long long i) const { st2(u, i, make_double2(alpha, alpha)); }
+    __device__ void one(long long i) const { u[i] = alpha; }
+};
+
+struct InvertOp // math.okl:13-19
+{
+    double *u;
+    __device__ void vec2(long long i) const
+    {
+        double2 a = ld2(u, i);
+        st2(u, i, make_double2(1.0 / a.x, 1.0 / a.y));
+    }
+    __device__ void one(long long i) const { u[i] = 1.0 / u[i]; }
+};
+
+struct AxpbyOp // math.okl:21-27
+{
+    double *uv;
+    const double *u;
+    const double *v;
+    double alpha, beta;
+    __device__ void vec2(long long i) const
+    {
+        double2 a = ld2(u, i), b = ld2(v, i);
+        st2(uv, i, make_double2(alpha * a.x + beta * b.x, alpha * a.y + beta * b.y));
+    }
+    __device__ void one(long long i) const { uv[i] = alpha * u[i] + beta * v[i]; }
+};
+
+struct ScaleOp // math.okl:29-35
+{
+    double *au;
+    const double *u;
+    double alpha;
+    __device__ void vec2(long long i) const
+    {
+        double2 a = ld2(u, i);
+        st2(au, i, make_double2(alpha * a.x, alpha * a.y));
+    }
+    __device__ void one(long long i) const { au[i] = alpha * u[i]; }
+};
+
+// ------------------------------------------------- domain.okl / subdomain.okl
+struct InitOp // domain.okl:100-107, subdomain.okl:211-218
+{
+    double *u_k;
+    double *r_k;
+    const double *f;
+    __device__ void vec2(long long i) const
+    {
+        double2 a = ld2(f, i);
+        st2(u_k, i, make_double2(0.0, 0.0));
+        st2(r_k, i, a);
+    }
+    __device__ void one(long long i) const
+    {
+        u_k[i] = 0.0;
+        r_k[i] = f[i];
+    }
+};
+
+// alpha either by value or as num/den read from device memory
+struct ScalarByValue
+{
+    double v;
+    __device__ double get() const { return v; }
+};
+struct ScalarRatioDev
+{
+    const double *num;
+    const double *den;
+    __device__ double get() const { return num[0] / den[0]; }
+};
+
+template <typename S>
+struct UpdateUROp // domain.okl:186-193, subdomain.okl:220-227
+{
+    double *u_k;
+    double *r_kp1;
+    const double *r_k;
+    const double *p_k;
+    const double *q_k;
+    S alpha;
+    __device__ void vec2(long long i) const
+    {
+        const double a = alpha.get();
+        double2 u = ld2(u_k, i), r = ld2(r_k, i), p = ld2(p_k, i), q = ld2(q_k, i);
+        u.x += a * p.x;
+        u.y += a * p.y;
+        st2(u_k, i, u);
+        st2(r_kp1, i, make_double2(r.x - a * q.x, r.y - a * q.y));
+    }
+    __device__ void one(long long i) const
+    {
+        const double a = alpha.get();
+        u_k[i] += a * p_k[i];
+        r_kp1[i] = r_k[i] - a * q_k[i];
+    }
+};
+
+template <typename S>
+struct UpdatePROp // domain.okl:226-233, subdomain.okl:259-266
+{
+    double *p_k;
+    double *r_k;
+    const double *z_k;
+    const double *r_kp1;
+    S beta;
+    __device__ void vec2(long long i) const
+    {
+        const double b = beta.get();
+        double2 z = ld2(z_k, i), p = ld2(p_k, i), r = ld2(r_kp1, i);
+        st2(p_k, i, make_double2(z.x + b * p.x, z.y + b * p.y));
+        st2(r_k, i, r);
+    }
+    __device__ void one(long long i) const
+    {
+        const double b = beta.get();
+        p_k[i] = z_k[i] + b * p_k[i];
+        r_k[i] = r_kp1[i];
+    }
+};
+
+struct CopyOp // subdomain.okl:268-282 with DType = EType = double
+{
+    double *u;
+    const double *v;
+    __device__ void vec2(long long i) const { st2(u, i, ld2(v, i)); }
+    __device__ void one(long long i) const { u[i] = v[i]; }
+};
+
+struct CopyF32F64Op // subdomain.okl:268-274, DType = float
+{
+    float *u;
+    const double *v;
+    __device__ void vec2(long long i) const
+    {
+        double2 a = ld2(v, i);
+        reinterpret_cast<float2 *>(u)[i] = make_float2((float)a.x, (float)a.y);
+    }
+    __device__ void one(long long i) const { u[i] = (float)v[i]; }
+};
+
+struct CopyF64F32Op // subdomain.okl:276-282, DType = float
+{
+    double *u;
+    const float *v;
+    __device__ void vec2(long long i) const
+    {
+        float2 a = reinterpret_cast<const float2 *>(v)[i];
+        st2(u, i, make_double2((double)a.x, (double)a.y));
+    }
+    __device__ void one(long long i) const { u[i] = (double)v[i]; }
+};
+
+// ------------------------------------------------------------ AMG/kernels.cu
+struct ScaledResidualOp // AMG/kernels.cu:25-41
+{
+    double *Sr;
+    double *w;
+    const double *f_m_Au;
+    const double *S;
+    double alpha;
+    __device__ void vec2(long long i) const
+    {
+        double2 s = ld2(S, i), r = ld2(f_m_Au, i);
+        double2 sr = make_double2(s.x * r.x, s.y * r.y);
+        st2(Sr, i, sr);
+        st2(w, i, make_double2(alpha * sr.x, alpha * sr.y));
+    }
+    __device__ void one(long long i) const
+    {
+        Sr[i] = S[i] * f_m_Au[i];
+        w[i] = alpha * Sr[i];
+    }
+};
+
+struct PolyEvalOp // AMG/kernels.cu:43-59
+{
+    double *w;
+    double *v;
+    const double *r;
+    const double *D_val;
+    double alpha;
+    __device__ void vec2(long long i) const
+    {
+        double2 vv = ld2(v, i), d = ld2(D_val, i), rr = ld2(r, i);
+        vv.x *= d.x;
+        vv.y *= d.y;
+        st2(v, i, vv);
+        st2(w, i, make_double2(alpha * rr.x + vv.x, alpha * rr.y + vv.y));
+    }
+    __device__ void one(long long i) const
+    {
+        v[i] *= D_val[i];
+        w[i] = alpha * r[i] + v[i];
+    }
+};
+
+struct UpdateFieldOp // AMG/kernels.cu:61-76
+{
+    double *u;
+    const double *w;
+    const double *D_val;
+    __device__ void vec2(long long i) const
+    {
+        double2 uu = ld2(u, i), ww = ld2(w, i), d = ld2(D_val, i);
+        uu.x += d.x * ww.x;
+        uu.y += d.y * ww.y;
+        st2(u, i, uu);
+    }
+    __device__ void one(long long i) const { u[i] += D_val[i] * w[i]; }
+};
+
+struct VMulOp // AMG/kernels.cu:79-94
+{
+    double *uv;
+    const double *u;
+    const double *v;
+    __device__ void vec2(long long i) const
+    {
+        double2 a = ld2(u, i), b = ld2(v, i);
+        st2(uv, i, make_double2(a.x * b.x, a.y * b.y));
+    }
+    __device__ void one(long long i) const { uv[i] = u[i] * v[i]; }
+};
+
+static int initialize_arrays(double *u_k, double *r_k, const double *f, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(u_k != nullptr && r_k != nullptr && f != nullptr);
+    return launch_ew(InitOp{u_k, r_k, f}, n, fdd_aligned16(u_k) && fdd_aligned16(r_k) && fdd_aligned16(f), stream);
+}
+
+template <typename S>
+static int update_ur(double *u_k, double *r_kp1, const double *r_k, const double *p_k, const double *q_k, S alpha, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(u_k != nullptr && r_kp1 != nullptr && r_k != nullptr && p_k != nullptr && q_k != nullptr);
+    bool al = fdd_aligned16(u_k) && fdd_aligned16(r_kp1) && fdd_aligned16(r_k) && fdd_aligned16(p_k) && fdd_aligned16(q_k);
+    return launch_ew(UpdateUROp<S>{u_k, r_kp1, r_k, p_k, q_k, alpha}, n, al, stream);
+}
+
+template <typename S>
+static int update_pr(double *p_k, double *r_k, const double *z_k, const double *r_kp1, S beta, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(p_k != nullptr && r_k != nullptr && z_k != nullptr && r_kp1 != nullptr);
+    bool al = fdd_aligned16(p_k) && fdd_aligned16(r_k) && fdd_aligned16(z_k) && fdd_aligned16(r_kp1);
+    return launch_ew(UpdatePROp<S>{p_k, r_k, z_k, r_kp1, beta}, n, al, stream);
+}
+
+} // namespace
+
+extern "C" {
+
+int fdd_set_to_value(double *u, double alpha, int n, int offset, void *stream)
+{
+    FDD_REQUIRE(n >= 0 && offset >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(u != nullptr);
+    double *p = u + offset;
+    return launch_ew(SetOp{p, alpha}, n, fdd_aligned16(p), stream);
+}
+
+int fdd_invert_vector_elements(double *u, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(u != nullptr);
+    return launch_ew(InvertOp{u}, n, fdd_aligned16(u), stream);
+}
+
+int fdd_vector_vector_addition(double *uv, double alpha, const double *u, double beta, const double *v, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(uv != nullptr && u != nullptr && v != nullptr);
+    return launch_ew(AxpbyOp{uv, u, v, alpha, beta}, n, fdd_aligned16(uv) && fdd_aligned16(u) && fdd_aligned16(v), stream);
+}
+
+int fdd_vector_scaling(double *au, double alpha, const double *u, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(au != nullptr && u != nullptr);
+    return launch_ew(ScaleOp{au, u, alpha}, n, fdd_aligned16(au) && fdd_aligned16(u), stream);
+}
+
+int fdd_dom_initialize_arrays(double *u_k, double *r_k, const double *f, int num_points, void *stream)
+{
+    return initialize_arrays(u_k, r_k, f, num_points, stream);
+}
+
+int fdd_sub_initialize_arrays(double *u_k, double *r_k, const double *f, int num_values, void *stream)
+{
+    return initialize_arrays(u_k, r_k, f, num_values, stream);
+}
+
+int fdd_dom_solution_and_residual_update(double *u_k, double *r_kp1, const double *r_k, const double *p_k, const double *q_k, double alpha_k, int num_points, void *stream)
+{
+    return update_ur(u_k, r_kp1, r_k, p_k, q_k, ScalarByValue{alpha_k}, num_points, stream);
+}
+
+int fdd_sub_solution_and_residual_update(double *u_k, double *r_kp1, const double *r_k, const double *p_k, const double *q_k, double alpha_k, int num_values, void *stream)
+{
+    return update_ur(u_k, r_kp1, r_k, p_k, q_k, ScalarByValue{alpha_k}, num_values, stream);
+}
+
+int fdd_dom_solution_and_residual_update_dev(double *u_k, double *r_kp1, const double *r_k, const double *p_k, const double *q_k, const double *alpha_num, const double *alpha_den, int num_points, void *stream)
+{
+    FDD_REQUIRE(alpha_num != nullptr && alpha_den != nullptr);
+    return update_ur(u_k, r_kp1, r_k, p_k, q_k, ScalarRatioDev{alpha_num, alpha_den}, num_points, stream);
+}
+
+int fdd_dom_residual_and_search_update(double *p_k, double *r_k, const double *z_k, const double *r_kp1, double beta_k, int num_points, void *stream)
+{
+    return update_pr(p_k, r_k, z_k, r_kp1, ScalarByValue{beta_k}, num_points, stream);
+}
+
+int fdd_sub_residual_and_search_update(double *p_k, double *r_k, const double *z_k, const double *r_kp1, double beta_k, int num_values, void *stream)
+{
+    return update_pr(p_k, r_k, z_k, r_kp1, ScalarByValue{beta_k}, num_values, stream);
+}
+
+int fdd_dom_residual_and_search_update_dev(double *p_k, double *r_k, const double *z_k, const double *r_kp1, const double *beta_num, const double *beta_den, int num_points, void *stream)
+{
+    FDD_REQUIRE(beta_num != nullptr && beta_den != nullptr);
+    return update_pr(p_k, r_k, z_k, r_kp1, ScalarRatioDev{beta_num, beta_den}, num_points, stream);
+}
+
+int fdd_sub_copy_f64_f64(double *u, const double *v, int num_points, void *stream)
+{
+    FDD_REQUIRE(num_points >= 0);
+    if (num_points == 0) return 0;
+    FDD_REQUIRE(u != nullptr && v != nullptr);
+    return launch_ew(CopyOp{u, v}, num_points, fdd_aligned16(u) && fdd_aligned16(v), stream);
+}
+
+int fdd_sub_copy_f32_f64(float *u, const double *v, int num_points, void *stream)
+{
+    FDD_REQUIRE(num_points >= 0);
+    if (num_points == 0) return 0;
+    FDD_REQUIRE(u != nullptr && v != nullptr);
+    bool al = fdd_aligned16(v) && ((reinterpret_cast<uintptr_t>(u) & 7u) == 0);
+    return launch_ew(CopyF32F64Op{u, v}, num_points, al, stream);
+}
+
+int fdd_sub_copy_f64_f32(double *u, const float *v, int num_points, void *stream)
+{
+    FDD_REQUIRE(num_points >= 0);
+    if (num_points == 0) return 0;
+    FDD_REQUIRE(u != nullptr && v != nullptr);
+    bool al = fdd_aligned16(u) && ((reinterpret_cast<uintptr_t>(v) & 7u) == 0);
+    return launch_ew(CopyF64F32Op{u, v}, num_points, al, stream);
+}
+
+int fdd_amg_vector_set_to_value(double *data, double value, int size, void *stream)
+{
+    return fdd_set_to_value(data, value, size, 0, stream);
+}
+
+int fdd_amg_main_scaled_residual(double *Sr, double *w, const double *f_m_Au, const double *S, double alpha, int size, void *stream)
+{
+    FDD_REQUIRE(size >= 0);
+    if (size == 0) return 0;
+    FDD_REQUIRE(Sr != nullptr && w != nullptr && f_m_Au != nullptr && S != nullptr);
+    bool al = fdd_aligned16(Sr) && fdd_aligned16(w) && fdd_aligned16(f_m_Au) && fdd_aligned16(S);
+    return launch_ew(ScaledResidualOp{Sr, w, f_m_Au, S, alpha}, size, al, stream);
+}
+
+int fdd_amg_main_polynomial_evaluation(double *w, double *v, const double *r, const double *D_val, double alpha, int size, void *stream)
+{
+    FDD_REQUIRE(size >= 0);
+    if (size == 0) return 0;
+    FDD_REQUIRE(w != nullptr && v != nullptr && r != nullptr && D_val != nullptr);
+    bool al = fdd_aligned16(w) && fdd_aligned16(v) && fdd_aligned16(r) && fdd_aligned16(D_val);
+    return launch_ew(PolyEvalOp{w, v, r, D_val, alpha}, size, al, stream);
+}
+
+int fdd_amg_main_update_field(double *u, const double *w, const double *D_val, int size, void *stream)
+{
+    FDD_REQUIRE(size >= 0);
+    if (size == 0) return 0;
+    FDD_REQUIRE(u != nullptr && w != nullptr && D_val != nullptr);
+    bool al = fdd_aligned16(u) && fdd_aligned16(w) && fdd_aligned16(D_val);
+    return launch_ew(UpdateFieldOp{u, w, D_val}, size, al, stream);
+}
+
+int fdd_amg_vector_multiplication(double *uv, const double *u, const double *v, int size, void *stream)
+{
+    FDD_REQUIRE(size >= 0);
+    if (size == 0) return 0;
+    FDD_REQUIRE(uv != nullptr && u != nullptr && v != nullptr);
+    bool al = fdd_aligned16(uv) && fdd_aligned16(u) && fdd_aligned16(v);
+    return launch_ew(VMulOp{uv, u, v}, size, al, stream);
+}
+
+} // extern "C"

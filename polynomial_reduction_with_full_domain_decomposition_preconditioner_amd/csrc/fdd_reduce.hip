@@ -1,0 +1,311 @@
+// Dot-product style reductions (HBM-bound): the four Domain dot kernels
+// (domain.okl:109-264), the Subdomain ones (subdomain.okl:103-258) and the
+// cublasDdot replacement of AMG/vector.cpp.
+//
+// The reference writes one partial per 128-thread block, copies all of them to
+// the host (131 072 doubles at config C2) and sums them there.  Here a capped
+// grid (<= 2048 workgroups) strides over the vectors with 16-B loads, each
+// lane keeps a private sum, a wavefront __shfl_down tree and a 4-wave LDS step
+// give one partial per workgroup, and a second one-workgroup launch folds the
+// partials into the final scalar on the device.  The result is deterministic
+// for a given n (fixed grid, fixed tree) but its summation order differs from
+// the reference's 128-wide tree + serial block sum: parity is
+// tolerance-based (tests/).
+#include "fdd_common.h"
+
+namespace
+{
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / FDD_WAVE;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = FDD_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, FDD_WAVE);
+    return v;
+}
+
+// NV values per element (1 or 2 simultaneous sums)
+template <int NV>
+struct Acc
+{
+    double v[NV];
+};
+
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(Acc<NV> a, double *ws, int nblocks_stride)
+{
+    __shared__ double s[NV][kWaves];
+    const int lane = threadIdx.x & (FDD_WAVE - 1);
+    const int wave = threadIdx.x / FDD_WAVE;
+
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+    {
+        double x = wave_sum(a.v[k]);
+        if (lane == 0) s[k][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+        {
+            double x = s[k][0];
+#pragma unroll
+            for (int w = 1; w < kWaves; w++) x += s[k][w];
+            ws[blockIdx.x + k * nblocks_stride] = x;
+        }
+    }
+}
+
+template <typename Op>
+__global__ __launch_bounds__(kBlock) void reduce_vec2_kernel(Op op, double *ws, long long n2, long long n)
+{
+    Acc<Op::NV> a;
+#pragma unroll
+    for (int k = 0; k < Op::NV; k++) a.v[k] = 0.0;
+
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) op.vec2(i, a);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) op.one(n - 1, a);
+
+    block_reduce_store<Op::NV>(a, ws, FDD_REDUCE_MAX_BLOCKS);
+}
+
+template <typename Op>
+__global__ __launch_bounds__(kBlock) void reduce_scalar_kernel(Op op, double *ws, long long n)
+{
+    Acc<Op::NV> a;
+#pragma unroll
+    for (int k = 0; k < Op::NV; k++) a.v[k] = 0.0;
+
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) op.one(i, a);
+
+    block_reduce_store<Op::NV>(a, ws, FDD_REDUCE_MAX_BLOCKS);
+}
+
+// second stage: one workgroup folds `nblocks` partials per value
+template <int NV>
+__global__ __launch_bounds__(kBlock) void reduce_final_kernel(double *out, const double *ws, int nblocks)
+{
+    __shared__ double s[NV][kWaves];
+    const int lane = threadIdx.x & (FDD_WAVE - 1);
+    const int wave = threadIdx.x / FDD_WAVE;
+
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+    {
+        double x = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += kBlock) x += ws[b + k * FDD_REDUCE_MAX_BLOCKS];
+        x = wave_sum(x);
+        if (lane == 0) s[k][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+        {
+            double x = s[k][0];
+#pragma unroll
+            for (int w = 1; w < kWaves; w++) x += s[k][w];
+            out[k] = x;
+        }
+    }
+}
+
+template <typename Op>
+int launch_reduce(const Op &op, double *out, double *ws, long long n, bool aligned, void *stream)
+{
+    hipStream_t s = fdd_stream(stream);
+    if (n <= 0)
+    {
+        // empty sums are zero; keep it asynchronous
+        return (int)hipMemsetAsync(out, 0, sizeof(double) * Op::NV, s);
+    }
+
+    int grid;
+    if (aligned && n >= 2)
+    {
+        long long n2 = n / 2;
+        grid = fdd_stream_grid(n2, kBlock);
+        hipLaunchKernelGGL(reduce_vec2_kernel<Op>, dim3(grid), dim3(kBlock), 0, s, op, ws, n2, n);
+    }
+    else
+    {
+        grid = fdd_stream_grid(n, kBlock);
+        hipLaunchKernelGGL(reduce_scalar_kernel<Op>, dim3(grid), dim3(kBlock), 0, s, op, ws, n);
+    }
+    FDD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_final_kernel<Op::NV>, dim3(1), dim3(kBlock), 0, s, out, ws, grid);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+__device__ __forceinline__ double2 ld2(const double *p, long long i) { return reinterpret_cast<const double2 *>(p)[i]; }
+
+struct Dot2Op // subdomain.okl:103-132 / cublasDdot
+{
+    static constexpr int NV = 1;
+    const double *u, *v;
+    __device__ void vec2(long long i, Acc<1> &a) const
+    {
+        double2 x = ld2(u, i), y = ld2(v, i);
+        a.v[0] += x.x * y.x;
+        a.v[0] += x.y * y.y;
+    }
+    __device__ void one(long long i, Acc<1> &a) const { a.v[0] += u[i] * v[i]; }
+};
+
+struct Dot3Op // domain.okl:109-138 (r*QQt_r*mask), :235-264 (u*v*mask), subdomain.okl:134-163 (u*v*w)
+{
+    static constexpr int NV = 1;
+    const double *u, *v, *w;
+    __device__ void vec2(long long i, Acc<1> &a) const
+    {
+        double2 x = ld2(u, i), y = ld2(v, i), z = ld2(w, i);
+        a.v[0] += x.x * y.x * z.x;
+        a.v[0] += x.y * y.y * z.y;
+    }
+    __device__ void one(long long i, Acc<1> &a) const { a.v[0] += u[i] * v[i] * w[i]; }
+};
+
+struct ProjOp // domain.okl:140-184
+{
+    static constexpr int NV = 2;
+    const double *z, *r, *p, *q;
+    __device__ void vec2(long long i, Acc<2> &a) const
+    {
+        double2 zz = ld2(z, i), rr = ld2(r, i), pp = ld2(p, i), qq = ld2(q, i);
+        a.v[0] += zz.x * rr.x;
+        a.v[0] += zz.y * rr.y;
+        a.v[1] += pp.x * qq.x;
+        a.v[1] += pp.y * qq.y;
+    }
+    __device__ void one(long long i, Acc<2> &a) const
+    {
+        a.v[0] += z[i] * r[i];
+        a.v[1] += p[i] * q[i];
+    }
+};
+
+struct ProjWOp // subdomain.okl:165-209
+{
+    static constexpr int NV = 2;
+    const double *z, *r, *p, *q, *w;
+    __device__ void vec2(long long i, Acc<2> &a) const
+    {
+        double2 zz = ld2(z, i), rr = ld2(r, i), pp = ld2(p, i), qq = ld2(q, i), ww = ld2(w, i);
+        a.v[0] += zz.x * rr.x * ww.x;
+        a.v[0] += zz.y * rr.y * ww.y;
+        a.v[1] += pp.x * qq.x * ww.x;
+        a.v[1] += pp.y * qq.y * ww.y;
+    }
+    __device__ void one(long long i, Acc<2> &a) const
+    {
+        a.v[0] += z[i] * r[i] * w[i];
+        a.v[1] += p[i] * q[i] * w[i];
+    }
+};
+
+struct FlexOp // domain.okl:195-224
+{
+    static constexpr int NV = 1;
+    const double *r, *r1, *z;
+    __device__ void vec2(long long i, Acc<1> &a) const
+    {
+        double2 a0 = ld2(r, i), a1 = ld2(r1, i), zz = ld2(z, i);
+        a.v[0] += (a1.x - a0.x) * zz.x;
+        a.v[0] += (a1.y - a0.y) * zz.y;
+    }
+    __device__ void one(long long i, Acc<1> &a) const { a.v[0] += (r1[i] - r[i]) * z[i]; }
+};
+
+struct FlexWOp // subdomain.okl:229-258
+{
+    static constexpr int NV = 1;
+    const double *r, *r1, *z, *w;
+    __device__ void vec2(long long i, Acc<1> &a) const
+    {
+        double2 a0 = ld2(r, i), a1 = ld2(r1, i), zz = ld2(z, i), ww = ld2(w, i);
+        a.v[0] += (a1.x - a0.x) * zz.x * ww.x;
+        a.v[0] += (a1.y - a0.y) * zz.y * ww.y;
+    }
+    __device__ void one(long long i, Acc<1> &a) const { a.v[0] += (r1[i] - r[i]) * z[i] * w[i]; }
+};
+
+inline bool al2(const void *a, const void *b) { return fdd_aligned16(a) && fdd_aligned16(b); }
+
+} // namespace
+
+extern "C" {
+
+size_t fdd_reduce_workspace_doubles(void) { return 2 * (size_t)FDD_REDUCE_MAX_BLOCKS; }
+
+int fdd_dom_residual_norm(double *out, double *ws, const double *r_k, const double *QQt_r_k, const double *dirichlet_mask, int num_points, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && ws != nullptr && num_points >= 0);
+    FDD_REQUIRE(num_points == 0 || (r_k != nullptr && QQt_r_k != nullptr && dirichlet_mask != nullptr));
+    return launch_reduce(Dot3Op{r_k, QQt_r_k, dirichlet_mask}, out, ws, num_points, al2(r_k, QQt_r_k) && fdd_aligned16(dirichlet_mask), stream);
+}
+
+int fdd_dom_inner_product(double *out, double *ws, const double *u_k, const double *v_k, const double *dirichlet_mask, int num_points, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && ws != nullptr && num_points >= 0);
+    FDD_REQUIRE(num_points == 0 || (u_k != nullptr && v_k != nullptr && dirichlet_mask != nullptr));
+    return launch_reduce(Dot3Op{u_k, v_k, dirichlet_mask}, out, ws, num_points, al2(u_k, v_k) && fdd_aligned16(dirichlet_mask), stream);
+}
+
+int fdd_dom_projection_inner_products(double *out2, double *ws, const double *z_k, const double *r_k, const double *p_k, const double *q_k, int num_points, void *stream)
+{
+    FDD_REQUIRE(out2 != nullptr && ws != nullptr && num_points >= 0);
+    FDD_REQUIRE(num_points == 0 || (z_k != nullptr && r_k != nullptr && p_k != nullptr && q_k != nullptr));
+    return launch_reduce(ProjOp{z_k, r_k, p_k, q_k}, out2, ws, num_points, al2(z_k, r_k) && al2(p_k, q_k), stream);
+}
+
+int fdd_dom_inner_product_flexible(double *out, double *ws, const double *r_k, const double *r_kp1, const double *z_k, int num_points, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && ws != nullptr && num_points >= 0);
+    FDD_REQUIRE(num_points == 0 || (r_k != nullptr && r_kp1 != nullptr && z_k != nullptr));
+    return launch_reduce(FlexOp{r_k, r_kp1, z_k}, out, ws, num_points, al2(r_k, r_kp1) && fdd_aligned16(z_k), stream);
+}
+
+int fdd_sub_inner_product(double *out, double *ws, const double *u, const double *v, int num_values, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && ws != nullptr && num_values >= 0);
+    FDD_REQUIRE(num_values == 0 || (u != nullptr && v != nullptr));
+    return launch_reduce(Dot2Op{u, v}, out, ws, num_values, al2(u, v), stream);
+}
+
+int fdd_sub_weighted_inner_product(double *out, double *ws, const double *u, const double *v, const double *w, int num_values, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && ws != nullptr && num_values >= 0);
+    FDD_REQUIRE(num_values == 0 || (u != nullptr && v != nullptr && w != nullptr));
+    return launch_reduce(Dot3Op{u, v, w}, out, ws, num_values, al2(u, v) && fdd_aligned16(w), stream);
+}
+
+int fdd_sub_projection_inner_products(double *out2, double *ws, const double *z_k, const double *r_k, const double *p_k, const double *q_k, const double *weight, int num_values, void *stream)
+{
+    FDD_REQUIRE(out2 != nullptr && ws != nullptr && num_values >= 0);
+    FDD_REQUIRE(num_values == 0 || (z_k != nullptr && r_k != nullptr && p_k != nullptr && q_k != nullptr && weight != nullptr));
+    return launch_reduce(ProjWOp{z_k, r_k, p_k, q_k, weight}, out2, ws, num_values, al2(z_k, r_k) && al2(p_k, q_k) && fdd_aligned16(weight), stream);
+}
+
+int fdd_sub_search_update_inner_product(double *out, double *ws, const double *r_k, const double *r_kp1, const double *z_k, const double *weight, int num_points, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && ws != nullptr && num_points >= 0);
+    FDD_REQUIRE(num_points == 0 || (r_k != nullptr && r_kp1 != nullptr && z_k != nullptr && weight != nullptr));
+    return launch_reduce(FlexWOp{r_k, r_kp1, z_k, weight}, out, ws, num_points, al2(r_k, r_kp1) && al2(z_k, weight), stream);
+}
+
+int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int size, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && ws != nullptr && size >= 0);
+    FDD_REQUIRE(size == 0 || (x != nullptr && y != nullptr));
+    return launch_reduce(Dot2Op{x, y}, out, ws, size, al2(x, y), stream);
+}
+
+} // extern "C"

@@ -1,0 +1,221 @@
+// Degree-tree restriction J^T (x) J^T (x) J^T of the FDD preconditioner
+// (subdomain.okl:284-366; driven from Subdomain::tree_operator,
+// subdomain.tpp:4576-4609).
+//
+// (1) the reference's three launches with global intermediates (any dim);
+// (2) a fused 3-D kernel: one element per workgroup pass, the n_f^3 tensor is
+//     read once into LDS, contracted along x, y, z inside LDS
+//     (n_f^3 -> n_c n_f^2 -> n_c^2 n_f -> n_c^3) and only the n_c^3 result is
+//     written: 8*(n_f^3 + n_c^3) bytes per element, HBM-bound.
+//
+// Each output is the reference's sum over l = 0..n_f-1 from 0.0 in that order,
+// so with -ffp-contract=off both forms are bit-identical to OCCA-Serial.
+#include "fdd_common.h"
+
+namespace
+{
+
+constexpr int kBlock = 256;
+
+template <int DIM>
+__global__ __launch_bounds__(kBlock) void restriction_1_kernel(double *__restrict__ Ju, const double *__restrict__ J_cf, const double *__restrict__ u, int num_points, int n_f, int n_c)
+{
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= num_points) return;
+
+    const int num_elem_points_fine = (DIM == 2) ? n_f * n_f : n_f * n_f * n_f;
+    const int num_elem_points_coarse = (DIM == 2) ? n_f * n_c : n_f * n_f * n_c;
+    const int e = idx / num_elem_points_coarse;
+    const int v = idx % num_elem_points_coarse;
+    const double *ue = u + (size_t)e * num_elem_points_fine;
+    double *Je = Ju + (size_t)e * num_elem_points_coarse;
+    double Ju_ij = 0.0;
+
+    if (DIM == 2)
+    {
+        const int i = v % n_f;
+        const int j = v / n_f;
+        for (int k = 0; k < n_f; k++) Ju_ij += J_cf[j + k * n_c] * ue[i + k * n_f];
+        Je[i + j * n_f] = Ju_ij;
+    }
+    else
+    {
+        const int i = v % n_c;
+        const int j = (v / n_c) % n_f;
+        const int k = v / (n_c * n_f);
+        for (int l = 0; l < n_f; l++) Ju_ij += J_cf[i + l * n_c] * ue[l + j * n_f + k * (n_f * n_f)];
+        Je[i + j * n_c + k * (n_c * n_f)] = Ju_ij;
+    }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(kBlock) void restriction_2_kernel(double *__restrict__ Ju, const double *__restrict__ J_cf, const double *__restrict__ u, int num_points, int n_f, int n_c)
+{
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= num_points) return;
+
+    const int num_elem_points_fine = (DIM == 2) ? n_f * n_c : n_f * n_f * n_c;
+    const int num_elem_points_coarse = (DIM == 2) ? n_c * n_c : n_f * n_c * n_c;
+    const int e = idx / num_elem_points_coarse;
+    const int v = idx % num_elem_points_coarse;
+    const double *ue = u + (size_t)e * num_elem_points_fine;
+    double *Je = Ju + (size_t)e * num_elem_points_coarse;
+    double Ju_ij = 0.0;
+
+    if (DIM == 2)
+    {
+        const int i = v % n_c;
+        const int j = v / n_c;
+        for (int k = 0; k < n_f; k++) Ju_ij += ue[j * n_f + k] * J_cf[k * n_c + i];
+        Je[i + j * n_c] = Ju_ij;
+    }
+    else
+    {
+        const int i = v % n_c;
+        const int j = (v / n_c) % n_c;
+        const int k = v / (n_c * n_c);
+        for (int l = 0; l < n_f; l++) Ju_ij += J_cf[j + l * n_c] * ue[i + l * n_c + k * (n_c * n_f)];
+        Je[i + j * n_c + k * (n_c * n_c)] = Ju_ij;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void restriction_3_kernel(double *__restrict__ Ju, const double *__restrict__ J_cf, const double *__restrict__ u, int num_points, int n_f, int n_c)
+{
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= num_points) return;
+
+    const int num_elem_points_fine = n_f * n_c * n_c;
+    const int num_elem_points_coarse = n_c * n_c * n_c;
+    const int e = idx / num_elem_points_coarse;
+    const int v = idx % num_elem_points_coarse;
+    const double *ue = u + (size_t)e * num_elem_points_fine;
+    double Ju_ij = 0.0;
+
+    const int i = v % n_c;
+    const int j = (v / n_c) % n_c;
+    const int k = v / (n_c * n_c);
+    for (int l = 0; l < n_f; l++) Ju_ij += J_cf[k + l * n_c] * ue[i + j * n_c + l * (n_c * n_c)];
+    Ju[(size_t)e * num_elem_points_coarse + i + j * n_c + k * (n_c * n_c)] = Ju_ij;
+}
+
+// Fused: grid-stride over elements, dynamic LDS = (n_f*n_c + n_f^3 + n_c*n_f^2) doubles.
+// Buffer A holds u (n_f^3) and later the y-contracted tensor (n_c^2 n_f);
+// buffer B holds the x-contracted tensor (n_c n_f^2).
+__global__ __launch_bounds__(kBlock) void restriction_fused_kernel(double *__restrict__ u_c, const double *__restrict__ J_cf, const double *__restrict__ u_f, int num_elements, int n_f, int n_c)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *sJ = smem;                  // n_f * n_c
+    double *sA = sJ + n_f * n_c;        // n_f^3
+    double *sB = sA + n_f * n_f * n_f;  // n_c * n_f^2
+
+    const int nf2 = n_f * n_f;
+    const int nf3 = nf2 * n_f;
+    const int nc2 = n_c * n_c;
+    const int nc3 = nc2 * n_c;
+    const int s1 = n_c * nf2; // after x
+    const int s2 = nc2 * n_f; // after y
+
+    for (int t = threadIdx.x; t < n_f * n_c; t += kBlock) sJ[t] = J_cf[t];
+
+    for (int e = blockIdx.x; e < num_elements; e += gridDim.x)
+    {
+        const double *ue = u_f + (size_t)e * nf3;
+        __syncthreads(); // previous element's readers of sA are done; sJ visible
+        for (int t = threadIdx.x; t < nf3; t += kBlock) sA[t] = ue[t];
+        __syncthreads();
+
+        // restriction_1: (l, j, k) -> (i, j, k), i < n_c
+        for (int v = threadIdx.x; v < s1; v += kBlock)
+        {
+            const int i = v % n_c;
+            const int j = (v / n_c) % n_f;
+            const int k = v / (n_c * n_f);
+            double s = 0.0;
+            for (int l = 0; l < n_f; l++) s += sJ[i + l * n_c] * sA[l + j * n_f + k * nf2];
+            sB[i + j * n_c + k * (n_c * n_f)] = s;
+        }
+        __syncthreads();
+
+        // restriction_2: (i, l, k) -> (i, j, k), j < n_c
+        for (int v = threadIdx.x; v < s2; v += kBlock)
+        {
+            const int i = v % n_c;
+            const int j = (v / n_c) % n_c;
+            const int k = v / nc2;
+            double s = 0.0;
+            for (int l = 0; l < n_f; l++) s += sJ[j + l * n_c] * sB[i + l * n_c + k * (n_c * n_f)];
+            sA[i + j * n_c + k * nc2] = s;
+        }
+        __syncthreads();
+
+        // restriction_3: (i, j, l) -> (i, j, k), k < n_c
+        for (int v = threadIdx.x; v < nc3; v += kBlock)
+        {
+            const int i = v % n_c;
+            const int j = (v / n_c) % n_c;
+            const int k = v / nc2;
+            double s = 0.0;
+            for (int l = 0; l < n_f; l++) s += sJ[k + l * n_c] * sA[i + j * n_c + l * nc2];
+            u_c[(size_t)e * nc3 + v] = s;
+        }
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int fdd_sub_restriction_1(double *Ju, const double *J_cf, const double *u, int num_points, int n_f, int n_c, int dim, void *stream)
+{
+    FDD_REQUIRE(num_points >= 0 && n_f >= 1 && n_c >= 1 && (dim == 2 || dim == 3));
+    if (num_points == 0) return 0;
+    FDD_REQUIRE(Ju != nullptr && J_cf != nullptr && u != nullptr);
+    const int grid = (num_points + kBlock - 1) / kBlock;
+    if (dim == 2)
+        hipLaunchKernelGGL(restriction_1_kernel<2>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Ju, J_cf, u, num_points, n_f, n_c);
+    else
+        hipLaunchKernelGGL(restriction_1_kernel<3>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Ju, J_cf, u, num_points, n_f, n_c);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fdd_sub_restriction_2(double *Ju, const double *J_cf, const double *u, int num_points, int n_f, int n_c, int dim, void *stream)
+{
+    FDD_REQUIRE(num_points >= 0 && n_f >= 1 && n_c >= 1 && (dim == 2 || dim == 3));
+    if (num_points == 0) return 0;
+    FDD_REQUIRE(Ju != nullptr && J_cf != nullptr && u != nullptr);
+    const int grid = (num_points + kBlock - 1) / kBlock;
+    if (dim == 2)
+        hipLaunchKernelGGL(restriction_2_kernel<2>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Ju, J_cf, u, num_points, n_f, n_c);
+    else
+        hipLaunchKernelGGL(restriction_2_kernel<3>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Ju, J_cf, u, num_points, n_f, n_c);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fdd_sub_restriction_3(double *Ju, const double *J_cf, const double *u, int num_points, int n_f, int n_c, void *stream)
+{
+    FDD_REQUIRE(num_points >= 0 && n_f >= 1 && n_c >= 1);
+    if (num_points == 0) return 0;
+    FDD_REQUIRE(Ju != nullptr && J_cf != nullptr && u != nullptr);
+    const int grid = (num_points + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(restriction_3_kernel, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Ju, J_cf, u, num_points, n_f, n_c);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fdd_sub_restriction(double *u_c, const double *J_cf, const double *u_f, int num_elements, int n_f, int n_c, void *stream)
+{
+    FDD_REQUIRE(num_elements >= 0 && n_f >= 1 && n_c >= 1 && n_c <= n_f && n_f <= 16);
+    if (num_elements == 0) return 0;
+    FDD_REQUIRE(u_c != nullptr && J_cf != nullptr && u_f != nullptr);
+    const size_t lds = sizeof(double) * ((size_t)n_f * n_c + (size_t)n_f * n_f * n_f + (size_t)n_c * n_f * n_f);
+    const int grid = num_elements < 8 * FDD_CU_COUNT ? num_elements : 8 * FDD_CU_COUNT;
+    if (lds > 48 * 1024)
+        FDD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(restriction_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(restriction_fused_kernel, dim3(grid), dim3(kBlock), lds, fdd_stream(stream), u_c, J_cf, u_f, num_elements, n_f, n_c);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,514 @@
+// Matrix-free SEM stiffness Au = D^T G D u on GLL points, gfx950.
+// Replaces domain.okl:5-98 (uniform degree) and subdomain.okl:4-101 (mixed
+// degree with per-point indirection).
+//
+// (1) Reference two-launch form (stiffness_matrix_1 / _2, one lane per point,
+//     global scratch GDu): kept for API parity, for 2-D and for any degree.
+//     112 B/point of HBM traffic.
+//
+// (2) Fused kernel (fdd_dom_stiffness_matrix / fdd_sub_stiffness_matrix):
+//     64 B/point (u 8 + six geometric factors 48 + Au 8).  An element of
+//     n = N+1 points per edge is owned by n*n lanes, lane (i,j) keeps its
+//     k-column of u in registers.  For each k-slab the slab of u and then the
+//     slabs of G*Du are staged through LDS (rows padded by one double: bank
+//     conflict free for 8-B reads), x/y contractions read LDS, the z
+//     contraction stays in registers.  With n = 8 an element is exactly one
+//     64-lane wavefront and a 256-lane workgroup holds four elements.
+//
+//     Every output keeps the reference's operation order: Du_d and Au_d are
+//     summed over p = 0..n-1 from 0.0, G*Du is evaluated left to right,
+//     Au = (Au_1 + Au_2) + Au_3.  With -ffp-contract=off the fused kernel is
+//     bit-identical to the two-launch form and to the OCCA-Serial arithmetic.
+//
+// Both are HBM-bound: 12n+17 flop/point is 1.77 flop/B at N=7.
+#include "fdd_common.h"
+
+namespace
+{
+
+constexpr int kBlock = 256;
+
+struct GPtrs
+{
+    const double *g[FDD_NUM_GEOM_FACTS];
+};
+struct GDuPtrs
+{
+    double *g[3];
+};
+struct LevelTable
+{
+    const double *D_hat[16];
+    int poly_degree[16];
+};
+
+// ---------------------------------------------------------------------------
+// (1) reference form, uniform degree: domain.okl:5-52 / :54-98
+// ---------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(kBlock) void dom_stiffness_1_kernel(GDuPtrs GDu, const double *__restrict__ u, const double *__restrict__ D_hat, GPtrs G, int num_points, int n_x)
+{
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= num_points) return;
+
+    const int n_xy = n_x * n_x;
+    const int num_elem_points = (DIM == 2) ? n_xy : n_xy * n_x;
+    const int e = idx / num_elem_points;
+    const int v = idx % num_elem_points;
+    const double *ue = u + (size_t)e * num_elem_points;
+
+    if (DIM == 2)
+    {
+        const int i = v % n_x;
+        const int j = v / n_x;
+        double Du_1 = 0.0, Du_2 = 0.0;
+        for (int k = 0; k < n_x; k++)
+        {
+            Du_1 += D_hat[k + i * n_x] * ue[k + j * n_x];
+            Du_2 += D_hat[k + j * n_x] * ue[i + k * n_x];
+        }
+        GDu.g[0][idx] = G.g[0][idx] * Du_1 + G.g[2][idx] * Du_2;
+        GDu.g[1][idx] = G.g[2][idx] * Du_1 + G.g[1][idx] * Du_2;
+    }
+    else
+    {
+        const int i = v % n_x;
+        const int j = (v / n_x) % n_x;
+        const int k = v / n_xy;
+        double Du_1 = 0.0, Du_2 = 0.0, Du_3 = 0.0;
+        for (int p = 0; p < n_x; p++)
+        {
+            Du_1 += D_hat[p + i * n_x] * ue[p + j * n_x + k * n_xy];
+            Du_2 += D_hat[p + j * n_x] * ue[i + p * n_x + k * n_xy];
+            Du_3 += D_hat[p + k * n_x] * ue[i + j * n_x + p * n_xy];
+        }
+        GDu.g[0][idx] = G.g[0][idx] * Du_1 + G.g[3][idx] * Du_2 + G.g[4][idx] * Du_3;
+        GDu.g[1][idx] = G.g[3][idx] * Du_1 + G.g[1][idx] * Du_2 + G.g[5][idx] * Du_3;
+        GDu.g[2][idx] = G.g[4][idx] * Du_1 + G.g[5][idx] * Du_2 + G.g[2][idx] * Du_3;
+    }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(kBlock) void dom_stiffness_2_kernel(double *__restrict__ Au, GDuPtrs GDu, const double *__restrict__ D_hat, int num_points, int n_x)
+{
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= num_points) return;
+
+    const int n_xy = n_x * n_x;
+    const int num_elem_points = (DIM == 2) ? n_xy : n_xy * n_x;
+    const int e = idx / num_elem_points;
+    const int v = idx % num_elem_points;
+    const size_t o = (size_t)e * num_elem_points;
+
+    if (DIM == 2)
+    {
+        const int i = v % n_x;
+        const int j = v / n_x;
+        double Au_1 = 0.0, Au_2 = 0.0;
+        for (int k = 0; k < n_x; k++)
+        {
+            Au_1 += D_hat[i + k * n_x] * GDu.g[0][o + (k + j * n_x)];
+            Au_2 += D_hat[j + k * n_x] * GDu.g[1][o + (i + k * n_x)];
+        }
+        Au[idx] = Au_1 + Au_2;
+    }
+    else
+    {
+        const int i = v % n_x;
+        const int j = (v / n_x) % n_x;
+        const int k = v / n_xy;
+        double Au_1 = 0.0, Au_2 = 0.0, Au_3 = 0.0;
+        for (int p = 0; p < n_x; p++)
+        {
+            Au_1 += D_hat[i + p * n_x] * GDu.g[0][o + (p + j * n_x + k * n_xy)];
+            Au_2 += D_hat[j + p * n_x] * GDu.g[1][o + (i + p * n_x + k * n_xy)];
+            Au_3 += D_hat[k + p * n_x] * GDu.g[2][o + (i + j * n_x + p * n_xy)];
+        }
+        Au[idx] = Au_1 + Au_2 + Au_3;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// (1') reference form, per-point indirection: subdomain.okl:4-53 / :55-101
+// ---------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(kBlock) void sub_stiffness_1_kernel(GDuPtrs GDu, const double *__restrict__ u, LevelTable T, const int *__restrict__ offset, const int *__restrict__ vert, const int *__restrict__ level, GPtrs G, int num_points)
+{
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= num_points) return;
+
+    const int o = offset[idx];
+    const int v = vert[idx];
+    const int l = level[idx];
+    const int n_x = T.poly_degree[l] + 1;
+    const int n_xy = n_x * n_x;
+    const double *D_hat = T.D_hat[l];
+
+    if (DIM == 2)
+    {
+        const int i = v % n_x;
+        const int j = v / n_x;
+        double Du_1 = 0.0, Du_2 = 0.0;
+        for (int k = 0; k < n_x; k++)
+        {
+            Du_1 += D_hat[k + i * n_x] * u[o + (k + j * n_x)];
+            Du_2 += D_hat[k + j * n_x] * u[o + (i + k * n_x)];
+        }
+        GDu.g[0][idx] = G.g[0][idx] * Du_1 + G.g[2][idx] * Du_2;
+        GDu.g[1][idx] = G.g[2][idx] * Du_1 + G.g[1][idx] * Du_2;
+    }
+    else
+    {
+        const int i = v % n_x;
+        const int j = (v / n_x) % n_x;
+        const int k = v / n_xy;
+        double Du_1 = 0.0, Du_2 = 0.0, Du_3 = 0.0;
+        for (int p = 0; p < n_x; p++)
+        {
+            Du_1 += D_hat[p + i * n_x] * u[o + (p + j * n_x + k * n_xy)];
+            Du_2 += D_hat[p + j * n_x] * u[o + (i + p * n_x + k * n_xy)];
+            Du_3 += D_hat[p + k * n_x] * u[o + (i + j * n_x + p * n_xy)];
+        }
+        GDu.g[0][idx] = G.g[0][idx] * Du_1 + G.g[3][idx] * Du_2 + G.g[4][idx] * Du_3;
+        GDu.g[1][idx] = G.g[3][idx] * Du_1 + G.g[1][idx] * Du_2 + G.g[5][idx] * Du_3;
+        GDu.g[2][idx] = G.g[4][idx] * Du_1 + G.g[5][idx] * Du_2 + G.g[2][idx] * Du_3;
+    }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(kBlock) void sub_stiffness_2_kernel(double *__restrict__ Au, GDuPtrs GDu, LevelTable T, const int *__restrict__ offset, const int *__restrict__ vert, const int *__restrict__ level, int num_points)
+{
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= num_points) return;
+
+    const int o = offset[idx];
+    const int v = vert[idx];
+    const int l = level[idx];
+    const int n_x = T.poly_degree[l] + 1;
+    const int n_xy = n_x * n_x;
+    const double *D_hat = T.D_hat[l];
+
+    if (DIM == 2)
+    {
+        const int i = v % n_x;
+        const int j = v / n_x;
+        double Au_1 = 0.0, Au_2 = 0.0;
+        for (int k = 0; k < n_x; k++)
+        {
+            Au_1 += D_hat[i + k * n_x] * GDu.g[0][o + (k + j * n_x)];
+            Au_2 += D_hat[j + k * n_x] * GDu.g[1][o + (i + k * n_x)];
+        }
+        Au[idx] = Au_1 + Au_2;
+    }
+    else
+    {
+        const int i = v % n_x;
+        const int j = (v / n_x) % n_x;
+        const int k = v / n_xy;
+        double Au_1 = 0.0, Au_2 = 0.0, Au_3 = 0.0;
+        for (int p = 0; p < n_x; p++)
+        {
+            Au_1 += D_hat[i + p * n_x] * GDu.g[0][o + (p + j * n_x + k * n_xy)];
+            Au_2 += D_hat[j + p * n_x] * GDu.g[1][o + (i + p * n_x + k * n_xy)];
+            Au_3 += D_hat[k + p * n_x] * GDu.g[2][o + (i + j * n_x + p * n_xy)];
+        }
+        Au[idx] = Au_1 + Au_2 + Au_3;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// (2) fused kernel, 3-D, n = N+1 in [2, 16]
+// ---------------------------------------------------------------------------
+template <int n>
+struct FusedCfg
+{
+    static constexpr int nn = n * n;
+    static constexpr int epb = (kBlock / nn) > 0 ? (kBlock / nn) : 1; // elements per workgroup
+    static constexpr int ld = n + 1;                                  // padded LDS row
+    static constexpr int slab = n * ld;
+};
+
+template <int n>
+__global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
+{
+    using C = FusedCfg<n>;
+    constexpr int nn = C::nn;
+    constexpr int n3 = nn * n;
+    // D_hat rows/columns a lane needs in every slab live in registers up to
+    // n = 8 (4 x 8 doubles); above that they are re-read from LDS per slab.
+    constexpr bool kDReg = (n <= 8);
+    constexpr int nd = kDReg ? n : 1;
+
+    __shared__ double s_D[n * n];
+    __shared__ double s_u[C::epb][C::slab];
+    __shared__ double s_g1[C::epb][C::slab];
+    __shared__ double s_g2[C::epb][C::slab];
+    __shared__ double s_12[C::epb][n3]; // Au_1 + Au_2 per point, until Au_3 is complete
+
+    const int tid = threadIdx.x;
+    const int e_loc = tid / nn;
+    const int ij = tid - e_loc * nn;
+    const int j = ij / n;
+    const int i = ij - j * n;
+    const int elem = blockIdx.x * C::epb + e_loc;
+    const bool active = (e_loc < C::epb) && (elem < num_elements);
+
+    for (int t = tid; t < n * n; t += kBlock) s_D[t] = D_hat[t];
+
+    size_t base = 0;
+    if (active) base = elem_offset ? (size_t)elem_offset[elem] : (size_t)elem * n3;
+
+    // this lane's k-column of u (z contraction stays in registers)
+    double r_u[n], r_3[n];
+#pragma unroll
+    for (int k = 0; k < n; k++)
+    {
+        r_u[k] = active ? u[base + ij + k * nn] : 0.0;
+        r_3[k] = 0.0;
+    }
+
+    __syncthreads();
+
+    double D_i[nd], D_j[nd], Dt_i[nd], Dt_j[nd];
+    if (kDReg)
+    {
+#pragma unroll
+        for (int p = 0; p < nd; p++)
+        {
+            D_i[p] = s_D[p + i * n];  // D_hat[p + i*n_x]: pass 1, x
+            D_j[p] = s_D[p + j * n];  // D_hat[p + j*n_x]: pass 1, y
+            Dt_i[p] = s_D[i + p * n]; // D_hat[i + p*n_x]: pass 2, x
+            Dt_j[p] = s_D[j + p * n]; // D_hat[j + p*n_x]: pass 2, y
+        }
+    }
+
+    const int el = active ? e_loc : 0;
+    double *su = s_u[el];
+    double *sg1 = s_g1[el];
+    double *sg2 = s_g2[el];
+    double *s12 = s_12[el];
+
+    // The slab loop is deliberately NOT unrolled: unrolled, every D_hat entry
+    // becomes loop-invariant register state (> 256 VGPRs and scratch spills).
+#pragma unroll 1
+    for (int k = 0; k < n; k++)
+    {
+        // geometric factors of this slab: issued first, consumed after the
+        // x/y/z contractions
+        double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0, g4 = 0.0, g5 = 0.0, uk = 0.0;
+        if (active)
+        {
+            const size_t idx = base + ij + k * nn;
+            uk = u[idx]; // L1/L2 hit: the column was just read into r_u
+            g0 = G.g[0][idx];
+            g1 = G.g[1][idx];
+            g2 = G.g[2][idx];
+            g3 = G.g[3][idx];
+            g4 = G.g[4][idx];
+            g5 = G.g[5][idx];
+            su[i + j * C::ld] = uk;
+        }
+
+        // row k of D_hat: wave-uniform address -> scalar loads, lives in SGPRs
+        double Dk[n];
+#pragma unroll
+        for (int p = 0; p < n; p++) Dk[p] = D_hat[p + k * n];
+
+        // opaque copies of i, j stop the compiler from hoisting the D_hat LDS
+        // reads out of the slab loop when they are not meant to be registers
+        int io = i, jo = j;
+        if (!kDReg) asm volatile("" : "+v"(io), "+v"(jo));
+
+        __syncthreads();
+
+        double Du_1 = 0.0, Du_2 = 0.0, Du_3 = 0.0;
+#pragma unroll
+        for (int p = 0; p < n; p++)
+        {
+            const double di = kDReg ? D_i[kDReg ? p : 0] : s_D[p + io * n];
+            const double dj = kDReg ? D_j[kDReg ? p : 0] : s_D[p + jo * n];
+            Du_1 += di * su[p + j * C::ld];
+            Du_2 += dj * su[i + p * C::ld];
+            Du_3 += Dk[p] * r_u[p];
+        }
+
+        const double GDu_1 = g0 * Du_1 + g3 * Du_2 + g4 * Du_3;
+        const double GDu_2 = g3 * Du_1 + g1 * Du_2 + g5 * Du_3;
+        const double GDu_3 = g4 * Du_1 + g5 * Du_2 + g2 * Du_3;
+
+        if (active)
+        {
+            sg1[i + j * C::ld] = GDu_1;
+            sg2[i + j * C::ld] = GDu_2;
+        }
+        __syncthreads();
+
+        double Au_1 = 0.0, Au_2 = 0.0;
+#pragma unroll
+        for (int p = 0; p < n; p++)
+        {
+            const double dti = kDReg ? Dt_i[kDReg ? p : 0] : s_D[io + p * n];
+            const double dtj = kDReg ? Dt_j[kDReg ? p : 0] : s_D[jo + p * n];
+            Au_1 += dti * sg1[p + j * C::ld];
+            Au_2 += dtj * sg2[i + p * C::ld];
+        }
+        if (active) s12[ij + k * nn] = Au_1 + Au_2;
+
+        // Au_3(i,j,m) += D_hat[m + k*n_x] * GDu_3(i,j,k): the reference's p = k term
+#pragma unroll
+        for (int m = 0; m < n; m++) r_3[m] += Dk[m] * GDu_3;
+    }
+
+    if (active)
+    {
+        // s12 entries are read back by the lane that wrote them
+#pragma unroll
+        for (int k = 0; k < n; k++) Au[base + ij + k * nn] = s12[ij + k * nn] + r_3[k];
+    }
+}
+
+template <int n>
+int launch_fused(double *Au, const double *u, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
+{
+    using C = FusedCfg<n>;
+    const int grid = (num_elements + C::epb - 1) / C::epb;
+    hipLaunchKernelGGL(fused_stiffness_kernel<n>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, D_hat, G, elem_offset, num_elements);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fused_dispatch(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    FDD_REQUIRE(num_elements >= 0);
+    if (num_elements == 0) return 0;
+    FDD_REQUIRE(Au != nullptr && u != nullptr && D_hat != nullptr && G != nullptr);
+    GPtrs g;
+    for (int k = 0; k < FDD_NUM_GEOM_FACTS; k++)
+    {
+        FDD_REQUIRE(G[k] != nullptr);
+        g.g[k] = G[k];
+    }
+
+    switch (poly_degree + 1)
+    {
+    case 2: return launch_fused<2>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 3: return launch_fused<3>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 4: return launch_fused<4>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 5: return launch_fused<5>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 6: return launch_fused<6>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 7: return launch_fused<7>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 8: return launch_fused<8>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 9: return launch_fused<9>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 10: return launch_fused<10>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 11: return launch_fused<11>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 12: return launch_fused<12>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 13: return launch_fused<13>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 14: return launch_fused<14>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 15: return launch_fused<15>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 16: return launch_fused<16>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    default:
+        fdd_set_error("fused stiffness kernel supports poly_degree 1..15, got %d (use the two-launch form)", poly_degree);
+        return FDD_ERR_UNSUPPORTED;
+    }
+}
+
+int fill_level_table(LevelTable &T, const double *const *D_hat_ptr, const int *poly_degree, int num_levels)
+{
+    FDD_REQUIRE(D_hat_ptr != nullptr && poly_degree != nullptr && num_levels >= 1 && num_levels <= 16);
+    for (int l = 0; l < 16; l++)
+    {
+        T.D_hat[l] = (l < num_levels) ? D_hat_ptr[l] : nullptr;
+        T.poly_degree[l] = (l < num_levels) ? poly_degree[l] : 0;
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int fdd_dom_stiffness_matrix_1(double *const GDu[3], const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], int num_points, int poly_degree, int dim, void *stream)
+{
+    FDD_REQUIRE(num_points >= 0 && poly_degree >= 1 && (dim == 2 || dim == 3));
+    if (num_points == 0) return 0;
+    FDD_REQUIRE(GDu != nullptr && u != nullptr && D_hat != nullptr && G != nullptr);
+    GDuPtrs gd;
+    GPtrs g;
+    for (int k = 0; k < 3; k++) gd.g[k] = GDu[k];
+    for (int k = 0; k < FDD_NUM_GEOM_FACTS; k++) g.g[k] = G[k];
+    const int grid = (num_points + kBlock - 1) / kBlock;
+    if (dim == 2)
+        hipLaunchKernelGGL(dom_stiffness_1_kernel<2>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), gd, u, D_hat, g, num_points, poly_degree + 1);
+    else
+        hipLaunchKernelGGL(dom_stiffness_1_kernel<3>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), gd, u, D_hat, g, num_points, poly_degree + 1);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fdd_dom_stiffness_matrix_2(double *Au, const double *const GDu[3], const double *D_hat, int num_points, int poly_degree, int dim, void *stream)
+{
+    FDD_REQUIRE(num_points >= 0 && poly_degree >= 1 && (dim == 2 || dim == 3));
+    if (num_points == 0) return 0;
+    FDD_REQUIRE(Au != nullptr && GDu != nullptr && D_hat != nullptr);
+    GDuPtrs gd;
+    for (int k = 0; k < 3; k++) gd.g[k] = const_cast<double *>(GDu[k]);
+    const int grid = (num_points + kBlock - 1) / kBlock;
+    if (dim == 2)
+        hipLaunchKernelGGL(dom_stiffness_2_kernel<2>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, gd, D_hat, num_points, poly_degree + 1);
+    else
+        hipLaunchKernelGGL(dom_stiffness_2_kernel<3>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, gd, D_hat, num_points, poly_degree + 1);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fdd_dom_stiffness_matrix(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], int num_elements, int poly_degree, void *stream)
+{
+    return fused_dispatch(Au, u, D_hat, G, nullptr, num_elements, poly_degree, stream);
+}
+
+int fdd_sub_stiffness_matrix(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    return fused_dispatch(Au, u, D_hat, G, elem_offset, num_elements, poly_degree, stream);
+}
+
+int fdd_sub_stiffness_matrix_1(double *const GDu[3], const double *u, const double *const *D_hat_ptr, const int *offset, const int *vert, const int *level, const int *poly_degree, int num_levels, const double *const G[FDD_NUM_GEOM_FACTS], int num_points, int dim, void *stream)
+{
+    FDD_REQUIRE(num_points >= 0 && (dim == 2 || dim == 3));
+    if (num_points == 0) return 0;
+    FDD_REQUIRE(GDu != nullptr && u != nullptr && offset != nullptr && vert != nullptr && level != nullptr && G != nullptr);
+    LevelTable T;
+    int rc = fill_level_table(T, D_hat_ptr, poly_degree, num_levels);
+    if (rc) return rc;
+    GDuPtrs gd;
+    GPtrs g;
+    for (int k = 0; k < 3; k++) gd.g[k] = GDu[k];
+    for (int k = 0; k < FDD_NUM_GEOM_FACTS; k++) g.g[k] = G[k];
+    const int grid = (num_points + kBlock - 1) / kBlock;
+    if (dim == 2)
+        hipLaunchKernelGGL(sub_stiffness_1_kernel<2>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), gd, u, T, offset, vert, level, g, num_points);
+    else
+        hipLaunchKernelGGL(sub_stiffness_1_kernel<3>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), gd, u, T, offset, vert, level, g, num_points);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fdd_sub_stiffness_matrix_2(double *Au, const double *const GDu[3], const double *const *D_hat_ptr, const int *offset, const int *vert, const int *level, const int *poly_degree, int num_levels, int num_points, int dim, void *stream)
+{
+    FDD_REQUIRE(num_points >= 0 && (dim == 2 || dim == 3));
+    if (num_points == 0) return 0;
+    FDD_REQUIRE(Au != nullptr && GDu != nullptr && offset != nullptr && vert != nullptr && level != nullptr);
+    LevelTable T;
+    int rc = fill_level_table(T, D_hat_ptr, poly_degree, num_levels);
+    if (rc) return rc;
+    GDuPtrs gd;
+    for (int k = 0; k < 3; k++) gd.g[k] = const_cast<double *>(GDu[k]);
+    const int grid = (num_points + kBlock - 1) / kBlock;
+    if (dim == 2)
+        hipLaunchKernelGGL(sub_stiffness_2_kernel<2>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, gd, T, offset, vert, level, num_points);
+    else
+        hipLaunchKernelGGL(sub_stiffness_2_kernel<3>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, gd, T, offset, vert, level, num_points);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,389 @@
+"""Test support: ctypes binding of the CPU oracle, GLL golden tables, and an
+independent numpy generator of the synthetic box mesh.
+
+The oracle is the CHECKER only; nothing here is imported by the product.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libfdd_oracle.so")
+SPECLIB_REF_SO = os.path.join(ORACLE_DIR, "_ref", "libspeclib_ref.so")
+GOLDEN_DIR = os.path.join(HERE, "golden")
+
+c_int_p = ctypes.POINTER(ctypes.c_int)
+vp = ctypes.c_void_p
+
+
+def _p(a):
+    if a is None:
+        return vp(0)
+    assert a.flags["C_CONTIGUOUS"]
+    return vp(a.ctypes.data)
+
+
+class OrcCsr(ctypes.Structure):
+    _fields_ = [
+        ("num_rows", ctypes.c_int),
+        ("num_cols", ctypes.c_int),
+        ("num_nnz", ctypes.c_int),
+        ("ptr", c_int_p),
+        ("col", c_int_p),
+        ("val", ctypes.POINTER(ctypes.c_double)),
+    ]
+
+    def to_numpy(self):
+        ptr = np.ctypeslib.as_array(self.ptr, shape=(self.num_rows + 1,)).copy()
+        if self.num_nnz:
+            col = np.ctypeslib.as_array(self.col, shape=(self.num_nnz,)).copy()
+            val = np.ctypeslib.as_array(self.val, shape=(self.num_nnz,)).copy()
+        else:
+            col = np.zeros(0, np.int32)
+            val = np.zeros(0)
+        return ptr, col, val
+
+
+class OrcMesh(ctypes.Structure):
+    _fields_ = [
+        ("dim", ctypes.c_int),
+        ("poly_degree", ctypes.c_int),
+        ("num_local_elements", ctypes.c_int),
+        ("x", vp),
+        ("y", vp),
+        ("z", vp),
+        ("glo_num", vp),
+        ("node_degree", vp),
+        ("p_mask", vp),
+        ("g", vp * 6),
+    ]
+
+
+PRECOND_FN = ctypes.CFUNCTYPE(None, vp, ctypes.POINTER(vp), ctypes.POINTER(vp))
+
+
+class OrcSolverOpts(ctypes.Structure):
+    _fields_ = [
+        ("max_iterations", ctypes.c_int),
+        ("num_vectors", ctypes.c_int),
+        ("tolerance", ctypes.c_double),
+        ("use_relative", ctypes.c_int),
+        ("precond", PRECOND_FN),
+        ("precond_ctx", vp),
+    ]
+
+
+class OrcSubdomainOpts(ctypes.Structure):
+    _fields_ = [
+        ("num_vectors", ctypes.c_int),
+        ("max_iterations", ctypes.c_int),
+        ("tolerance", ctypes.c_double),
+        ("use_preconditioner", ctypes.c_int),
+    ]
+
+
+_oracle = None
+
+
+def oracle():
+    """Load (building if needed) the CPU oracle."""
+    global _oracle
+    if _oracle is None:
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+        stale = (not os.path.exists(ORACLE_SO)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs)
+        if stale:
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+        L = ctypes.CDLL(ORACLE_SO)
+        L.orc_block_sum.restype = ctypes.c_double
+        L.orc_world_create.restype = vp
+        L.orc_world_Q.restype = ctypes.POINTER(OrcCsr)
+        L.orc_world_Qt.restype = ctypes.POINTER(OrcCsr)
+        L.orc_world_assembled_weight.restype = ctypes.POINTER(ctypes.c_double)
+        L.orc_world_residual_norm.restype = ctypes.c_double
+        L.orc_world_assembled_inner_product.restype = ctypes.c_double
+        L.orc_subdomain_create.restype = vp
+        L.orc_subdomain_residual_norm.restype = ctypes.c_double
+        _oracle = L
+    return _oracle
+
+
+# --------------------------------------------------------------------------
+# GLL tables
+# --------------------------------------------------------------------------
+_tables = None
+
+
+def gll_tables():
+    global _tables
+    if _tables is None:
+        with open(os.path.join(GOLDEN_DIR, "gll_tables.json")) as fh:
+            _tables = json.load(fh)
+    return _tables
+
+
+def gll(N):
+    t = gll_tables()["levels"][str(N)]
+    return np.array(t["z"]), np.array(t["w"]), np.array(t["D_hat"])
+
+
+def J_cf(N_c, N_f):
+    return np.array(gll_tables()["J_cf"][f"{N_c},{N_f}"])
+
+
+def level_degrees(N, reduction):
+    """subdomain.tpp:98-110"""
+    deg = [N]
+    while deg[-1] > 1:
+        deg.append(max(deg[-1] - reduction, 1))
+    return deg
+
+
+# --------------------------------------------------------------------------
+# synthetic box mesh (independent numpy statement of SURVEY.md section 8(d))
+# --------------------------------------------------------------------------
+class BoxMesh:
+    """Unit cube, E = (Ex,Ey,Ez) global elements split into (Px,Py,Pz) rank
+    blocks; this object is rank `rank`'s part at degree N.  Arrays are
+    element-major with x fastest inside an element, exactly what
+    Domain::initialize reads (domain.tpp:45-224)."""
+
+    def __init__(self, E, N, P=(1, 1, 1), rank=0):
+        E = tuple(E)
+        P = tuple(P)
+        self.E, self.N, self.P, self.rank = E, N, P, rank
+        n = N + 1
+        z, w, _ = gll(N)
+        Ex, Ey, Ez = E
+        Px, Py, Pz = P
+        assert Ex % Px == 0 and Ey % Py == 0 and Ez % Pz == 0
+        lx, ly, lz = Ex // Px, Ey // Py, Ez // Pz
+        rx, ry, rz = rank % Px, (rank // Px) % Py, rank // (Px * Py)
+        self.local_E = (lx, ly, lz)
+        self.origin = (rx * lx, ry * ly, rz * lz)
+        ne = lx * ly * lz
+        self.num_local_elements = ne
+        self.num_elem_points = n**3
+        self.num_local_points = ne * n**3
+        hx, hy, hz = 1.0 / Ex, 1.0 / Ey, 1.0 / Ez
+
+        # global node grid
+        Gx, Gy, Gz = Ex * N + 1, Ey * N + 1, Ez * N + 1
+        self.global_nodes = Gx * Gy * Gz
+
+        ex = np.arange(lx) + self.origin[0]
+        ey = np.arange(ly) + self.origin[1]
+        ez = np.arange(lz) + self.origin[2]
+        # element-major ordering: local element id = ix + lx*(iy + ly*iz)
+        EZ, EY, EX = np.meshgrid(ez, ey, ex, indexing="ij")
+        EX, EY, EZ = EX.reshape(-1), EY.reshape(-1), EZ.reshape(-1)
+
+        k, j, i = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+        i, j, k = i.reshape(-1), j.reshape(-1), k.reshape(-1)  # x fastest
+
+        gi = EX[:, None] * N + i[None, :]
+        gj = EY[:, None] * N + j[None, :]
+        gk = EZ[:, None] * N + k[None, :]
+
+        self.glo_num = (1 + gi + Gx * (gj + Gy * gk)).astype(np.int64).reshape(-1)
+
+        def mult(g, G):
+            # number of elements sharing a grid line index g along one axis
+            m = np.ones_like(g)
+            m[(g % N == 0) & (g > 0) & (g < G - 1)] = 2
+            return m
+
+        self.node_degree = (mult(gi, Gx) * mult(gj, Gy) * mult(gk, Gz)).astype(np.int32).reshape(-1)
+        on_bdry = (gi == 0) | (gi == Gx - 1) | (gj == 0) | (gj == Gy - 1) | (gk == 0) | (gk == Gz - 1)
+        self.p_mask = np.where(on_bdry, 0.0, 1.0).reshape(-1)
+
+        xi = 0.5 * (z + 1.0)
+        self.x = ((EX[:, None] + xi[i][None, :]) * hx).reshape(-1)
+        self.y = ((EY[:, None] + xi[j][None, :]) * hy).reshape(-1)
+        self.z = ((EZ[:, None] + xi[k][None, :]) * hz).reshape(-1)
+
+        # geometric factors with quadrature weights folded in: the stiffness
+        # integrand of an affine hex, G_rr = w_i w_j w_k * (hy*hz)/(2*hx) etc.;
+        # for the cube hx=hy=hz=h this is w_i w_j w_k * h/2.
+        www = (w[i] * w[j] * w[k])[None, :] * np.ones((ne, 1))
+        self.g = [
+            (www * (hy * hz) / (2.0 * hx)).reshape(-1),
+            (www * (hx * hz) / (2.0 * hy)).reshape(-1),
+            (www * (hx * hy) / (2.0 * hz)).reshape(-1),
+            np.zeros(ne * n**3),
+            np.zeros(ne * n**3),
+            np.zeros(ne * n**3),
+        ]
+
+    def orc_mesh(self):
+        m = OrcMesh()
+        m.dim = 3
+        m.poly_degree = self.N
+        m.num_local_elements = self.num_local_elements
+        m.x, m.y, m.z = _p(self.x), _p(self.y), _p(self.z)
+        m.glo_num = _p(self.glo_num)
+        m.node_degree = _p(self.node_degree)
+        m.p_mask = _p(self.p_mask)
+        for g in range(6):
+            m.g[g] = _p(self.g[g]).value
+        return m
+
+
+def rank_grid(num_ranks):
+    """Rank blocks for a cube: 1->(1,1,1), 2->(2,1,1), 4->(2,2,1), 8->(2,2,2)."""
+    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[num_ranks]
+
+
+# --------------------------------------------------------------------------
+# oracle world wrapper
+# --------------------------------------------------------------------------
+class OracleWorld:
+    def __init__(self, meshes, N):
+        self.L = oracle()
+        self.meshes = meshes
+        self.R = len(meshes)
+        self._cm = (OrcMesh * self.R)(*[m.orc_mesh() for m in meshes])
+        _, _, D = gll(N)
+        self.D_hat = np.ascontiguousarray(D)
+        self.w = vp(self.L.orc_world_create(self.R, self._cm, _p(self.D_hat)))
+        self.npts = [self.L.orc_world_num_local_points(self.w, r) for r in range(self.R)]
+
+    def close(self):
+        if self.w:
+            self.L.orc_world_destroy(self.w)
+            self.w = None
+
+    def _pp(self, arrays):
+        arr = (vp * self.R)()
+        for r, a in enumerate(arrays):
+            arr[r] = a.ctypes.data
+        return arr
+
+    def zeros(self):
+        return [np.zeros(n) for n in self.npts]
+
+    def Q(self, r):
+        return self.L.orc_world_Q(self.w, r).contents.to_numpy()
+
+    def Qt(self, r):
+        return self.L.orc_world_Qt(self.w, r).contents.to_numpy()
+
+    def num_nodes(self, r):
+        return self.L.orc_world_num_local_nodes(self.w, r)
+
+    def num_bdary(self, r):
+        return self.L.orc_world_num_bdary_nodes(self.w, r)
+
+    def assembled_weight(self, r):
+        p = self.L.orc_world_assembled_weight(self.w, r)
+        return np.ctypeslib.as_array(p, shape=(self.num_nodes(r),)).copy()
+
+    def dssum(self, u, mask=True, weight=False):
+        out = self.zeros()
+        self.L.orc_world_dssum(self.w, self._pp(out), self._pp(u), int(mask), int(weight))
+        return out
+
+    def stiffness(self, u, dssum=False):
+        out = self.zeros()
+        self.L.orc_world_stiffness(self.w, self._pp(out), self._pp(u), int(dssum))
+        return out
+
+    def residual_norm(self, r):
+        return self.L.orc_world_residual_norm(self.w, self._pp(r))
+
+    def inner(self, u, v):
+        return self.L.orc_world_assembled_inner_product(self.w, self._pp(u), self._pp(v))
+
+    def solve(self, f, method="fcg", max_iterations=500, num_vectors=20, tolerance=1e-7, precond=None):
+        u = self.zeros()
+        opts = OrcSolverOpts()
+        opts.max_iterations = max_iterations
+        opts.num_vectors = num_vectors
+        opts.tolerance = tolerance
+        opts.use_relative = 1
+        keep = None
+        if precond is not None:
+            npts = self.npts
+            R = self.R
+
+            def cb(ctx, zpp, rpp):
+                z = [np.ctypeslib.as_array(ctypes.cast(zpp[r], ctypes.POINTER(ctypes.c_double)), shape=(npts[r],)) for r in range(R)]
+                rr = [np.ctypeslib.as_array(ctypes.cast(rpp[r], ctypes.POINTER(ctypes.c_double)), shape=(npts[r],)) for r in range(R)]
+                precond(z, rr)
+
+            keep = PRECOND_FN(cb)
+            opts.precond = keep
+        else:
+            opts.precond = ctypes.cast(None, PRECOND_FN)
+        hist = np.zeros(max_iterations + 2)
+        nh = ctypes.c_int(0)
+        fn = self.L.orc_world_fcg if method == "fcg" else self.L.orc_world_gmres
+        its = fn(self.w, self._pp(u), self._pp(f), ctypes.byref(opts), _p(hist), len(hist), ctypes.byref(nh))
+        return u, its, hist[: nh.value].copy()
+
+
+class OracleSubdomain:
+    """orc_subdomain for one rank's own elements (conforming composite)."""
+
+    def __init__(self, E, N, reduction, P=(1, 1, 1), rank=0):
+        self.L = oracle()
+        self.deg = level_degrees(N, reduction)
+        self.meshes = [BoxMesh(E, d, P, rank) for d in self.deg]
+        nl = len(self.deg)
+        self._cm = (OrcMesh * nl)(*[m.orc_mesh() for m in self.meshes])
+        self._D = [np.ascontiguousarray(gll(d)[2]) for d in self.deg]
+        self._J = [np.ascontiguousarray(J_cf(self.deg[l + 1], self.deg[l])) for l in range(nl - 1)]
+        Dp = (vp * nl)(*[a.ctypes.data for a in self._D])
+        Jp = (vp * max(nl, 1))(*([a.ctypes.data for a in self._J] + [0]))
+        degs = (ctypes.c_int * nl)(*self.deg)
+        self.s = vp(self.L.orc_subdomain_create(nl, degs, Dp, Jp, self._cm))
+        self.num_values = self.L.orc_subdomain_num_values(self.s)
+        self.num_points = self.meshes[0].num_local_points
+
+    def close(self):
+        if self.s:
+            self.L.orc_subdomain_destroy(self.s)
+            self.s = None
+
+    def tree(self, u):
+        out = np.zeros(self.num_values)
+        self.L.orc_subdomain_tree_operator(self.s, _p(out), _p(u))
+        return out
+
+    def stiffness(self, u):
+        out = np.zeros(self.num_values)
+        self.L.orc_subdomain_stiffness(self.s, _p(out), _p(u))
+        return out
+
+    def dssum(self, u):
+        out = np.zeros(self.num_values)
+        self.L.orc_subdomain_dssum(self.s, _p(out), _p(u))
+        return out
+
+    def residual_norm(self, r):
+        return self.L.orc_subdomain_residual_norm(self.s, _p(r))
+
+    def solve(self, f, method="gmres", num_vectors=4, max_iterations=4, tolerance=1e-12):
+        u = np.zeros(self.num_points)
+        opts = OrcSubdomainOpts(num_vectors, max_iterations, tolerance, 0)
+        hist = np.zeros(max_iterations + 2)
+        nh = ctypes.c_int(0)
+        fn = self.L.orc_subdomain_gmres if method == "gmres" else self.L.orc_subdomain_fcg
+        its = fn(self.s, _p(u), _p(np.ascontiguousarray(f)), ctypes.byref(opts), _p(hist), len(hist), ctypes.byref(nh))
+        return u, its, hist[: nh.value].copy()
+
+
+def seeded_uniform(n, seed=1234):
+    """Seeded stand-in for the reference's unseeded rand()/RAND_MAX RHS
+    (domain.tpp:572-573)."""
+    return np.random.Generator(np.random.MT19937(seed)).random(n)
