@@ -14,10 +14,12 @@ def k(name: str, *args):
     L = lib.hip()
     restype, argtypes = L.decls[name]
     conv = []
+    keep = []  # host pointer tables must outlive the call
     for a in args:
         if isinstance(a, (list, tuple)):
-            conv.append(ctypes.cast(lib.ptr_array(a), ctypes.c_void_p))
-            conv[-1]._keep = a  # keep the array alive for the call
+            arr = lib.ptr_array(a)
+            keep.append(arr)
+            conv.append(ctypes.cast(arr, ctypes.c_void_p))
         elif hasattr(a, "data_ptr") or a is None:
             conv.append(lib.ptr(a))
         else:

@@ -1,0 +1,625 @@
+"""GPU parity: every HIP kernel entry of libfdd_hip.so, called through the
+C-ABI, against the CPU oracle on the same seeded inputs.
+
+Bar (include/fdd_hip.h): element-wise kernels, thread-per-row and LDS-staged
+SpMV, stiffness (two-launch and fused) and restriction keep the reference's
+per-output operation order and must be BIT-IDENTICAL to the oracle
+(both sides compiled with -ffp-contract=off).  Reductions use a different
+summation tree: |gpu - oracle| <= 1e-13 * sum|terms| (a 1e-13 relative bound
+on the conditioning-free scale; SURVEY.md section 8(d) asks 1e-11*sqrt(n/1e6)).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import support as S
+from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
+from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd.kernels import k, reduce_workspace
+
+pytestmark = pytest.mark.gpu
+
+vp = ctypes.c_void_p
+P = S._p
+
+
+def dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def rnd(n, seed):
+    return np.random.default_rng(seed).uniform(-1.0, 1.0, n)
+
+
+SIZES = [1, 2, 3, 127, 128, 129, 4097, 1000003]
+
+
+# ------------------------------------------------------------------ math.okl
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("offset", [0, 1])
+def test_set_to_value(gpu, n, offset):
+    L = S.oracle()
+    ref = rnd(n + offset + 3, 1)
+    u = dev(ref, gpu)
+    L.orc_set_to_value(P(ref), ctypes.c_double(0.375), n, offset)
+    k("fdd_set_to_value", u, 0.375, n, offset)
+    assert np.array_equal(host(u), ref)
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_invert(gpu, n):
+    L = S.oracle()
+    ref = rnd(n, 2) + 2.0
+    u = dev(ref, gpu)
+    L.orc_invert_vector_elements(P(ref), n)
+    k("fdd_invert_vector_elements", u, n)
+    assert np.array_equal(host(u), ref)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("alias", ["none", "u", "v"])
+@pytest.mark.parametrize("shift", [0, 1])
+def test_axpby(gpu, n, alias, shift):
+    L = S.oracle()
+    a, b = 1.25, -0.7
+    u = rnd(n + shift, 3)[shift:]
+    v = rnd(n + shift, 4)[shift:]
+    du_full = dev(rnd(n + shift, 3), gpu)
+    dv_full = dev(rnd(n + shift, 4), gpu)
+    du, dv = du_full[shift:], dv_full[shift:]
+    u = np.ascontiguousarray(u)
+    v = np.ascontiguousarray(v)
+    if alias == "none":
+        out = np.zeros(n)
+        dout_full = torch.zeros(n + shift, dtype=torch.float64, device=gpu)
+        dout = dout_full[shift:]
+    elif alias == "u":
+        out, dout = u, du
+    else:
+        out, dout = v, dv
+    L.orc_vector_vector_addition(P(out), ctypes.c_double(a), P(u), ctypes.c_double(b), P(v), n)
+    k("fdd_vector_vector_addition", dout, a, du, b, dv, n)
+    assert np.array_equal(host(dout), out)
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_scale(gpu, n):
+    L = S.oracle()
+    u = rnd(n, 5)
+    out = np.zeros(n)
+    L.orc_vector_scaling(P(out), ctypes.c_double(1.0 / 3.0), P(u), n)
+    dout = torch.zeros(n, dtype=torch.float64, device=gpu)
+    k("fdd_vector_scaling", dout, 1.0 / 3.0, dev(u, gpu), n)
+    assert np.array_equal(host(dout), out)
+
+
+def test_zero_length_is_noop(gpu):
+    z = torch.zeros(4, dtype=torch.float64, device=gpu)
+    k("fdd_set_to_value", z, 1.0, 0, 0)
+    k("fdd_vector_scaling", z, 2.0, z, 0)
+    k("fdd_csr_multiply", z, None, None, None, z, 0)
+    assert host(z).sum() == 0.0
+
+
+def test_invalid_argument_is_reported(gpu):
+    z = torch.zeros(4, dtype=torch.float64, device=gpu)
+    with pytest.raises(lib.FddError):
+        k("fdd_vector_scaling", z, 2.0, z, -1)
+    with pytest.raises(lib.FddError):
+        k("fdd_csr_multiply_range", z, z, z, z, z, 3, 2)  # csr_matrix.tpp:322-326
+
+
+# --------------------------------------------------- fused vector updates
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("family", ["dom", "sub"])
+def test_vector_updates(gpu, n, family):
+    L = S.oracle()
+    u, r, p, q, z, f = (rnd(n, s) for s in range(10, 16))
+    alpha, beta = 0.618, -1.7
+
+    # initialize_arrays
+    u0, r0 = u.copy(), r.copy()
+    getattr(L, f"orc_{family}_initialize_arrays")(P(u0), P(r0), P(f), n)
+    du, dr = dev(u, gpu), dev(r, gpu)
+    k(f"fdd_{family}_initialize_arrays", du, dr, dev(f, gpu), n)
+    assert np.array_equal(host(du), u0) and np.array_equal(host(dr), r0)
+
+    # solution_and_residual_update
+    u1, r1 = u.copy(), np.zeros(n)
+    getattr(L, f"orc_{family}_solution_and_residual_update")(P(u1), P(r1), P(r), P(p), P(q), ctypes.c_double(alpha), n)
+    du, dr1 = dev(u, gpu), torch.zeros(n, dtype=torch.float64, device=gpu)
+    k(f"fdd_{family}_solution_and_residual_update", du, dr1, dev(r, gpu), dev(p, gpu), dev(q, gpu), alpha, n)
+    assert np.array_equal(host(du), u1) and np.array_equal(host(dr1), r1)
+
+    # residual_and_search_update
+    p2, r2 = p.copy(), r.copy()
+    getattr(L, f"orc_{family}_residual_and_search_update")(P(p2), P(r2), P(z), P(r1), ctypes.c_double(beta), n)
+    dp, dr = dev(p, gpu), dev(r, gpu)
+    k(f"fdd_{family}_residual_and_search_update", dp, dr, dev(z, gpu), dr1, beta, n)
+    assert np.array_equal(host(dp), p2) and np.array_equal(host(dr), r2)
+
+
+def test_vector_updates_device_scalars(gpu):
+    """alpha = num/den read on the device: same bits as the host-side division."""
+    L = S.oracle()
+    n = 100003
+    u, r, p, q, z = (rnd(n, s) for s in range(20, 25))
+    num, den = 0.37, 1.9
+    alpha = num / den
+    u1, r1 = u.copy(), np.zeros(n)
+    L.orc_dom_solution_and_residual_update(P(u1), P(r1), P(r), P(p), P(q), ctypes.c_double(alpha), n)
+    sc = dev(np.array([num, den]), gpu)
+    du, dr1 = dev(u, gpu), torch.zeros(n, dtype=torch.float64, device=gpu)
+    k("fdd_dom_solution_and_residual_update_dev", du, dr1, dev(r, gpu), dev(p, gpu), dev(q, gpu), sc[0:], sc[1:], n)
+    assert np.array_equal(host(du), u1) and np.array_equal(host(dr1), r1)
+    p2, r2 = p.copy(), r.copy()
+    L.orc_dom_residual_and_search_update(P(p2), P(r2), P(z), P(r1), ctypes.c_double(alpha), n)
+    dp, dr = dev(p, gpu), dev(r, gpu)
+    k("fdd_dom_residual_and_search_update_dev", dp, dr, dev(z, gpu), dr1, sc[0:], sc[1:], n)
+    assert np.array_equal(host(dp), p2) and np.array_equal(host(dr), r2)
+
+
+def test_cast_copies(gpu):
+    L = S.oracle()
+    n = 70001
+    v = rnd(n, 30)
+    out = np.zeros(n)
+    L.orc_sub_copy_f64_f64(P(out), P(v), n)
+    d = torch.zeros(n, dtype=torch.float64, device=gpu)
+    k("fdd_sub_copy_f64_f64", d, dev(v, gpu), n)
+    assert np.array_equal(host(d), out)
+
+    out32 = np.zeros(n, np.float32)
+    L.orc_sub_copy_f32_f64(P(out32), P(v), n)
+    d32 = torch.zeros(n, dtype=torch.float32, device=gpu)
+    k("fdd_sub_copy_f32_f64", d32, dev(v, gpu), n)
+    assert np.array_equal(host(d32), out32)
+
+    back = np.zeros(n)
+    L.orc_sub_copy_f64_f32(P(back), P(out32), n)
+    k("fdd_sub_copy_f64_f32", d, d32, n)
+    assert np.array_equal(host(d), back)
+
+
+# ------------------------------------------------------------ reductions
+@pytest.mark.parametrize("n", [1, 2, 127, 128, 129, 4097, 1000003, 5000001])
+def test_reductions(gpu, n):
+    L = S.oracle()
+    nb = (n + 127) // 128
+    ws = reduce_workspace(gpu)
+    out = torch.zeros(2, dtype=torch.float64, device=gpu)
+    a, b, c, d, w = (rnd(n, s) for s in range(40, 45))
+    w = np.abs(w)
+    block = np.zeros(2 * nb)
+
+    def check(got, ref, scale):
+        assert abs(got - ref) <= 1e-13 * scale + 1e-300, (got, ref, scale)
+
+    # domain.okl:109-138 and :235-264
+    L.orc_dom_residual_norm(P(block), P(a), P(b), P(w), n, nb)
+    ref = L.orc_block_sum(P(block), nb)
+    k("fdd_dom_residual_norm", out, ws, dev(a, gpu), dev(b, gpu), dev(w, gpu), n)
+    check(host(out)[0], ref, np.abs(a * b * w).sum())
+    k("fdd_dom_inner_product", out, ws, dev(a, gpu), dev(b, gpu), dev(w, gpu), n)
+    L.orc_dom_inner_product(P(block), P(a), P(b), P(w), n, nb)
+    check(host(out)[0], L.orc_block_sum(P(block), nb), np.abs(a * b * w).sum())
+
+    # domain.okl:140-184
+    L.orc_dom_projection_inner_products(P(block), P(a), P(b), P(c), P(d), n, nb)
+    g = L.orc_block_sum(P(block), nb)
+    t = L.orc_block_sum(P(block[nb:]), nb)
+    k("fdd_dom_projection_inner_products", out, ws, dev(a, gpu), dev(b, gpu), dev(c, gpu), dev(d, gpu), n)
+    o = host(out)
+    check(o[0], g, np.abs(a * b).sum())
+    check(o[1], t, np.abs(c * d).sum())
+
+    # domain.okl:195-224
+    L.orc_dom_inner_product_flexible(P(block), P(a), P(b), P(c), n, nb)
+    k("fdd_dom_inner_product_flexible", out, ws, dev(a, gpu), dev(b, gpu), dev(c, gpu), n)
+    check(host(out)[0], L.orc_block_sum(P(block), nb), np.abs((b - a) * c).sum())
+
+    # subdomain.okl:103-258
+    L.orc_sub_inner_product(P(block), P(a), P(b), n, nb)
+    k("fdd_sub_inner_product", out, ws, dev(a, gpu), dev(b, gpu), n)
+    check(host(out)[0], L.orc_block_sum(P(block), nb), np.abs(a * b).sum())
+    k("fdd_amg_dot", out, ws, dev(a, gpu), dev(b, gpu), n)
+    check(host(out)[0], L.orc_block_sum(P(block), nb), np.abs(a * b).sum())
+
+    L.orc_sub_weighted_inner_product(P(block), P(a), P(b), P(w), n, nb)
+    k("fdd_sub_weighted_inner_product", out, ws, dev(a, gpu), dev(b, gpu), dev(w, gpu), n)
+    check(host(out)[0], L.orc_block_sum(P(block), nb), np.abs(a * b * w).sum())
+
+    L.orc_sub_projection_inner_products(P(block), P(a), P(b), P(c), P(d), P(w), n, nb)
+    k("fdd_sub_projection_inner_products", out, ws, dev(a, gpu), dev(b, gpu), dev(c, gpu), dev(d, gpu), dev(w, gpu), n)
+    o = host(out)
+    check(o[0], L.orc_block_sum(P(block), nb), np.abs(a * b * w).sum())
+    check(o[1], L.orc_block_sum(P(block[nb:]), nb), np.abs(c * d * w).sum())
+
+    L.orc_sub_search_update_inner_product(P(block), P(a), P(b), P(c), P(w), n, nb)
+    k("fdd_sub_search_update_inner_product", out, ws, dev(a, gpu), dev(b, gpu), dev(c, gpu), dev(w, gpu), n)
+    check(host(out)[0], L.orc_block_sum(P(block), nb), np.abs((b - a) * c * w).sum())
+
+
+def test_reduction_is_deterministic_and_empty_is_zero(gpu):
+    n = 3000001
+    ws = reduce_workspace(gpu)
+    a, b = dev(rnd(n, 50), gpu), dev(rnd(n, 51), gpu)
+    o1 = torch.zeros(1, dtype=torch.float64, device=gpu)
+    o2 = torch.ones(1, dtype=torch.float64, device=gpu)
+    k("fdd_sub_inner_product", o1, ws, a, b, n)
+    k("fdd_sub_inner_product", o2, ws, a, b, n)
+    assert host(o1)[0] == host(o2)[0]
+    k("fdd_sub_inner_product", o2, ws, a, b, 0)
+    assert host(o2)[0] == 0.0
+
+
+# ----------------------------------------------------------------- CSR
+def csr_random(rows, cols, row_lens, seed):
+    rng = np.random.default_rng(seed)
+    ptr = np.zeros(rows + 1, np.int32)
+    ptr[1:] = np.cumsum(row_lens)
+    nnz = int(ptr[-1])
+    col = np.zeros(nnz, np.int32)
+    for i in range(rows):
+        L = row_lens[i]
+        if L:
+            col[ptr[i]:ptr[i + 1]] = np.sort(rng.choice(cols, size=L, replace=(L > cols)))
+    val = rng.uniform(-1, 1, nnz)
+    return ptr, col, val
+
+
+def stencil27(m):
+    """27-point stencil CSR on an m^3 node grid (stand-in for A_fem[0] / the
+    superdomain operator)."""
+    idx = np.arange(m**3).reshape(m, m, m)
+    rows, cols = [], []
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                z0, z1 = max(0, -dz), m - max(0, dz)
+                y0, y1 = max(0, -dy), m - max(0, dy)
+                x0, x1 = max(0, -dx), m - max(0, dx)
+                r = idx[z0:z1, y0:y1, x0:x1].reshape(-1)
+                c = idx[z0 + dz:z1 + dz, y0 + dy:y1 + dy, x0 + dx:x1 + dx].reshape(-1)
+                rows.append(r)
+                cols.append(c)
+    rows = np.concatenate(rows)
+    cols = np.concatenate(cols)
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    ptr = np.zeros(m**3 + 1, np.int32)
+    np.add.at(ptr, rows + 1, 1)
+    ptr = np.cumsum(ptr).astype(np.int32)
+    val = np.random.default_rng(7).uniform(-1, 1, len(cols))
+    return ptr, cols.astype(np.int32), val
+
+
+def run_csr_case(gpu, ptr, col, val, ncols, expect_kind=None, exact=True):
+    L = S.oracle()
+    rows = len(ptr) - 1
+    u = rnd(ncols, 60)
+    w = rnd(rows, 61)
+    dptr, dcol, dval, du, dw = dev(ptr, gpu), dev(col, gpu), dev(val, gpu), dev(u, gpu), dev(w, gpu)
+
+    ref = np.zeros(rows)
+    L.orc_csr_multiply(P(ref), P(ptr), P(col), P(val), P(u), rows)
+    refw = np.zeros(rows)
+    L.orc_csr_multiply_weight(P(refw), P(ptr), P(col), P(val), P(u), P(w), rows)
+
+    def same(got, want):
+        if exact:
+            assert np.array_equal(got, want)
+        else:
+            scale = np.abs(want).max() + 1e-300
+            assert np.abs(got - want).max() <= 1e-13 * max(scale, 1.0) * 64
+
+    out = torch.full((rows,), 7.0, dtype=torch.float64, device=gpu)
+    k("fdd_csr_multiply", out, dptr, dcol, dval, du, rows)
+    same(host(out), ref)
+    k("fdd_csr_multiply_weight", out, dptr, dcol, dval, du, dw, rows)
+    same(host(out), refw)
+
+    # inclusive row range (csr_matrix.okl:20-33)
+    if rows >= 5:
+        r0, r1 = rows // 3, rows - 2
+        out.fill_(7.0)
+        k("fdd_csr_multiply_range", out, dptr, dcol, dval, du, r0, r1)
+        want = np.full(rows, 7.0)
+        L.orc_csr_multiply_range(P(want), P(ptr), P(col), P(val), P(u), r0, r1)
+        same(host(out), want)
+
+    # planned SpMV
+    plan = vp()
+    lib.hip().call("fdd_csr_plan_create", ctypes.byref(plan), P(ptr), rows, ncols, int(ptr[-1]))
+    try:
+        kind = ctypes.c_int(-1)
+        lib.hip().call("fdd_csr_plan_kind", plan, ctypes.byref(kind))
+        if expect_kind is not None:
+            assert kind.value == expect_kind
+        out.fill_(7.0)
+        k("fdd_csr_plan_multiply", plan, out, dptr, dcol, dval, du, None)
+        same(host(out), ref)
+        k("fdd_csr_plan_multiply", plan, out, dptr, dcol, dval, du, dw)
+        same(host(out), refw)
+    finally:
+        lib.hip().call("fdd_csr_plan_destroy", plan)
+
+    # y = alpha*A*x + beta*y (AMG/csr_matrix.cpp:112-134)
+    y = rnd(rows, 62)
+    dy = dev(y, gpu)
+    L.orc_amg_matvec(P(y), P(ptr), P(col), P(val), P(u), ctypes.c_double(-1.0), ctypes.c_double(1.0), rows)
+    k("fdd_amg_matvec", dy, dptr, dcol, dval, du, -1.0, 1.0, rows)
+    same(host(dy), y)
+
+
+def test_csr_boolean_gather_scatter(gpu):
+    """Q and Qt of a box-mesh Domain (domain.tpp:287-294): 1 and 1..8 nnz/row."""
+    m = S.BoxMesh((6, 6, 6), 5)
+    W = S.OracleWorld([m], 5)
+    try:
+        ptr, col, val = W.Q(0)
+        run_csr_case(gpu, ptr, col, val, W.num_nodes(0), expect_kind=0)
+        ptr, col, val = W.Qt(0)
+        assert np.diff(ptr).max() == 8
+        run_csr_case(gpu, ptr, col, val, m.num_local_points, expect_kind=0)
+    finally:
+        W.close()
+
+
+def test_csr_stencil27_lds_staged(gpu):
+    ptr, col, val = stencil27(41)
+    run_csr_case(gpu, ptr, col, val, 41**3, expect_kind=1)
+
+
+def test_csr_ragged_rows(gpu):
+    """Empty rows, rows of every length up to a block, and rows longer than a
+    block (workgroup-reduced: tolerance instead of bit equality)."""
+    rng = np.random.default_rng(9)
+    rows = 3000
+    lens = rng.integers(0, 40, rows)
+    lens[rng.integers(0, rows, 200)] = 0
+    lens[5] = 2048
+    lens[6] = 2047
+    lens[700] = 1
+    ptr, col, val = csr_random(rows, 5000, lens, 10)
+    run_csr_case(gpu, ptr, col, val, 5000, expect_kind=1)
+
+    lens2 = lens.copy()
+    lens2[17] = 2049
+    lens2[18] = 10000
+    lens2[rows - 1] = 4100
+    ptr, col, val = csr_random(rows, 5000, lens2, 11)
+    run_csr_case(gpu, ptr, col, val, 5000, expect_kind=1, exact=False)
+
+
+def test_csr_empty_matrix(gpu):
+    ptr = np.zeros(11, np.int32)
+    run_csr_case(gpu, ptr, np.zeros(0, np.int32), np.zeros(0), 7, expect_kind=0)
+
+
+# ------------------------------------------------------------ stiffness
+def stiffness_inputs(E, N, seed, dim=3):
+    n = N + 1
+    npts = E * n**dim
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(-1, 1, npts)
+    G = [rng.uniform(0.1, 1.0, npts) if g < dim else rng.uniform(-0.3, 0.3, npts) for g in range(6)]
+    _, _, D = S.gll(N)
+    return u, G, np.ascontiguousarray(D)
+
+
+def oracle_stiffness(u, G, D, N, dim):
+    L = S.oracle()
+    npts = len(u)
+    GDu = [np.zeros(npts) for _ in range(3)]
+    Au = np.zeros(npts)
+    gd = (vp * 3)(*[a.ctypes.data for a in GDu])
+    gg = (vp * 6)(*[a.ctypes.data for a in G])
+    L.orc_dom_stiffness_matrix_1(gd, P(u), P(D), gg, npts, N, dim)
+    L.orc_dom_stiffness_matrix_2(P(Au), gd, P(D), npts, N, dim)
+    return Au, GDu
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 5, 7, 15])
+@pytest.mark.parametrize("dim", [2, 3])
+def test_stiffness_two_launch_form(gpu, N, dim):
+    E = 37 if dim == 3 else 101
+    u, G, D = stiffness_inputs(E, N, 70 + N, dim)
+    Au, GDu = oracle_stiffness(u, G, D, N, dim)
+    npts = len(u)
+    dG = [dev(g, gpu) for g in G]
+    dGDu = [torch.zeros(npts, dtype=torch.float64, device=gpu) for _ in range(3)]
+    dAu = torch.zeros(npts, dtype=torch.float64, device=gpu)
+    k("fdd_dom_stiffness_matrix_1", dGDu, dev(u, gpu), dev(D, gpu), dG, npts, N, dim)
+    k("fdd_dom_stiffness_matrix_2", dAu, dGDu, dev(D, gpu), npts, N, dim)
+    for d in range(dim):
+        assert np.array_equal(host(dGDu[d]), GDu[d])
+    assert np.array_equal(host(dAu), Au)
+
+
+@pytest.mark.parametrize("N", list(range(1, 16)))
+def test_stiffness_fused_bit_exact(gpu, N):
+    """Fused D^T G D u == oracle two-kernel arithmetic, bit for bit, with all
+    six geometric factors non-zero; element counts that do not fill the last
+    workgroup."""
+    for E in (1, 7, 130):
+        u, G, D = stiffness_inputs(E, N, 90 + N)
+        Au, _ = oracle_stiffness(u, G, D, N, 3)
+        dAu = torch.full((len(u),), 3.0, dtype=torch.float64, device=gpu)
+        k("fdd_dom_stiffness_matrix", dAu, dev(u, gpu), dev(D, gpu), [dev(g, gpu) for g in G], E, N)
+        assert np.array_equal(host(dAu), Au), (N, E)
+
+
+def test_stiffness_fused_unsupported_degree(gpu):
+    z = torch.zeros(8, dtype=torch.float64, device=gpu)
+    with pytest.raises(lib.FddError):
+        k("fdd_dom_stiffness_matrix", z, z, z, [z] * 6, 1, 16)
+
+
+def mixed_level_inputs(seed):
+    """A Subdomain-like element list with mixed degrees (subdomain.tpp:558-566,
+    1603-1630): levels N = 7, 5, 3, 1 interleaved."""
+    rng = np.random.default_rng(seed)
+    degs = [7, 5, 3, 1]
+    elems = rng.integers(0, 4, 90)
+    offset, vert, level = [], [], []
+    elem_offsets = {l: [] for l in range(4)}
+    o = 0
+    for l in elems:
+        n3 = (degs[l] + 1) ** 3
+        offset += [o] * n3
+        vert += list(range(n3))
+        level += [l] * n3
+        elem_offsets[int(l)].append(o)
+        o += n3
+    npts = o
+    u = rng.uniform(-1, 1, npts)
+    G = [rng.uniform(0.1, 1.0, npts) if g < 3 else rng.uniform(-0.3, 0.3, npts) for g in range(6)]
+    D = [np.ascontiguousarray(S.gll(d)[2]) for d in degs]
+    return degs, np.array(offset, np.int32), np.array(vert, np.int32), np.array(level, np.int32), elem_offsets, u, G, D
+
+
+def test_sub_stiffness_mixed_degree(gpu):
+    L = S.oracle()
+    degs, offset, vert, level, elem_offsets, u, G, D = mixed_level_inputs(5)
+    npts = len(u)
+    GDu = [np.zeros(npts) for _ in range(3)]
+    Au = np.zeros(npts)
+    gd = (vp * 3)(*[a.ctypes.data for a in GDu])
+    gg = (vp * 6)(*[a.ctypes.data for a in G])
+    Dp = (vp * 4)(*[a.ctypes.data for a in D])
+    pd = (ctypes.c_int * 4)(*degs)
+    L.orc_sub_stiffness_matrix_1(gd, P(u), Dp, P(offset), P(vert), P(level), pd, gg, npts, 3)
+    L.orc_sub_stiffness_matrix_2(P(Au), gd, Dp, P(offset), P(vert), P(level), pd, npts, 3)
+
+    dD = [dev(d, gpu) for d in D]
+    dG = [dev(g, gpu) for g in G]
+    du = dev(u, gpu)
+    dGDu = [torch.zeros(npts, dtype=torch.float64, device=gpu) for _ in range(3)]
+    dAu = torch.zeros(npts, dtype=torch.float64, device=gpu)
+    doff, dvert, dlev = dev(offset, gpu), dev(vert, gpu), dev(level, gpu)
+    k("fdd_sub_stiffness_matrix_1", dGDu, du, dD, doff, dvert, dlev, pd, 4, dG, npts, 3)
+    k("fdd_sub_stiffness_matrix_2", dAu, dGDu, dD, doff, dvert, dlev, pd, 4, npts, 3)
+    assert np.array_equal(host(dAu), Au)
+
+    # level-sorted fused form: one launch per level over that level's elements
+    dAu2 = torch.zeros(npts, dtype=torch.float64, device=gpu)
+    for l, d in enumerate(degs):
+        eo = np.array(elem_offsets[l], np.int32)
+        if len(eo):
+            k("fdd_sub_stiffness_matrix", dAu2, du, dD[l], dG, dev(eo, gpu), len(eo), d)
+    assert np.array_equal(host(dAu2), Au)
+
+
+# ---------------------------------------------------------- restriction
+@pytest.mark.parametrize("Nf,Nc", [(7, 1), (7, 5), (5, 3), (3, 1), (15, 9), (15, 1), (2, 1)])
+def test_restriction(gpu, Nf, Nc):
+    L = S.oracle()
+    E = 53
+    n_f, n_c = Nf + 1, Nc + 1
+    J = np.ascontiguousarray(S.J_cf(Nc, Nf))
+    u = rnd(E * n_f**3, 100 + Nf)
+    w1 = np.zeros(E * n_f * n_f * n_c)
+    w2 = np.zeros(E * n_f * n_c * n_c)
+    uc = np.zeros(E * n_c**3)
+    L.orc_sub_restriction_1(P(w1), P(J), P(u), len(w1), n_f, n_c, 3)
+    L.orc_sub_restriction_2(P(w2), P(J), P(w1), len(w2), n_f, n_c, 3)
+    L.orc_sub_restriction_3(P(uc), P(J), P(w2), len(uc), n_f, n_c)
+
+    dJ, du = dev(J, gpu), dev(u, gpu)
+    d1 = torch.zeros(len(w1), dtype=torch.float64, device=gpu)
+    d2 = torch.zeros(len(w2), dtype=torch.float64, device=gpu)
+    dc = torch.zeros(len(uc), dtype=torch.float64, device=gpu)
+    k("fdd_sub_restriction_1", d1, dJ, du, len(w1), n_f, n_c, 3)
+    k("fdd_sub_restriction_2", d2, dJ, d1, len(w2), n_f, n_c, 3)
+    k("fdd_sub_restriction_3", dc, dJ, d2, len(uc), n_f, n_c)
+    assert np.array_equal(host(d1), w1)
+    assert np.array_equal(host(d2), w2)
+    assert np.array_equal(host(dc), uc)
+
+    dc2 = torch.zeros(len(uc), dtype=torch.float64, device=gpu)
+    k("fdd_sub_restriction", dc2, dJ, du, E, n_f, n_c)
+    assert np.array_equal(host(dc2), uc)
+
+
+def test_restriction_2d(gpu):
+    L = S.oracle()
+    E, Nf, Nc = 77, 7, 3
+    n_f, n_c = Nf + 1, Nc + 1
+    J = np.ascontiguousarray(S.J_cf(Nc, Nf))
+    u = rnd(E * n_f**2, 111)
+    w1 = np.zeros(E * n_f * n_c)
+    uc = np.zeros(E * n_c * n_c)
+    L.orc_sub_restriction_1(P(w1), P(J), P(u), len(w1), n_f, n_c, 2)
+    L.orc_sub_restriction_2(P(uc), P(J), P(w1), len(uc), n_f, n_c, 2)
+    d1 = torch.zeros(len(w1), dtype=torch.float64, device=gpu)
+    dc = torch.zeros(len(uc), dtype=torch.float64, device=gpu)
+    k("fdd_sub_restriction_1", d1, dev(J, gpu), dev(u, gpu), len(w1), n_f, n_c, 2)
+    k("fdd_sub_restriction_2", dc, dev(J, gpu), d1, len(uc), n_f, n_c, 2)
+    assert np.array_equal(host(d1), w1) and np.array_equal(host(dc), uc)
+
+
+# ------------------------------------------------------------------ AMG
+def test_amg_elementwise(gpu):
+    L = S.oracle()
+    n = 99991
+    f, Sv, r, D, w, v, u = (rnd(n, s) for s in range(120, 127))
+    alpha = 0.83
+
+    Sr, ww = np.zeros(n), np.zeros(n)
+    L.orc_amg_main_scaled_residual(P(Sr), P(ww), P(f), P(Sv), ctypes.c_double(alpha), n)
+    dSr = torch.zeros(n, dtype=torch.float64, device=gpu)
+    dw = torch.zeros(n, dtype=torch.float64, device=gpu)
+    k("fdd_amg_main_scaled_residual", dSr, dw, dev(f, gpu), dev(Sv, gpu), alpha, n)
+    assert np.array_equal(host(dSr), Sr) and np.array_equal(host(dw), ww)
+
+    w2, v2 = w.copy(), v.copy()
+    L.orc_amg_main_polynomial_evaluation(P(w2), P(v2), P(r), P(D), ctypes.c_double(alpha), n)
+    dw, dv = dev(w, gpu), dev(v, gpu)
+    k("fdd_amg_main_polynomial_evaluation", dw, dv, dev(r, gpu), dev(D, gpu), alpha, n)
+    assert np.array_equal(host(dw), w2) and np.array_equal(host(dv), v2)
+
+    u2 = u.copy()
+    L.orc_amg_main_update_field(P(u2), P(w), P(D), n)
+    du = dev(u, gpu)
+    k("fdd_amg_main_update_field", du, dev(w, gpu), dev(D, gpu), n)
+    assert np.array_equal(host(du), u2)
+
+    uv = np.zeros(n)
+    L.orc_amg_vector_multiplication(P(uv), P(u), P(v), n)
+    duv = torch.zeros(n, dtype=torch.float64, device=gpu)
+    k("fdd_amg_vector_multiplication", duv, dev(u, gpu), dev(v, gpu), n)
+    assert np.array_equal(host(duv), uv)
+
+    k("fdd_amg_vector_set_to_value", duv, -2.5, n)
+    assert np.all(host(duv) == -2.5)
+
+
+# -------------------------------------------------------------- runtime
+def test_runtime_memory_roundtrip(gpu):
+    L = lib.hip()
+    p = vp()
+    L.call("fdd_malloc", ctypes.byref(p), 8 * 1000)
+    a = rnd(1000, 130)
+    b = np.zeros(1000)
+    q = vp()
+    L.call("fdd_malloc", ctypes.byref(q), 8 * 1000)
+    L.call("fdd_memcpy_h2d", p, P(a), 8000, None)
+    L.call("fdd_memcpy_d2d", q, p, 8000, None)
+    L.call("fdd_device_sync")
+    L.call("fdd_memcpy_d2h", P(b), q, 8000, None)
+    assert np.array_equal(a, b)
+    L.call("fdd_memset", q, 0, 8000, None)
+    L.call("fdd_memcpy_d2h", P(b), q, 8000, None)
+    assert not b.any()
+    L.call("fdd_free", p)
+    L.call("fdd_free", q)
+    name = ctypes.create_string_buffer(128)
+    L.call("fdd_device_name", name, 128)
+    assert b"gfx950" in name.value
