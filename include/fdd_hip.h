@@ -177,6 +177,14 @@ int fdd_amg_matvec(double *y, const int *ptr, const int *col, const double *val,
 /* cublasDdot replacement (AMG/vector.cpp:100,129): out[0] = sum x*y */
 int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int size, void *stream);
 
+/* ------------------------------------------------------------------ */
+/* interface exchange helpers: gslib gs(gs_add) on the boundary-node    */
+/* prefix (domain.tpp:590-594) becomes pack -> all-reduce -> unpack on a */
+/* dense interface-slot vector                                           */
+/* ------------------------------------------------------------------ */
+int fdd_interface_pack(double *slots, const int *slot_of, const double *prefix, int n, void *stream);   /* slots[slot_of[i]] = prefix[i]; slot_of is injective */
+int fdd_interface_unpack(double *prefix, const double *slots, const int *slot_of, int n, void *stream); /* prefix[i] = slots[slot_of[i]] */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,124 @@
+/*
+ * fdd_host.h -- C-ABI of libfdd_host.so: the C++ host classes
+ * (CSR_Matrix / Math / Domain / Subdomain, mirrors of the reference's
+ * csr_matrix.hpp / math.hpp / domain.hpp / subdomain.hpp) and what the
+ * reference's driver does with them (poisson.cpp:150-251: one Domain per
+ * polynomial level, a Subdomain preconditioner, manufactured right-hand side,
+ * outer flexible CG / GMRES), exposed with plain pointers so that tests,
+ * bench.py and foreign-language hosts can drive it.
+ *
+ * Vectors cross this boundary as HOST arrays of num_local_points doubles
+ * (element-major, the layout of the mesh files); the solver works on device
+ * copies.  Every entry returns 0 on success; fddh_last_error() has the text.
+ */
+#ifndef FDD_HOST_H
+#define FDD_HOST_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *fddh_last_error(void);
+
+/* Device and stream of this rank (OCCA_Initialize, poisson.cpp:127-148).
+ * stream == NULL creates a private stream; pass torch's current stream to
+ * share ordering with torch.distributed collectives. */
+int fddh_init(int device, void *stream);
+int fddh_set_print(int on); /* rank-0 residual history lines (rstdout) */
+int fddh_set_timer(int on); /* named timing regions (timer.hpp); off by default */
+int fddh_timer_total(const char *key, double *seconds);
+
+/* Communicator (MPI_Initialize, poisson.cpp:84-89).  Exactly one of: */
+int fddh_comm_single(void);
+int fddh_comm_rccl_unique_id(char *out128);                        /* rank 0; ship the 128 bytes to all ranks */
+int fddh_comm_rccl_init(const char *id128, int rank, int size);    /* RCCL over xGMI, called directly */
+typedef int (*fddh_allreduce_fn)(void *ctx, void *buf, long long n);
+typedef int (*fddh_allgather_fn)(void *ctx, const void *send, void *recv, long long bytes);
+typedef int (*fddh_barrier_fn)(void *ctx);
+int fddh_comm_callbacks(int rank, int size, void *ctx, fddh_allreduce_fn allreduce_sum_f64, fddh_allreduce_fn allreduce_max_f64, fddh_allgather_fn allgather_bytes, fddh_barrier_fn barrier);
+int fddh_comm_info(int *rank, int *size, char *name, size_t name_len);
+
+/* A "problem" = what run_simulation builds (poisson.cpp:176-206): Domains for
+ * the levels N, N-r, ..., 1 of this rank and, optionally, the Subdomain
+ * preconditioner over them. */
+typedef struct fddh_problem fddh_problem;
+
+/* synthetic box mesh: E global elements, P rank blocks per direction */
+int fddh_problem_create_box(fddh_problem **out, const int E[3], const int P[3], int poly_degree, int poly_reduction, int with_subdomain);
+/* Nek5000-export directory, the reference's input (poisson.cpp:61-68, domain.tpp:45-224) */
+int fddh_problem_create_dir(fddh_problem **out, const char *directory, int poly_degree, int poly_reduction, int subdomain_overlap, int superdomain_overlap, int with_subdomain);
+int fddh_problem_destroy(fddh_problem *p);
+/* write the box mesh of this rank as the reference's file set under `directory` */
+int fddh_write_box_mesh_files(const char *directory, const int E[3], const int P[3], int poly_degree, int rank);
+
+enum
+{
+    FDDH_INFO_NUM_LOCAL_POINTS = 0,
+    FDDH_INFO_NUM_LOCAL_NODES,
+    FDDH_INFO_NUM_BDARY_NODES,
+    FDDH_INFO_NUM_INTERFACE_SLOTS,
+    FDDH_INFO_NUM_TOTAL_NODES,
+    FDDH_INFO_NUM_TOTAL_ELEMENTS,
+    FDDH_INFO_NUM_LOCAL_ELEMENTS,
+    FDDH_INFO_NUM_LEVELS,
+    FDDH_INFO_SUB_NUM_VALUES,
+    FDDH_INFO_SUB_NUM_DOFS,
+    FDDH_INFO_NUM_ITERATIONS,
+    FDDH_INFO_COUNT
+};
+int fddh_problem_info(const fddh_problem *p, long long *info, int n);
+int fddh_problem_level_degree(const fddh_problem *p, int level, int *poly_degree);
+
+/* mesh arrays of a level as Domain::initialize holds them: name in
+ * {"x","y","z","glo_num"(int64),"node_degree"(int32),"p_mask","g_1".."g_6"} */
+int fddh_problem_mesh_array(const fddh_problem *p, int level, const char *name, void *out, size_t bytes);
+/* CSR of the fine level's gather matrix Qt / scatter matrix Q (host copies) */
+int fddh_problem_csr(const fddh_problem *p, int which /*0 = Q, 1 = Qt*/, int *num_rows, int *num_cols, int *num_nnz, int *ptr, int *col, double *val);
+int fddh_problem_assembled_weight(const fddh_problem *p, double *out, int n);
+
+/* Replace the GLL tables (D_hat of a level, J_cf between two levels) -- tests
+ * feed the reference's own tables so parity does not hinge on the last bit of
+ * the GLL nodes. */
+int fddh_problem_set_D_hat(fddh_problem *p, int level, const double *D_hat, int n);
+int fddh_problem_get_D_hat(const fddh_problem *p, int level, double *D_hat, int n);
+
+/* Solver options: domain.hpp:112-118 and subdomain.hpp:228-238.  Negative
+ * values (and NaN tolerance) leave a field unchanged. */
+int fddh_problem_set_options(fddh_problem *p, int max_iterations, double tolerance, int num_vectors, int use_preconditioner, int preconditioner_type, int sub_num_vectors, int sub_max_iterations, int sub_build_tree);
+
+/* Domain operations on host vectors of num_local_points */
+int fddh_problem_dssum(fddh_problem *p, double *out, const double *in, int apply_mask, int apply_weight);          /* Domain::direct_stiffness_summation */
+int fddh_problem_stiffness(fddh_problem *p, double *out, const double *in, int apply_dssum);                       /* Domain::stiffness_matrix */
+int fddh_problem_residual_norm(fddh_problem *p, const double *r, double *norm);                                    /* Domain::residual_norm */
+int fddh_problem_make_rhs(fddh_problem *p, int function_id, unsigned long long seed, double *u_star, double *f);   /* poisson.cpp:211-219 */
+/* u* given on the host (e.g. a seeded vector): u* <- weighted dssum(u*), f = A_L u* */
+int fddh_problem_make_rhs_from(fddh_problem *p, double *u_star_inout, double *f);
+
+/* Outer solve: solver_id 0 = flexible_conjugate_gradient, 1 = generalized_minimum_residual
+ * (poisson.cpp:224-231).  history receives the residual norms the reference
+ * prints (iteration 0 first). */
+int fddh_problem_solve(fddh_problem *p, int solver_id, const double *f, double *u, double *history, int history_cap, int *num_history, int *num_iterations);
+
+/* Subdomain (preconditioner) operations; type 0 = flexible_conjugate_gradient,
+ * 1 = generalized_minimum_residual */
+int fddh_problem_precond_apply(fddh_problem *p, int type, const double *r, double *z, double *history, int history_cap, int *num_history);
+/* op 0 = tree_operator, 1 = stiffness_matrix, 2 = direct_stiffness_summation; in/out of sub_num_values */
+int fddh_problem_sub_op(fddh_problem *p, int op, const double *in, double *out);
+int fddh_problem_sub_residual_norm(fddh_problem *p, const double *r, double *norm);
+
+/* Stepwise PCG with vectors resident in HBM (what bench.py times): begin sets
+ * u = 0, r = f, z = M^-1 r, p = z; each step is one full outer iteration with
+ * no stopping test.  last_residual receives ||r|| of the last step. */
+int fddh_problem_pcg_begin(fddh_problem *p, const double *f);
+int fddh_problem_pcg_steps(fddh_problem *p, int steps, double *last_residual);
+int fddh_problem_pcg_solution(fddh_problem *p, double *u);
+int fddh_sync(void);   /* stream synchronise */
+int fddh_barrier(void); /* communicator barrier (stream-ordered, then synchronised) */
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FDD_HOST_H */

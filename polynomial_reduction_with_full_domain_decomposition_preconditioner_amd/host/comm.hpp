@@ -1,0 +1,288 @@
+/*
+ * comm.hpp -- the communication layer that stands where MPI + gslib stood.
+ *
+ * The reference's solve path has three kinds of exchange:
+ *   MPI_Allreduce(SUM) of 1-2 scalars        (domain.tpp:929,946,969,995)
+ *   gslib gs(gs_add) on the boundary prefix  (domain.tpp:590-594)
+ *   MPI_Allgatherv of the coarse level       (subdomain.tpp:4620-4621)
+ * all host-staged.  Here every exchange is a collective on DEVICE buffers,
+ * one rank per GPU:
+ *   - SingleComm: one rank, everything is a no-op / copy;
+ *   - RcclComm:   RCCL over xGMI, called directly (librccl is dlopen'ed so the
+ *                 kernel library carries no link-time dependency on it);
+ *   - CallbackComm: the collectives are supplied by the embedding process
+ *                 through C function pointers (torch.distributed: "nccl" on
+ *                 GPUs, "gloo" in the CPU tests).
+ * gs_add becomes: scatter the prefix into a dense interface-slot vector,
+ * all-reduce it, gather back (slots = sorted unique global ids that appear in
+ * any rank's prefix).
+ */
+#ifndef FDD_COMM_HPP
+#define FDD_COMM_HPP
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "fdd_device.hpp"
+
+namespace fdd
+{
+
+class Comm
+{
+  public:
+    int rank = 0;
+    int size = 1;
+
+    virtual ~Comm() {}
+    virtual const char *name() const = 0;
+    // in-place sum over ranks of n doubles in device memory
+    virtual void allreduce_sum(double *buf_dev, size_t n) = 0;
+    // in-place max over ranks of n doubles in device memory
+    virtual void allreduce_max(double *buf_dev, size_t n) = 0;
+    // every rank contributes `bytes` from send_dev; recv_dev gets size*bytes in rank order
+    virtual void allgather(const void *send_dev, void *recv_dev, size_t bytes) = 0;
+    virtual void barrier() = 0;
+
+    // ---- host-side helpers for setup (tiny, staged through device scratch) ----
+    void allreduce_sum_host(double *v, size_t n)
+    {
+        if (size == 1) return;
+        memory tmp = dev().malloc<double>(n);
+        tmp.copyFrom(v, n * sizeof(double));
+        allreduce_sum(tmp.as<double>(), n);
+        tmp.copyTo(v, n * sizeof(double));
+        tmp.free();
+    }
+
+    void allreduce_max_host(double *v, size_t n)
+    {
+        if (size == 1) return;
+        memory tmp = dev().malloc<double>(n);
+        tmp.copyFrom(v, n * sizeof(double));
+        allreduce_max(tmp.as<double>(), n);
+        tmp.copyTo(v, n * sizeof(double));
+        tmp.free();
+    }
+
+    // MPI_Allgatherv of int64 lists: returns the concatenation in rank order
+    // and fills counts[rank]
+    std::vector<long long> allgatherv_host(const std::vector<long long> &local, std::vector<int> &counts)
+    {
+        counts.assign(size, 0);
+        if (size == 1)
+        {
+            counts[0] = (int)local.size();
+            return local;
+        }
+
+        std::vector<double> cnt(size, 0.0);
+        cnt[rank] = (double)local.size();
+        allreduce_sum_host(cnt.data(), size);
+        size_t max_count = 0;
+        for (int p = 0; p < size; p++)
+        {
+            counts[p] = (int)cnt[p];
+            max_count = std::max(max_count, (size_t)counts[p]);
+        }
+        if (max_count == 0) return std::vector<long long>();
+
+        std::vector<long long> padded(max_count, 0);
+        std::copy(local.begin(), local.end(), padded.begin());
+        memory send = dev().malloc<long long>(max_count);
+        memory recv = dev().malloc<long long>(max_count * size);
+        send.copyFrom(padded.data(), max_count * sizeof(long long));
+        allgather(send.ptr(), recv.ptr(), max_count * sizeof(long long));
+        std::vector<long long> all(max_count * size);
+        recv.copyTo(all.data(), all.size() * sizeof(long long));
+        send.free();
+        recv.free();
+
+        std::vector<long long> out;
+        for (int p = 0; p < size; p++) out.insert(out.end(), all.begin() + p * max_count, all.begin() + p * max_count + counts[p]);
+        return out;
+    }
+};
+
+class SingleComm : public Comm
+{
+  public:
+    const char *name() const override { return "single"; }
+    void allreduce_sum(double *, size_t) override {}
+    void allreduce_max(double *, size_t) override {}
+    void allgather(const void *send_dev, void *recv_dev, size_t bytes) override
+    {
+        if (send_dev != recv_dev) FDD_CALL(fdd_memcpy_d2d(recv_dev, send_dev, bytes, dev().stream));
+    }
+    void barrier() override {}
+};
+
+// Collectives supplied by the embedding process (C function pointers).  Each
+// returns 0 on success.  Pointers are device pointers of this rank (host
+// pointers in the CPU test build); the callee must order the collective after
+// work already queued on the rank's stream and before work queued later.
+struct CommCallbacks
+{
+    void *ctx;
+    int (*allreduce_sum_f64)(void *ctx, void *buf, long long n);
+    int (*allreduce_max_f64)(void *ctx, void *buf, long long n);
+    int (*allgather_bytes)(void *ctx, const void *send, void *recv, long long bytes);
+    int (*barrier)(void *ctx);
+};
+
+class CallbackComm : public Comm
+{
+    CommCallbacks cb_;
+
+    static void ok(int rc, const char *what)
+    {
+        if (rc != 0)
+        {
+            fprintf(stderr, "ERROR: communication callback %s failed (code %d)\n", what, rc);
+            exit(EXIT_FAILURE);
+        }
+    }
+
+  public:
+    CallbackComm(int rank_, int size_, const CommCallbacks &cb) : cb_(cb)
+    {
+        rank = rank_;
+        size = size_;
+    }
+    const char *name() const override { return "callback"; }
+    void allreduce_sum(double *buf, size_t n) override { ok(cb_.allreduce_sum_f64(cb_.ctx, buf, (long long)n), "allreduce_sum_f64"); }
+    void allreduce_max(double *buf, size_t n) override { ok(cb_.allreduce_max_f64(cb_.ctx, buf, (long long)n), "allreduce_max_f64"); }
+    void allgather(const void *send, void *recv, size_t bytes) override { ok(cb_.allgather_bytes(cb_.ctx, send, recv, (long long)bytes), "allgather_bytes"); }
+    void barrier() override { ok(cb_.barrier(cb_.ctx), "barrier"); }
+};
+
+// RCCL called directly.  Only the handful of entry points used are resolved.
+class RcclComm : public Comm
+{
+  public:
+    static constexpr int kUniqueIdBytes = 128; // NCCL_UNIQUE_ID_BYTES
+
+  private:
+    struct UniqueId
+    {
+        char internal[kUniqueIdBytes];
+    };
+    typedef int (*GetUniqueId_t)(UniqueId *);
+    typedef int (*CommInitRank_t)(void **, int, UniqueId, int);
+    typedef int (*CommDestroy_t)(void *);
+    typedef int (*AllReduce_t)(const void *, void *, size_t, int, int, void *, void *);
+    typedef int (*AllGather_t)(const void *, void *, size_t, int, void *, void *);
+    typedef const char *(*GetErrorString_t)(int);
+
+    void *lib_ = nullptr;
+    void *comm_ = nullptr;
+    memory token_;
+    GetUniqueId_t get_unique_id_ = nullptr;
+    CommInitRank_t comm_init_rank_ = nullptr;
+    CommDestroy_t comm_destroy_ = nullptr;
+    AllReduce_t all_reduce_ = nullptr;
+    AllGather_t all_gather_ = nullptr;
+    GetErrorString_t get_error_string_ = nullptr;
+
+    enum
+    {
+        kSum = 0,
+        kMax = 2,
+        kInt8 = 0,
+        kFloat64 = 8
+    }; // rccl.h ncclRedOp_t / ncclDataType_t
+
+    void ok(int rc, const char *what)
+    {
+        if (rc != 0)
+        {
+            fprintf(stderr, "ERROR: RCCL %s failed: %s\n", what, get_error_string_ ? get_error_string_(rc) : "?");
+            exit(EXIT_FAILURE);
+        }
+    }
+
+    void load()
+    {
+        if (lib_) return;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names)
+        {
+            lib_ = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (lib_) break;
+        }
+        if (!lib_)
+        {
+            fprintf(stderr, "ERROR: cannot load librccl: %s\n", dlerror());
+            exit(EXIT_FAILURE);
+        }
+        get_unique_id_ = (GetUniqueId_t)dlsym(lib_, "ncclGetUniqueId");
+        comm_init_rank_ = (CommInitRank_t)dlsym(lib_, "ncclCommInitRank");
+        comm_destroy_ = (CommDestroy_t)dlsym(lib_, "ncclCommDestroy");
+        all_reduce_ = (AllReduce_t)dlsym(lib_, "ncclAllReduce");
+        all_gather_ = (AllGather_t)dlsym(lib_, "ncclAllGather");
+        get_error_string_ = (GetErrorString_t)dlsym(lib_, "ncclGetErrorString");
+        if (!get_unique_id_ || !comm_init_rank_ || !all_reduce_ || !all_gather_)
+        {
+            fprintf(stderr, "ERROR: librccl lacks a required entry point\n");
+            exit(EXIT_FAILURE);
+        }
+    }
+
+  public:
+    RcclComm() { load(); }
+    ~RcclComm() override
+    {
+        if (comm_ && comm_destroy_) comm_destroy_(comm_);
+    }
+    const char *name() const override { return "rccl"; }
+
+    // rank 0 creates the id; the launcher ships the 128 bytes to every rank
+    void unique_id(char *out128)
+    {
+        UniqueId id;
+        ok(get_unique_id_(&id), "ncclGetUniqueId");
+        memcpy(out128, id.internal, kUniqueIdBytes);
+    }
+
+    void init(const char *id128, int rank_, int size_)
+    {
+        UniqueId id;
+        memcpy(id.internal, id128, kUniqueIdBytes);
+        rank = rank_;
+        size = size_;
+        ok(comm_init_rank_(&comm_, size_, id, rank_), "ncclCommInitRank");
+        token_ = dev().malloc<double>(1);
+    }
+
+    void allreduce_sum(double *buf, size_t n) override { ok(all_reduce_(buf, buf, n, kFloat64, kSum, comm_, dev().stream), "ncclAllReduce"); }
+    void allreduce_max(double *buf, size_t n) override { ok(all_reduce_(buf, buf, n, kFloat64, kMax, comm_, dev().stream), "ncclAllReduce"); }
+    void allgather(const void *send, void *recv, size_t bytes) override { ok(all_gather_(send, recv, bytes, kInt8, comm_, dev().stream), "ncclAllGather"); }
+    void barrier() override
+    {
+        FDD_CALL(fdd_memset(token_.ptr(), 0, sizeof(double), dev().stream));
+        allreduce_sum(token_.as<double>(), 1);
+        dev().finish();
+    }
+};
+
+inline Comm *&comm_ptr()
+{
+    static Comm *c = new SingleComm();
+    return c;
+}
+
+inline Comm &comm() { return *comm_ptr(); }
+
+inline void set_comm(Comm *c)
+{
+    Comm *&p = comm_ptr();
+    if (p != c) delete p;
+    p = c;
+}
+
+} // namespace fdd
+
+#endif

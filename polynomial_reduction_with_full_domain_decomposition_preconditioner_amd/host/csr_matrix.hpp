@@ -1,0 +1,218 @@
+/*
+ * csr_matrix.hpp -- CSR_Matrix<DType>: the reference's sparse-matrix host
+ * class (csr_matrix.hpp:15-56, csr_matrix.tpp:28-341) with the same public
+ * members and methods, on the gfx950 SpMV kernels.
+ *
+ * Differences that matter:
+ *   - assemble() also builds the SpMV row-block plan (fdd_csr_plan_create)
+ *     while it still holds the host `ptr`; the multiply methods use it;
+ *   - duplicates are summed in insertion order (a stable sort; the
+ *     reference's std::sort leaves the order of equal keys unspecified);
+ *   - host copies of ptr/col/val are kept (setup code walks them), so
+ *     transpose()/diagonal()/print() need no device round trip.
+ */
+#ifndef FDD_CSR_MATRIX_HPP
+#define FDD_CSR_MATRIX_HPP
+
+#include <algorithm>
+#include <cmath>
+#include <tuple>
+#include <type_traits>
+#include <vector>
+
+#include "config.hpp"
+
+template <typename DType>
+class CSR_Matrix
+{
+    static_assert(std::is_same<DType, double>::value, "the gfx950 SpMV kernels are fp64");
+
+  private:
+    int is_initialized = false;
+    DType sparse_tolerance = 1.0e-12;
+    std::vector<std::tuple<int, int, DType>> entries;
+    fdd_csr_plan *plan = nullptr;
+
+    void initialization_check()
+    {
+        if (not is_initialized)
+        {
+            printf("ERROR: CSR matrix has not been initialize\n");
+            exit(EXIT_FAILURE);
+        }
+    }
+
+  public:
+    int num_rows = 0;
+    int num_cols = 0;
+    int num_nnz = 0;
+    fdd::memory ptr;
+    fdd::memory col;
+    fdd::memory val;
+
+    // host mirrors (valid after assemble)
+    std::vector<int> ptr_hst;
+    std::vector<int> col_hst;
+    std::vector<DType> val_hst;
+
+    CSR_Matrix() {}
+    CSR_Matrix(int num_rows_, int num_cols_) { initialize(num_rows_, num_cols_); }
+    ~CSR_Matrix() {}
+
+    void initialize(int num_rows_, int num_cols_)
+    {
+        num_rows = num_rows_;
+        num_cols = num_cols_;
+        num_nnz = 0;
+        sparse_tolerance = 1.0e-12; // csr_matrix.tpp:61-64
+        is_initialized = true;
+    }
+
+    void reserve(size_t n) { entries.reserve(n); }
+
+    void add_entry(int row, int col_, DType val_)
+    {
+        if ((row < 0) or (row >= num_rows) or (col_ < 0) or (col_ >= num_cols))
+        {
+            printf("ERROR: Entry at (%d, %d) is outside the matrix of size (%d, %d)\n", row, col_, num_rows, num_cols);
+            exit(EXIT_FAILURE);
+        }
+
+        if (std::abs(val_) > sparse_tolerance) entries.push_back(std::tuple<int, int, DType>(row, col_, val_));
+    }
+
+    void assemble()
+    {
+        if ((num_rows == 0) or (num_cols == 0) or (entries.size() == 0)) return;
+
+        initialization_check();
+
+        std::stable_sort(entries.begin(), entries.end(), [](const std::tuple<int, int, DType> &a, const std::tuple<int, int, DType> &b) {
+            if (std::get<0>(a) != std::get<0>(b)) return std::get<0>(a) < std::get<0>(b);
+            return std::get<1>(a) < std::get<1>(b);
+        });
+
+        ptr_hst.assign(num_rows + 1, 0);
+        col_hst.clear();
+        val_hst.clear();
+        col_hst.reserve(entries.size());
+        val_hst.reserve(entries.size());
+
+        int last_row = -1, last_col = -1;
+        for (auto &entry : entries)
+        {
+            const int r = std::get<0>(entry), c = std::get<1>(entry);
+            if (r != last_row or c != last_col)
+            {
+                ptr_hst[r + 1]++;
+                col_hst.push_back(c);
+                val_hst.push_back(std::get<2>(entry));
+                last_row = r;
+                last_col = c;
+            }
+            else
+            {
+                val_hst.back() += std::get<2>(entry);
+            }
+        }
+
+        for (int i = 1; i <= num_rows; i++) ptr_hst[i] += ptr_hst[i - 1];
+        num_nnz = (int)col_hst.size();
+
+        ptr = fdd::dev().malloc<int>(num_rows + 1);
+        col = fdd::dev().malloc<int>(num_nnz);
+        val = fdd::dev().malloc<DType>(num_nnz);
+
+        ptr.copyFrom(ptr_hst.data(), (num_rows + 1) * sizeof(int));
+        col.copyFrom(col_hst.data(), num_nnz * sizeof(int));
+        val.copyFrom(val_hst.data(), num_nnz * sizeof(DType));
+
+        if (plan) FDD_CALL(fdd_csr_plan_destroy(plan));
+        FDD_CALL(fdd_csr_plan_create(&plan, ptr_hst.data(), num_rows, num_cols, num_nnz));
+
+        entries.clear();
+        entries.shrink_to_fit();
+    }
+
+    // drop the host mirrors of a large matrix once setup no longer needs them
+    void release_host()
+    {
+        std::vector<int>().swap(ptr_hst);
+        std::vector<int>().swap(col_hst);
+        std::vector<DType>().swap(val_hst);
+    }
+
+    void print(FILE *file_ptr = NULL, int offset = 0)
+    {
+        FILE *out = file_ptr ? file_ptr : fdd::globals().pstdout_file;
+        if (!out) out = stdout;
+        fprintf(out, "num_rows = %d, num_cols = %d, num_nnz = %d\n", num_rows, num_cols, num_nnz);
+        if ((num_rows == 0) or (num_cols == 0) or (num_nnz == 0)) return;
+        for (int i = 0; i < num_rows; i++)
+            for (int j = ptr_hst[i]; j < ptr_hst[i + 1]; j++) fprintf(out, "(%d, %d): %.16g\n", i + offset, col_hst[j] + offset, val_hst[j]);
+    }
+
+    void transpose(CSR_Matrix &At)
+    {
+        At.initialize(num_cols, num_rows);
+        if ((num_rows == 0) or (num_cols == 0)) return;
+        At.reserve(num_nnz);
+        for (int i = 0; i < num_rows; i++)
+            for (int j = ptr_hst[i]; j < ptr_hst[i + 1]; j++) At.add_entry(col_hst[j], i, val_hst[j]);
+        At.assemble();
+    }
+
+    void diagonal(fdd::memory D)
+    {
+        if ((num_rows == 0) or (num_cols == 0)) return;
+        initialization_check();
+        std::vector<DType> work(num_rows, 0.0);
+        for (int i = 0; i < num_rows; i++)
+            for (int j = ptr_hst[i]; j < ptr_hst[i + 1]; j++)
+                if (i == col_hst[j])
+                {
+                    work[i] = val_hst[j];
+                    break;
+                }
+        D.copyFrom(work.data(), num_rows * sizeof(DType));
+    }
+
+    void multiply(fdd::memory &Au, fdd::memory &u)
+    {
+        if ((num_rows == 0) or (num_cols == 0)) return;
+        initialization_check();
+        if (num_nnz == 0) // never assembled (csr_matrix.tpp:96 leaves no device arrays): A = 0
+        {
+            FDD_CALL(fdd_set_to_value(Au.as<double>(), 0.0, num_rows, 0, fdd::dev().stream));
+            return;
+        }
+        FDD_CALL(fdd_csr_plan_multiply(plan, Au.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), u.as<double>(), nullptr, fdd::dev().stream));
+    }
+
+    void multiply_range(fdd::memory &Au, fdd::memory &u, int row_start, int row_end)
+    {
+        if ((num_rows == 0) or (num_cols == 0)) return;
+        initialization_check();
+        if (row_end < row_start)
+        {
+            printf("Row end (i_e = %d) has to be greater or equal to row start (i_s = %d)\n", row_end, row_start);
+            exit(EXIT_FAILURE);
+        }
+        if (num_nnz == 0) return;
+        FDD_CALL(fdd_csr_multiply_range(Au.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), u.as<double>(), row_start, row_end, fdd::dev().stream));
+    }
+
+    void multiply_weight(fdd::memory &Au, fdd::memory &u, fdd::memory &weight)
+    {
+        if ((num_rows == 0) or (num_cols == 0)) return;
+        initialization_check();
+        if (num_nnz == 0)
+        {
+            FDD_CALL(fdd_set_to_value(Au.as<double>(), 0.0, num_rows, 0, fdd::dev().stream));
+            return;
+        }
+        FDD_CALL(fdd_csr_plan_multiply(plan, Au.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), u.as<double>(), weight.as<double>(), fdd::dev().stream));
+    }
+};
+
+#endif

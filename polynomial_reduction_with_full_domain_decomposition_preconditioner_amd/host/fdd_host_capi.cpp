@@ -1,0 +1,569 @@
+// C-ABI over the C++ host classes (include/fdd_host.h).  Everything here is
+// plumbing: it instantiates Domain<double> / Subdomain<double> the way the
+// reference's run_simulation does (poisson.cpp:150-251) and moves host vectors
+// in and out of device memory.
+#include "fdd_host.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <sys/stat.h>
+#include <unordered_map>
+#include <vector>
+
+#include "box_mesh.hpp"
+#include "domain.hpp"
+#include "subdomain.hpp"
+
+typedef double SType; // config.hpp:19 STYPE
+typedef double PType; // config.hpp:20 PTYPE (AMG/config.hpp:4 Float)
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+struct fddh_problem
+{
+    int poly_degree = 1;
+    int poly_reduction = 1;
+    std::vector<int> degrees; // N, N-r, ..., 1
+    std::unordered_map<int, Domain<SType>> domains;
+    std::unique_ptr<Subdomain<PType>> subdomain;
+    NoPreconditioner none;
+
+    // device staging vectors
+    fdd::memory a, b, c;
+    fdd::memory sa, sb; // subdomain-sized
+
+    Domain<SType> &fine() { return domains[poly_degree]; }
+    const Domain<SType> &fine() const { return domains.at(poly_degree); }
+};
+
+static std::vector<int> level_degrees(int N, int reduction)
+{
+    std::vector<int> d;
+    d.push_back(N);
+    while (d.back() > 1)
+    {
+        int r = d.back() - reduction;
+        d.push_back(r >= 1 ? r : 1);
+    }
+    return d;
+}
+
+static void finish_problem(fddh_problem *p, int with_subdomain, int sub_overlap, int sup_overlap)
+{
+    Domain<SType> &dom = p->fine();
+    p->a = fdd::dev().malloc<double>(dom.num_local_points);
+    p->b = fdd::dev().malloc<double>(dom.num_local_points);
+    p->c = fdd::dev().malloc<double>(dom.num_local_points);
+    if (with_subdomain)
+    {
+        rstdout("Setting up subdomain object...\n");
+        p->subdomain.reset(new Subdomain<PType>(p->domains, p->poly_degree, p->poly_reduction, sub_overlap, sup_overlap));
+        p->sa = fdd::dev().malloc<double>(p->subdomain->num_values);
+        p->sb = fdd::dev().malloc<double>(p->subdomain->num_values);
+        dom.use_preconditioner = true;
+    }
+    else
+    {
+        dom.use_preconditioner = false;
+    }
+}
+
+extern "C" {
+
+const char *fddh_last_error(void) { return g_err; }
+
+int fddh_init(int device, void *stream)
+{
+    if (fdd_set_device(device) != 0) return fail("fdd_set_device(%d): %s", device, fdd_last_error());
+    if (stream == nullptr)
+    {
+        void *s = nullptr;
+        if (fdd_stream_create(&s) != 0) return fail("fdd_stream_create: %s", fdd_last_error());
+        stream = s;
+    }
+    fdd::dev().stream = stream;
+    return 0;
+}
+
+int fddh_set_print(int on)
+{
+    fdd::globals().print = on != 0;
+    return 0;
+}
+
+int fddh_set_timer(int on)
+{
+    timer.enabled = on != 0;
+    if (on) timer.initialize();
+    return 0;
+}
+
+int fddh_timer_total(const char *key, double *seconds)
+{
+    if (!key || !seconds) return fail("null argument");
+    *seconds = timer.total(key);
+    return 0;
+}
+
+int fddh_comm_single(void)
+{
+    fdd::set_comm(new fdd::SingleComm());
+    fdd::globals().proc_id = 0;
+    fdd::globals().num_procs = 1;
+    return 0;
+}
+
+int fddh_comm_rccl_unique_id(char *out128)
+{
+    if (!out128) return fail("null argument");
+    fdd::RcclComm tmp;
+    tmp.unique_id(out128);
+    return 0;
+}
+
+int fddh_comm_rccl_init(const char *id128, int rank, int size)
+{
+    if (!id128 || rank < 0 || size < 1 || rank >= size) return fail("bad rank/size");
+    fdd::RcclComm *c = new fdd::RcclComm();
+    c->init(id128, rank, size);
+    fdd::set_comm(c);
+    fdd::globals().proc_id = rank;
+    fdd::globals().num_procs = size;
+    return 0;
+}
+
+int fddh_comm_callbacks(int rank, int size, void *ctx, fddh_allreduce_fn allreduce_sum_f64, fddh_allreduce_fn allreduce_max_f64, fddh_allgather_fn allgather_bytes, fddh_barrier_fn barrier)
+{
+    if (rank < 0 || size < 1 || rank >= size || !allreduce_sum_f64 || !allreduce_max_f64 || !allgather_bytes || !barrier) return fail("bad callback set");
+    fdd::CommCallbacks cb;
+    cb.ctx = ctx;
+    cb.allreduce_sum_f64 = allreduce_sum_f64;
+    cb.allreduce_max_f64 = allreduce_max_f64;
+    cb.allgather_bytes = allgather_bytes;
+    cb.barrier = barrier;
+    fdd::set_comm(new fdd::CallbackComm(rank, size, cb));
+    fdd::globals().proc_id = rank;
+    fdd::globals().num_procs = size;
+    return 0;
+}
+
+int fddh_comm_info(int *rank, int *size, char *name, size_t name_len)
+{
+    if (rank) *rank = fdd::comm().rank;
+    if (size) *size = fdd::comm().size;
+    if (name && name_len) snprintf(name, name_len, "%s", fdd::comm().name());
+    return 0;
+}
+
+int fddh_problem_create_box(fddh_problem **out, const int E[3], const int P[3], int poly_degree, int poly_reduction, int with_subdomain)
+{
+    if (!out || !E || !P || poly_degree < 1 || poly_reduction < 1) return fail("bad argument");
+    if (P[0] * P[1] * P[2] != fdd::comm().size) return fail("rank grid %dx%dx%d does not match communicator size %d", P[0], P[1], P[2], fdd::comm().size);
+    for (int d = 0; d < 3; d++)
+        if (E[d] < 1 || P[d] < 1 || E[d] % P[d] != 0) return fail("elements per direction must be a multiple of the rank blocks");
+
+    fddh_problem *p = new fddh_problem();
+    p->poly_degree = poly_degree;
+    p->poly_reduction = poly_reduction;
+    p->degrees = with_subdomain ? level_degrees(poly_degree, poly_reduction) : std::vector<int>(1, poly_degree);
+
+    fdd::BoxSpec spec;
+    for (int d = 0; d < 3; d++)
+    {
+        spec.E[d] = E[d];
+        spec.P[d] = P[d];
+    }
+
+    for (int deg : p->degrees)
+    {
+        rstdout("Setting up domain \"N = %d\" object...\n", deg);
+        p->domains[deg].initialize(fdd::make_box_mesh<SType>(spec, deg, fdd::comm().rank));
+    }
+    // `dim` follows the last mesh read in the reference; keep the fine one current
+    fdd::globals().dim = p->fine().mesh.dim;
+
+    finish_problem(p, with_subdomain, 1, 1);
+    *out = p;
+    return 0;
+}
+
+int fddh_problem_create_dir(fddh_problem **out, const char *directory, int poly_degree, int poly_reduction, int subdomain_overlap, int superdomain_overlap, int with_subdomain)
+{
+    if (!out || !directory || poly_degree < 1 || poly_reduction < 1) return fail("bad argument");
+    fddh_problem *p = new fddh_problem();
+    p->poly_degree = poly_degree;
+    p->poly_reduction = poly_reduction;
+    p->degrees = with_subdomain ? level_degrees(poly_degree, poly_reduction) : std::vector<int>(1, poly_degree);
+    for (int deg : p->degrees)
+    {
+        MeshData<SType> m;
+        if (!Domain<SType>::read_mesh_files(directory, deg, fdd::comm().rank, m))
+        {
+            delete p;
+            return fail("cannot read mesh files of degree %d for rank %d under '%s'", deg, fdd::comm().rank, directory);
+        }
+        rstdout("Setting up domain \"N = %d\" object...\n", deg);
+        p->domains[deg].initialize(std::move(m));
+    }
+    fdd::globals().dim = p->fine().mesh.dim;
+    finish_problem(p, with_subdomain, subdomain_overlap, superdomain_overlap);
+    *out = p;
+    return 0;
+}
+
+int fddh_problem_destroy(fddh_problem *p)
+{
+    // Like the reference (empty destructors, domain.tpp:24-28), device memory of
+    // the host classes is released at process end; the staging vectors are freed.
+    if (!p) return 0;
+    p->a.free();
+    p->b.free();
+    p->c.free();
+    p->sa.free();
+    p->sb.free();
+    delete p;
+    return 0;
+}
+
+int fddh_write_box_mesh_files(const char *directory, const int E[3], const int P[3], int poly_degree, int rank)
+{
+    if (!directory || !E || !P) return fail("null argument");
+    fdd::BoxSpec spec;
+    for (int d = 0; d < 3; d++)
+    {
+        spec.E[d] = E[d];
+        spec.P[d] = P[d];
+    }
+    MeshData<SType> m = fdd::make_box_mesh<SType>(spec, poly_degree, rank);
+    char sub[4096];
+    mkdir(directory, 0777);
+    snprintf(sub, sizeof(sub), "%s/lx1_%d", directory, poly_degree + 1);
+    mkdir(sub, 0777);
+    if (!Domain<SType>::write_mesh_files(directory, rank, m)) return fail("cannot write mesh files under '%s'", directory);
+    return 0;
+}
+
+int fddh_problem_info(const fddh_problem *p, long long *info, int n)
+{
+    if (!p || !info) return fail("null argument");
+    const Domain<SType> &d = p->fine();
+    long long v[FDDH_INFO_COUNT];
+    v[FDDH_INFO_NUM_LOCAL_POINTS] = d.num_local_points;
+    v[FDDH_INFO_NUM_LOCAL_NODES] = d.num_local_nodes;
+    v[FDDH_INFO_NUM_BDARY_NODES] = d.boundary_nodes_count();
+    v[FDDH_INFO_NUM_INTERFACE_SLOTS] = d.interface_slots_count();
+    v[FDDH_INFO_NUM_TOTAL_NODES] = d.num_total_nodes;
+    v[FDDH_INFO_NUM_TOTAL_ELEMENTS] = d.num_total_elements;
+    v[FDDH_INFO_NUM_LOCAL_ELEMENTS] = d.num_local_elements;
+    v[FDDH_INFO_NUM_LEVELS] = (long long)p->degrees.size();
+    v[FDDH_INFO_SUB_NUM_VALUES] = p->subdomain ? p->subdomain->num_values : 0;
+    v[FDDH_INFO_SUB_NUM_DOFS] = p->subdomain ? p->subdomain->dofs() : 0;
+    v[FDDH_INFO_NUM_ITERATIONS] = d.num_iterations;
+    for (int i = 0; i < n && i < FDDH_INFO_COUNT; i++) info[i] = v[i];
+    return 0;
+}
+
+int fddh_problem_level_degree(const fddh_problem *p, int level, int *poly_degree)
+{
+    if (!p || !poly_degree || level < 0 || level >= (int)p->degrees.size()) return fail("bad level");
+    *poly_degree = p->degrees[level];
+    return 0;
+}
+
+int fddh_problem_mesh_array(const fddh_problem *p, int level, const char *name, void *out, size_t bytes)
+{
+    if (!p || !name || !out || level < 0 || level >= (int)p->degrees.size()) return fail("bad argument");
+    const MeshData<SType> &m = p->domains.at(p->degrees[level]).mesh;
+    const void *src = nullptr;
+    size_t have = 0;
+    std::string s(name);
+    if (s == "x") { src = m.x.data(); have = m.x.size() * sizeof(SType); }
+    else if (s == "y") { src = m.y.data(); have = m.y.size() * sizeof(SType); }
+    else if (s == "z") { src = m.z.data(); have = m.z.size() * sizeof(SType); }
+    else if (s == "glo_num") { src = m.glo_num.data(); have = m.glo_num.size() * sizeof(long long); }
+    else if (s == "node_degree") { src = m.node_degree.data(); have = m.node_degree.size() * sizeof(int); }
+    else if (s == "p_mask") { src = m.p_mask.data(); have = m.p_mask.size() * sizeof(SType); }
+    else if (s.size() == 3 && s[0] == 'g' && s[1] == '_' && s[2] >= '1' && s[2] <= '6') { const int g = s[2] - '1'; src = m.g[g].data(); have = m.g[g].size() * sizeof(SType); }
+    else return fail("unknown mesh array '%s'", name);
+    if (bytes != have) return fail("mesh array '%s' has %zu bytes, caller gave %zu", name, have, bytes);
+    memcpy(out, src, have);
+    return 0;
+}
+
+int fddh_problem_csr(const fddh_problem *cp, int which, int *num_rows, int *num_cols, int *num_nnz, int *ptr, int *col, double *val)
+{
+    if (!cp) return fail("null argument");
+    fddh_problem *p = const_cast<fddh_problem *>(cp);
+    CSR_Matrix<SType> &A = (which == 0) ? p->fine().scatter_matrix() : p->fine().gather_matrix();
+    if (num_rows) *num_rows = A.num_rows;
+    if (num_cols) *num_cols = A.num_cols;
+    if (num_nnz) *num_nnz = A.num_nnz;
+    if (ptr) memcpy(ptr, A.ptr_hst.data(), A.ptr_hst.size() * sizeof(int));
+    if (col) memcpy(col, A.col_hst.data(), A.col_hst.size() * sizeof(int));
+    if (val) memcpy(val, A.val_hst.data(), A.val_hst.size() * sizeof(double));
+    return 0;
+}
+
+int fddh_problem_assembled_weight(const fddh_problem *cp, double *out, int n)
+{
+    if (!cp || !out) return fail("null argument");
+    fddh_problem *p = const_cast<fddh_problem *>(cp);
+    if (n != p->fine().num_local_nodes) return fail("assembled_weight has %d entries", p->fine().num_local_nodes);
+    p->fine().assembled_weight_memory().copyTo(out, (size_t)n * sizeof(double));
+    return 0;
+}
+
+int fddh_problem_set_D_hat(fddh_problem *p, int level, const double *D_hat, int n)
+{
+    if (!p || !D_hat || level < 0 || level >= (int)p->degrees.size()) return fail("bad argument");
+    if (n != p->degrees[level] + 1) return fail("D_hat of level %d is %d x %d", level, p->degrees[level] + 1, p->degrees[level] + 1);
+    p->domains[p->degrees[level]].set_D_hat(D_hat, n);
+    return 0;
+}
+
+int fddh_problem_get_D_hat(const fddh_problem *p, int level, double *D_hat, int n)
+{
+    if (!p || !D_hat || level < 0 || level >= (int)p->degrees.size()) return fail("bad argument");
+    if (n != p->degrees[level] + 1) return fail("wrong size");
+    const std::vector<double> &D = p->domains.at(p->degrees[level]).D_hat_hst;
+    memcpy(D_hat, D.data(), D.size() * sizeof(double));
+    return 0;
+}
+
+int fddh_problem_set_options(fddh_problem *p, int max_iterations, double tolerance, int num_vectors, int use_preconditioner, int preconditioner_type, int sub_num_vectors, int sub_max_iterations, int sub_build_tree)
+{
+    if (!p) return fail("null argument");
+    Domain<SType> &d = p->fine();
+    if (max_iterations >= 0) d.max_iterations = max_iterations;
+    if (!std::isnan(tolerance) && tolerance >= 0.0) d.tolerance = tolerance;
+    if (num_vectors > 0) d.num_vectors = num_vectors;
+    if (use_preconditioner >= 0)
+    {
+        if (use_preconditioner && !p->subdomain) return fail("problem was created without a Subdomain");
+        d.use_preconditioner = use_preconditioner != 0;
+    }
+    if (preconditioner_type >= 0) d.preconditioner_type = preconditioner_type;
+    if (p->subdomain)
+    {
+        if (sub_num_vectors > 0) p->subdomain->num_vectors = sub_num_vectors;
+        if (sub_max_iterations >= 0) p->subdomain->max_iterations = sub_max_iterations;
+        if (sub_build_tree >= 0) p->subdomain->build_tree = sub_build_tree != 0;
+    }
+    return 0;
+}
+
+int fddh_problem_dssum(fddh_problem *p, double *out, const double *in, int apply_mask, int apply_weight)
+{
+    if (!p || !out || !in) return fail("null argument");
+    Domain<SType> &d = p->fine();
+    const size_t bytes = (size_t)d.num_local_points * sizeof(double);
+    p->a.copyFrom(in, bytes);
+    d.direct_stiffness_summation(p->b, p->a, apply_mask != 0, apply_weight != 0);
+    p->b.copyTo(out, bytes);
+    return 0;
+}
+
+int fddh_problem_stiffness(fddh_problem *p, double *out, const double *in, int apply_dssum)
+{
+    if (!p || !out || !in) return fail("null argument");
+    Domain<SType> &d = p->fine();
+    const size_t bytes = (size_t)d.num_local_points * sizeof(double);
+    p->a.copyFrom(in, bytes);
+    d.stiffness_matrix(p->b, p->a, apply_dssum != 0);
+    p->b.copyTo(out, bytes);
+    return 0;
+}
+
+int fddh_problem_residual_norm(fddh_problem *p, const double *r, double *norm)
+{
+    if (!p || !r || !norm) return fail("null argument");
+    Domain<SType> &d = p->fine();
+    const size_t bytes = (size_t)d.num_local_points * sizeof(double);
+    // ||r|| = sqrt(<r, r>) through the public pieces (Domain::residual_norm is private, domain.hpp:71)
+    p->a.copyFrom(r, bytes);
+    d.direct_stiffness_summation(p->b, p->a);
+    fdd::memory ws = fdd::dev().malloc<double>(fdd_reduce_workspace_doubles());
+    fdd::memory sc = fdd::dev().malloc<double>(1);
+    FDD_CALL(fdd_dom_residual_norm(sc.as<double>(), ws.as<double>(), p->a.as<double>(), p->b.as<double>(), d.dirichlet_mask_memory().as<double>(), d.num_local_points, fdd::dev().stream));
+    if (fdd::comm().size > 1) fdd::comm().allreduce_sum(sc.as<double>(), 1);
+    double v = 0.0;
+    sc.copyTo(&v, sizeof(double));
+    ws.free();
+    sc.free();
+    *norm = std::sqrt(v);
+    return 0;
+}
+
+int fddh_problem_make_rhs(fddh_problem *p, int function_id, unsigned long long seed, double *u_star, double *f)
+{
+    if (!p) return fail("null argument");
+    Domain<SType> &d = p->fine();
+    const size_t bytes = (size_t)d.num_local_points * sizeof(double);
+    d.initial_function(p->a, function_id, seed); // poisson.cpp:211-213
+    d.stiffness_matrix(p->b, p->a);              // poisson.cpp:219 (no dssum)
+    if (u_star) p->a.copyTo(u_star, bytes);
+    if (f) p->b.copyTo(f, bytes);
+    return 0;
+}
+
+int fddh_problem_make_rhs_from(fddh_problem *p, double *u_star_inout, double *f)
+{
+    if (!p || !u_star_inout) return fail("null argument");
+    Domain<SType> &d = p->fine();
+    const size_t bytes = (size_t)d.num_local_points * sizeof(double);
+    p->a.copyFrom(u_star_inout, bytes);
+    d.direct_stiffness_summation(p->a, p->a, true, true); // domain.tpp:579
+    d.stiffness_matrix(p->b, p->a);
+    p->a.copyTo(u_star_inout, bytes);
+    if (f) p->b.copyTo(f, bytes);
+    return 0;
+}
+
+int fddh_problem_solve(fddh_problem *p, int solver_id, const double *f, double *u, double *history, int history_cap, int *num_history, int *num_iterations)
+{
+    if (!p || !f || !u) return fail("null argument");
+    Domain<SType> &d = p->fine();
+    const size_t bytes = (size_t)d.num_local_points * sizeof(double);
+    p->a.copyFrom(f, bytes);
+
+    if (p->subdomain)
+    {
+        if (solver_id == 0)
+            d.flexible_conjugate_gradient(p->b, p->a, *p->subdomain);
+        else
+            d.generalized_minimum_residual(p->b, p->a, *p->subdomain);
+    }
+    else
+    {
+        if (solver_id == 0)
+            d.flexible_conjugate_gradient(p->b, p->a, p->none);
+        else
+            d.generalized_minimum_residual(p->b, p->a, p->none);
+    }
+
+    p->b.copyTo(u, bytes);
+    const int nh = (int)d.residual_history.size();
+    if (history)
+        for (int i = 0; i < nh && i < history_cap; i++) history[i] = d.residual_history[i];
+    if (num_history) *num_history = nh;
+    if (num_iterations) *num_iterations = d.num_iterations;
+    return 0;
+}
+
+int fddh_problem_precond_apply(fddh_problem *p, int type, const double *r, double *z, double *history, int history_cap, int *num_history)
+{
+    if (!p || !r || !z) return fail("null argument");
+    if (!p->subdomain) return fail("problem was created without a Subdomain");
+    Domain<SType> &d = p->fine();
+    const size_t bytes = (size_t)d.num_local_points * sizeof(double);
+    p->a.copyFrom(r, bytes);
+    if (type == 0)
+        p->subdomain->flexible_conjugate_gradient(p->b, p->a);
+    else
+        p->subdomain->generalized_minimum_residual(p->b, p->a);
+    p->b.copyTo(z, bytes);
+    const int nh = (int)p->subdomain->residual_history.size();
+    if (history)
+        for (int i = 0; i < nh && i < history_cap; i++) history[i] = p->subdomain->residual_history[i];
+    if (num_history) *num_history = nh;
+    return 0;
+}
+
+int fddh_problem_sub_op(fddh_problem *p, int op, const double *in, double *out)
+{
+    if (!p || !in || !out) return fail("null argument");
+    if (!p->subdomain) return fail("problem was created without a Subdomain");
+    Subdomain<PType> &s = *p->subdomain;
+    const size_t bytes = (size_t)s.num_values * sizeof(double);
+    if (op == 0)
+    {
+        // tree_operator: input is an outer (Domain) vector
+        p->a.copyFrom(in, (size_t)p->fine().num_local_points * sizeof(double));
+        s.apply_tree_operator(p->sb, p->a);
+    }
+    else
+    {
+        p->sa.copyFrom(in, bytes);
+        if (op == 1)
+            s.stiffness_matrix(p->sb, p->sa);
+        else if (op == 2)
+            s.direct_stiffness_summation(p->sb, p->sa);
+        else
+            return fail("unknown subdomain op %d", op);
+    }
+    p->sb.copyTo(out, bytes);
+    return 0;
+}
+
+int fddh_problem_sub_residual_norm(fddh_problem *p, const double *r, double *norm)
+{
+    if (!p || !r || !norm) return fail("null argument");
+    if (!p->subdomain) return fail("problem was created without a Subdomain");
+    p->sa.copyFrom(r, (size_t)p->subdomain->num_values * sizeof(double));
+    p->subdomain->compute_residual_norm(*norm, p->sa);
+    return 0;
+}
+
+int fddh_problem_pcg_begin(fddh_problem *p, const double *f)
+{
+    if (!p || !f) return fail("null argument");
+    Domain<SType> &d = p->fine();
+    p->a.copyFrom(f, (size_t)d.num_local_points * sizeof(double));
+    if (p->subdomain && d.use_preconditioner)
+        d.fcg_begin(p->b, p->a, *p->subdomain);
+    else
+        d.fcg_begin(p->b, p->a, p->none);
+    return 0;
+}
+
+int fddh_problem_pcg_steps(fddh_problem *p, int steps, double *last_residual)
+{
+    if (!p || steps < 0) return fail("bad argument");
+    Domain<SType> &d = p->fine();
+    double r = std::numeric_limits<double>::quiet_NaN();
+    for (int s = 0; s < steps; s++)
+    {
+        if (p->subdomain && d.use_preconditioner)
+            r = d.fcg_step(*p->subdomain);
+        else
+            r = d.fcg_step(p->none);
+    }
+    if (last_residual) *last_residual = r;
+    return 0;
+}
+
+int fddh_problem_pcg_solution(fddh_problem *p, double *u)
+{
+    if (!p || !u) return fail("null argument");
+    p->b.copyTo(u, (size_t)p->fine().num_local_points * sizeof(double));
+    return 0;
+}
+
+int fddh_sync(void)
+{
+    fdd::dev().finish();
+    return 0;
+}
+
+int fddh_barrier(void)
+{
+    fdd::dev().finish();
+    fdd::comm().barrier();
+    fdd::dev().finish();
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,238 @@
+/*
+ * poisson.cpp -- the driver, same command line as the reference
+ * (poisson.cpp:61-68):
+ *
+ *     poisson <directory> <polynomial degree> <polynomial reduction>
+ *             <subdomain overlap> <superdomain overlap>
+ *
+ * <directory> holds the Nek5000-export file sets lx1_<N+1>/ for every level
+ * degree N, N-r, ..., 1 (domain.tpp:45-224).  Extensions (all optional, after
+ * the five positional arguments):
+ *     --box Ex Ey Ez     generate the synthetic unit-cube mesh instead of
+ *                        reading <directory> (which is then ignored)
+ *     --solver fcg|gmres outer solver (the reference hard-codes solver_id = 1,
+ *                        GMRES, poisson.cpp:224; PCG is solver_id = 0)
+ *     --function ID      manufactured solution id (poisson.cpp:211: 4)
+ *     --no-precond       outer solve without the FDD preconditioner
+ *     --write-mesh DIR   write the box mesh as a reference-format file set
+ *
+ * One process per GPU.  With WORLD_SIZE > 1 in the environment (RANK,
+ * LOCAL_RANK, WORLD_SIZE as set by any launcher) the ranks join an RCCL
+ * communicator whose unique id travels through the file named by
+ * FDD_RCCL_ID_FILE (rank 0 writes it); MPI is not needed.
+ */
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unistd.h>
+
+#include "fdd_host.h"
+
+static void die(const char *what)
+{
+    fprintf(stderr, "ERROR: %s: %s\n", what, fddh_last_error());
+    exit(EXIT_FAILURE);
+}
+
+static int env_int(const char *name, int def)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : def;
+}
+
+static void library_banner(int rank)
+{
+    if (rank != 0) return;
+    printf("----------------------------------------------------------------------------------\n");
+    printf("|  Full domain decomposition with polynomial reduction -- MI355X (gfx950) build   |\n");
+    printf("----------------------------------------------------------------------------------\n\n");
+}
+
+int main(int argc, char *argv[])
+{
+    const int rank = env_int("RANK", 0);
+    const int size = env_int("WORLD_SIZE", 1);
+    const int local_rank = env_int("LOCAL_RANK", 0);
+
+    if (fddh_init(local_rank, nullptr)) die("fddh_init");
+    library_banner(rank);
+
+    if (size > 1)
+    {
+        const char *id_file = getenv("FDD_RCCL_ID_FILE");
+        if (!id_file)
+        {
+            fprintf(stderr, "ERROR: WORLD_SIZE > 1 needs FDD_RCCL_ID_FILE\n");
+            return EXIT_FAILURE;
+        }
+        char id[128];
+        if (rank == 0)
+        {
+            if (fddh_comm_rccl_unique_id(id)) die("fddh_comm_rccl_unique_id");
+            std::string tmp = std::string(id_file) + ".tmp";
+            FILE *f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(id, 1, 128, f) != 128)
+            {
+                fprintf(stderr, "ERROR: cannot write %s\n", tmp.c_str());
+                return EXIT_FAILURE;
+            }
+            fclose(f);
+            rename(tmp.c_str(), id_file);
+        }
+        else
+        {
+            FILE *f = nullptr;
+            for (int tries = 0; tries < 6000 && !(f = fopen(id_file, "rb")); tries++) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            if (!f || fread(id, 1, 128, f) != 128)
+            {
+                fprintf(stderr, "ERROR: cannot read %s\n", id_file);
+                return EXIT_FAILURE;
+            }
+            fclose(f);
+        }
+        if (fddh_comm_rccl_init(id, rank, size)) die("fddh_comm_rccl_init");
+    }
+    else
+    {
+        fddh_comm_single();
+    }
+
+    if (argc < 6)
+    {
+        if (rank == 0) printf("ERROR: Use as 'poisson <directory> <polynomial degree> <polynomial reduction> <subdomain overlap> <superdomain overlap>'\n");
+        return EXIT_SUCCESS; // the reference's quit() exits with SUCCESS (config.hpp:57-62)
+    }
+
+    const char *directory = argv[1];
+    const int poly_degree = atoi(argv[2]);
+    const int poly_reduction = atoi(argv[3]);
+    const int subdomain_overlap = atoi(argv[4]);
+    const int superdomain_overlap = atoi(argv[5]);
+
+    int box[3] = {0, 0, 0};
+    int solver_id = 1;
+    int function_id = 4;
+    int with_subdomain = 1;
+    const char *write_dir = nullptr;
+    for (int a = 6; a < argc; a++)
+    {
+        if (!strcmp(argv[a], "--box") && a + 3 < argc)
+        {
+            box[0] = atoi(argv[a + 1]);
+            box[1] = atoi(argv[a + 2]);
+            box[2] = atoi(argv[a + 3]);
+            a += 3;
+        }
+        else if (!strcmp(argv[a], "--solver") && a + 1 < argc)
+            solver_id = !strcmp(argv[++a], "fcg") ? 0 : 1;
+        else if (!strcmp(argv[a], "--function") && a + 1 < argc)
+            function_id = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--no-precond"))
+            with_subdomain = 0;
+        else if (!strcmp(argv[a], "--write-mesh") && a + 1 < argc)
+            write_dir = argv[++a];
+    }
+
+    if (rank == 0)
+    {
+        printf("Running simulation with:\n");
+        printf("- Directory: \"%s\"\n", directory);
+        printf("- Polynomial degree: \"%d\"\n", poly_degree);
+        printf("- Polynomial reduction: \"%d\"\n", poly_reduction);
+        printf("- Subdomain overlap: \"%d\"\n", subdomain_overlap);
+        printf("- Superdomain overlap: \"%d\"\n\n", superdomain_overlap);
+    }
+
+    // rank blocks: powers of two go round-robin over x, y, z
+    int P[3] = {1, 1, 1};
+    for (int s = size, d = 0; s > 1 && s % 2 == 0; s /= 2, d = (d + 1) % 3) P[d] *= 2;
+
+    fddh_problem *problem = nullptr;
+    if (box[0] > 0)
+    {
+        if (write_dir)
+        {
+            int deg = poly_degree;
+            for (;;)
+            {
+                if (fddh_write_box_mesh_files(write_dir, box, P, deg, rank)) die("fddh_write_box_mesh_files");
+                if (deg == 1 || !with_subdomain) break;
+                deg = (deg - poly_reduction >= 1) ? deg - poly_reduction : 1;
+            }
+        }
+        if (fddh_problem_create_box(&problem, box, P, poly_degree, poly_reduction, with_subdomain)) die("fddh_problem_create_box");
+    }
+    else
+    {
+        FILE *fp = fopen(directory, "r");
+        if (fp == NULL)
+        {
+            if (rank == 0) printf("Directory '%s' does not exist. Make sure the directory has all the 'lx1' subdirectories", directory);
+            return EXIT_SUCCESS;
+        }
+        fclose(fp);
+        if (fddh_problem_create_dir(&problem, directory, poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, with_subdomain)) die("fddh_problem_create_dir");
+    }
+
+    long long info[FDDH_INFO_COUNT];
+    fddh_problem_info(problem, info, FDDH_INFO_COUNT);
+    const size_t npts = (size_t)info[FDDH_INFO_NUM_LOCAL_POINTS];
+
+    if (rank == 0) printf("\nSetting up exact function...\nSetting up right-hand-side...\n");
+    double *u_star = (double *)malloc(npts * sizeof(double));
+    double *f = (double *)malloc(npts * sizeof(double));
+    double *u = (double *)malloc(npts * sizeof(double));
+    if (fddh_problem_make_rhs(problem, function_id, 1234ULL + (unsigned long long)rank, u_star, f)) die("fddh_problem_make_rhs");
+
+    if (rank == 0) printf("Solving Poisson problem...\n");
+    fddh_set_timer(1);
+    int nhist = 0, its = 0;
+    fddh_barrier();
+    auto t0 = std::chrono::high_resolution_clock::now();
+    if (fddh_problem_solve(problem, solver_id, f, u, nullptr, 0, &nhist, &its)) die("fddh_problem_solve");
+    fddh_barrier();
+    auto t1 = std::chrono::high_resolution_clock::now();
+    const double seconds = std::chrono::duration<double>(t1 - t0).count();
+
+    double err = 0.0;
+    for (size_t i = 0; i < npts; i++) err = std::max(err, std::fabs(u[i] - u_star[i]));
+
+    if (rank == 0)
+    {
+        printf("\nRun info:\n");
+        printf("-------------------------------------------------------------------------\n");
+        printf("Number of dimensions: %d\n", 3);
+        printf("Total number of elements: %lld\n", info[FDDH_INFO_NUM_TOTAL_ELEMENTS]);
+        printf("Total number of unique nodes: %lld\n", info[FDDH_INFO_NUM_TOTAL_NODES]);
+        printf("Polynomial degree: %d\n", poly_degree);
+        printf("Function ID: %d\n", function_id);
+        printf("Solver data precision: double\n");
+        printf("Solver type: \"%s\"\n", (solver_id == 0) ? "FCG" : "GMRES");
+        printf("Preconditioner: %s\n", with_subdomain ? "FDD subdomain solve (own elements, GMRES(4))" : "none");
+        printf("Iterations: %d\n", its);
+        printf("Solve wall time: %.6f s\n", seconds);
+        printf("max |u - u*| on rank 0: %.3e\n", err);
+        if (its > 0) printf("DOF-updates/s: %.4e\n", (double)info[FDDH_INFO_NUM_TOTAL_NODES] * its / seconds);
+
+        // timing table (poisson.cpp:253-401), per-rank regions of rank 0
+        const char *keys[] = {"domain.inner_products", "domain.residual_norm", "domain.vector_operations", "domain.operator_application", "subdomain.stitching", "subdomain.solver"};
+        printf("\nTiming (rank 0, seconds):\n");
+        for (const char *k : keys)
+        {
+            double s = 0.0;
+            fddh_timer_total(k, &s);
+            printf("  %-32s %10.6f\n", k, s);
+        }
+    }
+
+    free(u_star);
+    free(f);
+    free(u);
+    fddh_problem_destroy(problem);
+    return EXIT_SUCCESS;
+}

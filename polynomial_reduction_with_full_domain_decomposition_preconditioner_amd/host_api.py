@@ -1,0 +1,305 @@
+"""Python plumbing over libfdd_host.so (include/fdd_host.h): numpy vectors in
+and out, communicator set-up from torch.distributed.  The solver itself is the
+C++ host layer on the HIP kernels; nothing here computes."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import lib
+
+vp = ctypes.c_void_p
+
+INFO_NAMES = [
+    "num_local_points",
+    "num_local_nodes",
+    "num_bdary_nodes",
+    "num_interface_slots",
+    "num_total_nodes",
+    "num_total_elements",
+    "num_local_elements",
+    "num_levels",
+    "sub_num_values",
+    "sub_num_dofs",
+    "num_iterations",
+]
+
+_ALLREDUCE = ctypes.CFUNCTYPE(ctypes.c_int, vp, vp, ctypes.c_longlong)
+_ALLGATHER = ctypes.CFUNCTYPE(ctypes.c_int, vp, vp, vp, ctypes.c_longlong)
+_BARRIER = ctypes.CFUNCTYPE(ctypes.c_int, vp)
+
+_keepalive = []
+
+
+def _H():
+    return lib.host()
+
+
+def init(device: int = 0, use_torch_stream: bool = True) -> None:
+    """Bind this process to a GPU.  With use_torch_stream the kernels run on
+    torch's current stream, which orders them with torch.distributed
+    collectives issued from the communication callbacks."""
+    stream = None
+    if use_torch_stream:
+        import torch
+
+        torch.cuda.set_device(device)
+        stream = vp(torch.cuda.current_stream().cuda_stream)
+    _H().call("fddh_init", device, stream)
+
+
+def set_print(on: bool) -> None:
+    _H().call("fddh_set_print", int(on))
+
+
+def comm_single() -> None:
+    _H().call("fddh_comm_single")
+
+
+def comm_rccl_from_torch() -> None:
+    """RCCL called directly from the host layer; the 128-byte unique id is
+    shipped through torch.distributed's store (no GPU traffic)."""
+    import torch.distributed as dist
+
+    rank, size = dist.get_rank(), dist.get_world_size()
+    buf = ctypes.create_string_buffer(128)
+    if rank == 0:
+        _H().call("fddh_comm_rccl_unique_id", buf)
+    obj = [bytes(buf.raw) if rank == 0 else None]
+    dist.broadcast_object_list(obj, src=0)
+    ident = ctypes.create_string_buffer(obj[0], 128)
+    _H().call("fddh_comm_rccl_init", ident, rank, size)
+
+
+class _DevView:
+    """Minimal __cuda_array_interface__ holder so torch can wrap a raw device pointer."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def comm_torch_callbacks(on_gpu: bool = True) -> None:
+    """Collectives through torch.distributed (backend "nccl" = RCCL on GPUs,
+    "gloo" on CPU buffers in the CPU test build)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, size = dist.get_rank(), dist.get_world_size()
+
+    def wrap(ptr, n, dtype):
+        if on_gpu:
+            typestr = {torch.float64: "<f8", torch.uint8: "|u1"}[dtype]
+            return torch.as_tensor(_DevView(ptr, (n,), typestr), device="cuda")
+        ctype = {torch.float64: ctypes.c_double, torch.uint8: ctypes.c_uint8}[dtype]
+        arr = np.ctypeslib.as_array((ctype * n).from_address(ptr))
+        return torch.from_numpy(arr)
+
+    def allreduce(op):
+        def fn(ctx, buf, n):
+            try:
+                t = wrap(buf, int(n), torch.float64)
+                dist.all_reduce(t, op=op)
+                return 0
+            except Exception as exc:  # pragma: no cover - surfaced by the C++ side
+                print("allreduce callback failed:", exc, flush=True)
+                return 1
+
+        return fn
+
+    def allgather(ctx, send, recv, nbytes):
+        try:
+            nbytes = int(nbytes)
+            s = wrap(send, nbytes, torch.uint8)
+            r = wrap(recv, nbytes * size, torch.uint8)
+            dist.all_gather_into_tensor(r, s) if on_gpu else dist.all_gather(list(r.chunk(size)), s)
+            return 0
+        except Exception as exc:  # pragma: no cover
+            print("allgather callback failed:", exc, flush=True)
+            return 1
+
+    def barrier(ctx):
+        try:
+            dist.barrier()
+            return 0
+        except Exception as exc:  # pragma: no cover
+            print("barrier callback failed:", exc, flush=True)
+            return 1
+
+    cbs = (_ALLREDUCE(allreduce(dist.ReduceOp.SUM)), _ALLREDUCE(allreduce(dist.ReduceOp.MAX)), _ALLGATHER(allgather), _BARRIER(barrier))
+    _keepalive.append(cbs)
+    _H().call("fddh_comm_callbacks", rank, size, None, *[ctypes.cast(c, vp) for c in cbs])
+
+
+def rank_grid(num_ranks: int):
+    """Same rule as the C++ driver: powers of two go round-robin over x, y, z."""
+    P = [1, 1, 1]
+    d = 0
+    while num_ranks > 1 and num_ranks % 2 == 0:
+        P[d] *= 2
+        num_ranks //= 2
+        d = (d + 1) % 3
+    P[0] *= num_ranks
+    return tuple(P)
+
+
+def _arr3(v: Sequence[int]):
+    return (ctypes.c_int * 3)(*[int(x) for x in v])
+
+
+def _dp(a: Optional[np.ndarray]):
+    if a is None:
+        return vp(0)
+    assert a.flags["C_CONTIGUOUS"]
+    return vp(a.ctypes.data)
+
+
+class Problem:
+    """One rank's Domains (levels N, N-r, ..., 1) and optional Subdomain."""
+
+    def __init__(self, handle):
+        self.h = handle
+        self.info = self._info()
+        self.n = self.info["num_local_points"]
+
+    @classmethod
+    def box(cls, E, P=(1, 1, 1), poly_degree=7, poly_reduction=2, with_subdomain=True):
+        h = vp()
+        _H().call("fddh_problem_create_box", ctypes.byref(h), _arr3(E), _arr3(P), poly_degree, poly_reduction, int(with_subdomain))
+        return cls(h)
+
+    @classmethod
+    def from_directory(cls, directory, poly_degree, poly_reduction, subdomain_overlap=1, superdomain_overlap=1, with_subdomain=True):
+        h = vp()
+        _H().call("fddh_problem_create_dir", ctypes.byref(h), os.fsencode(directory), poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, int(with_subdomain))
+        return cls(h)
+
+    def close(self):
+        if self.h:
+            _H().call("fddh_problem_destroy", self.h)
+            self.h = None
+
+    def _info(self):
+        buf = (ctypes.c_longlong * len(INFO_NAMES))()
+        _H().call("fddh_problem_info", self.h, buf, len(INFO_NAMES))
+        return {k: int(buf[i]) for i, k in enumerate(INFO_NAMES)}
+
+    def refresh(self):
+        self.info = self._info()
+        return self.info
+
+    def level_degree(self, level):
+        d = ctypes.c_int()
+        _H().call("fddh_problem_level_degree", self.h, level, ctypes.byref(d))
+        return d.value
+
+    def mesh_array(self, name, level=0):
+        deg = self.level_degree(level)
+        npts = self.info["num_local_elements"] * (deg + 1) ** 3
+        dtype = {"glo_num": np.int64, "node_degree": np.int32}.get(name, np.float64)
+        out = np.zeros(npts, dtype)
+        _H().call("fddh_problem_mesh_array", self.h, level, name.encode(), _dp(out), out.nbytes)
+        return out
+
+    def csr(self, which):
+        nr, nc, nz = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _H().call("fddh_problem_csr", self.h, which, ctypes.byref(nr), ctypes.byref(nc), ctypes.byref(nz), None, None, None)
+        ptr = np.zeros(nr.value + 1, np.int32)
+        col = np.zeros(nz.value, np.int32)
+        val = np.zeros(nz.value)
+        _H().call("fddh_problem_csr", self.h, which, None, None, None, _dp(ptr), _dp(col), _dp(val))
+        return (nr.value, nc.value), ptr, col, val
+
+    def assembled_weight(self):
+        out = np.zeros(self.info["num_local_nodes"])
+        _H().call("fddh_problem_assembled_weight", self.h, _dp(out), len(out))
+        return out
+
+    def set_D_hat(self, level, D):
+        D = np.ascontiguousarray(D, dtype=np.float64)
+        n = self.level_degree(level) + 1
+        _H().call("fddh_problem_set_D_hat", self.h, level, _dp(D), n)
+
+    def get_D_hat(self, level):
+        n = self.level_degree(level) + 1
+        D = np.zeros(n * n)
+        _H().call("fddh_problem_get_D_hat", self.h, level, _dp(D), n)
+        return D
+
+    def set_options(self, max_iterations=-1, tolerance=float("nan"), num_vectors=-1, use_preconditioner=-1, preconditioner_type=-1, sub_num_vectors=-1, sub_max_iterations=-1, sub_build_tree=-1):
+        _H().call("fddh_problem_set_options", self.h, max_iterations, tolerance, num_vectors, int(use_preconditioner), preconditioner_type, sub_num_vectors, sub_max_iterations, int(sub_build_tree))
+
+    def dssum(self, u, mask=True, weight=False):
+        out = np.zeros(self.n)
+        _H().call("fddh_problem_dssum", self.h, _dp(out), _dp(np.ascontiguousarray(u)), int(mask), int(weight))
+        return out
+
+    def stiffness(self, u, dssum=False):
+        out = np.zeros(self.n)
+        _H().call("fddh_problem_stiffness", self.h, _dp(out), _dp(np.ascontiguousarray(u)), int(dssum))
+        return out
+
+    def residual_norm(self, r):
+        v = ctypes.c_double()
+        _H().call("fddh_problem_residual_norm", self.h, _dp(np.ascontiguousarray(r)), ctypes.byref(v))
+        return v.value
+
+    def make_rhs(self, function_id=0, seed=0):
+        u_star, f = np.zeros(self.n), np.zeros(self.n)
+        _H().call("fddh_problem_make_rhs", self.h, function_id, seed, _dp(u_star), _dp(f))
+        return u_star, f
+
+    def make_rhs_from(self, u_star):
+        u_star = np.ascontiguousarray(u_star, dtype=np.float64).copy()
+        f = np.zeros(self.n)
+        _H().call("fddh_problem_make_rhs_from", self.h, _dp(u_star), _dp(f))
+        return u_star, f
+
+    def solve(self, f, method="fcg"):
+        u = np.zeros(self.n)
+        cap = 4096
+        hist = np.zeros(cap)
+        nh, its = ctypes.c_int(), ctypes.c_int()
+        _H().call("fddh_problem_solve", self.h, 0 if method == "fcg" else 1, _dp(np.ascontiguousarray(f)), _dp(u), _dp(hist), cap, ctypes.byref(nh), ctypes.byref(its))
+        return u, its.value, hist[: min(nh.value, cap)].copy()
+
+    def precond_apply(self, r, method="gmres"):
+        z = np.zeros(self.n)
+        hist = np.zeros(64)
+        nh = ctypes.c_int()
+        _H().call("fddh_problem_precond_apply", self.h, 0 if method == "fcg" else 1, _dp(np.ascontiguousarray(r)), _dp(z), _dp(hist), 64, ctypes.byref(nh))
+        return z, hist[: nh.value].copy()
+
+    def sub_op(self, op, u):
+        code = {"tree": 0, "stiffness": 1, "dssum": 2}[op]
+        out = np.zeros(self.info["sub_num_values"])
+        _H().call("fddh_problem_sub_op", self.h, code, _dp(np.ascontiguousarray(u)), _dp(out))
+        return out
+
+    def sub_residual_norm(self, r):
+        v = ctypes.c_double()
+        _H().call("fddh_problem_sub_residual_norm", self.h, _dp(np.ascontiguousarray(r)), ctypes.byref(v))
+        return v.value
+
+    def pcg_begin(self, f):
+        _H().call("fddh_problem_pcg_begin", self.h, _dp(np.ascontiguousarray(f)))
+
+    def pcg_steps(self, steps):
+        v = ctypes.c_double()
+        _H().call("fddh_problem_pcg_steps", self.h, steps, ctypes.byref(v))
+        return v.value
+
+    def pcg_solution(self):
+        u = np.zeros(self.n)
+        _H().call("fddh_problem_pcg_solution", self.h, _dp(u))
+        return u
+
+
+def sync():
+    _H().call("fddh_sync")
+
+
+def barrier():
+    _H().call("fddh_barrier")

@@ -31,6 +31,7 @@ _SCALARS = {
     "float": ctypes.c_float,
     "size_t": ctypes.c_size_t,
     "long long": ctypes.c_longlong,
+    "unsigned long long": ctypes.c_ulonglong,
     "long": ctypes.c_long,
 }
 
@@ -49,6 +50,8 @@ def _ctype_of(decl: str):
     tname = " ".join(type_words)
     if tname in _SCALARS:
         return _SCALARS[tname]
+    if tname.endswith("_fn"):  # function-pointer typedefs
+        return ctypes.c_void_p
     raise FddError(f"cannot map C parameter '{decl}'")
 
 

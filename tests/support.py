@@ -239,6 +239,28 @@ class BoxMesh:
         return m
 
 
+class ArrayMesh(BoxMesh):
+    """A mesh given by its arrays (e.g. the ones the C++ host layer generated,
+    so that oracle and product see bit-identical geometric factors)."""
+
+    def __init__(self, N, num_local_elements, arrays):
+        self.N = N
+        self.num_local_elements = num_local_elements
+        self.num_elem_points = (N + 1) ** 3
+        self.num_local_points = num_local_elements * self.num_elem_points
+        self.x, self.y, self.z = arrays["x"], arrays["y"], arrays["z"]
+        self.glo_num = arrays["glo_num"]
+        self.node_degree = arrays["node_degree"]
+        self.p_mask = arrays["p_mask"]
+        self.g = [arrays[f"g_{k + 1}"] for k in range(6)]
+
+    @classmethod
+    def from_problem(cls, problem, level=0):
+        names = ["x", "y", "z", "glo_num", "node_degree", "p_mask"] + [f"g_{k + 1}" for k in range(6)]
+        arrays = {n: problem.mesh_array(n, level) for n in names}
+        return cls(problem.level_degree(level), problem.info["num_local_elements"], arrays)
+
+
 def rank_grid(num_ranks):
     """Rank blocks for a cube: 1->(1,1,1), 2->(2,1,1), 4->(2,2,1), 8->(2,2,2)."""
     return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[num_ranks]
@@ -335,10 +357,10 @@ class OracleWorld:
 class OracleSubdomain:
     """orc_subdomain for one rank's own elements (conforming composite)."""
 
-    def __init__(self, E, N, reduction, P=(1, 1, 1), rank=0):
+    def __init__(self, E, N, reduction, P=(1, 1, 1), rank=0, meshes=None):
         self.L = oracle()
         self.deg = level_degrees(N, reduction)
-        self.meshes = [BoxMesh(E, d, P, rank) for d in self.deg]
+        self.meshes = meshes if meshes is not None else [BoxMesh(E, d, P, rank) for d in self.deg]
         nl = len(self.deg)
         self._cm = (OrcMesh * nl)(*[m.orc_mesh() for m in self.meshes])
         self._D = [np.ascontiguousarray(gll(d)[2]) for d in self.deg]

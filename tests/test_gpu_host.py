@@ -1,0 +1,231 @@
+"""GPU parity of the C++ host layer (Domain / Subdomain / CSR_Matrix mirrors of
+the reference, libfdd_host.so) against the CPU oracle, through the C-ABI of
+include/fdd_host.h, on the same seeded inputs.
+
+Tolerances: operators built from bit-exact kernels must be
+bit-identical; reductions and therefore Krylov histories are tolerance-based:
+identical iteration counts, residual history within 1e-8 relative, solution
+within 1e-9 of the oracle's in the max norm.
+"""
+import numpy as np
+import pytest
+
+import support as S
+from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
+
+pytestmark = pytest.mark.gpu
+
+E1, N1, RED1 = (4, 4, 4), 3, 2  # BASELINE config C1
+
+
+@pytest.fixture(scope="module")
+def setup(gpu):
+    H.init(0)
+    H.comm_single()
+    H.set_print(False)
+    return True
+
+
+def make_problem(E, N, red, with_sub=True):
+    p = H.Problem.box(E, (1, 1, 1), N, red, with_sub)
+    # feed the reference's own GLL tables so operator parity is bit-exact
+    for lvl in range(p.info["num_levels"]):
+        p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
+    return p
+
+
+def oracle_subdomain(p, N, red):
+    meshes = [S.ArrayMesh.from_problem(p, lvl) for lvl in range(p.info["num_levels"])]
+    return S.OracleSubdomain(None, N, red, meshes=meshes)
+
+
+def test_gll_tables_of_the_host_layer(setup):
+    """host/gll.hpp against the reference's Fortran speclib tables."""
+    p = H.Problem.box((2, 2, 2), (1, 1, 1), 15, 1, True)
+    try:
+        assert p.info["num_levels"] == 15
+        for lvl in range(15):
+            N = p.level_degree(lvl)
+            D = p.get_D_hat(lvl)
+            ref = S.gll(N)[2]
+            assert np.abs(D - ref).max() <= 2e-13 * np.abs(ref).max(), N
+    finally:
+        p.close()
+
+
+def test_box_mesh_matches_numpy_statement(setup):
+    p = make_problem((4, 6, 2), 3, 2, False)
+    m = S.BoxMesh((4, 6, 2), 3)
+    try:
+        assert np.array_equal(p.mesh_array("glo_num"), m.glo_num)
+        assert np.array_equal(p.mesh_array("node_degree"), m.node_degree)
+        assert np.array_equal(p.mesh_array("p_mask"), m.p_mask)
+        for name, ref in (("x", m.x), ("y", m.y), ("z", m.z)):
+            assert np.abs(p.mesh_array(name) - ref).max() < 1e-15
+        for g in range(6):
+            got = p.mesh_array(f"g_{g + 1}")
+            assert np.abs(got - m.g[g]).max() <= 1e-15 * max(np.abs(m.g[g]).max(), 1e-300) + 0.0
+        assert p.info["num_total_nodes"] == m.global_nodes
+    finally:
+        p.close()
+
+
+def test_domain_setup_and_operators(setup):
+    p = make_problem(E1, N1, RED1, False)
+    m = S.ArrayMesh.from_problem(p)  # oracle and product share the mesh arrays bit for bit
+    W = S.OracleWorld([m], N1)
+    try:
+        assert p.info["num_local_points"] == 4096 and p.info["num_local_nodes"] == 2197
+        assert p.info["num_bdary_nodes"] == 0
+        # Q / Qt / weights (domain.tpp:233-302)
+        for which, ref in ((0, W.Q(0)), (1, W.Qt(0))):
+            _, ptr, col, val = p.csr(which)
+            assert np.array_equal(ptr, ref[0]) and np.array_equal(col, ref[1]) and np.array_equal(val, ref[2])
+        assert np.array_equal(p.assembled_weight(), W.assembled_weight(0))
+
+        u = S.seeded_uniform(p.n, 1234)
+        for mask, weight in ((True, False), (True, True), (False, False), (False, True)):
+            assert np.array_equal(p.dssum(u, mask, weight), W.dssum([u], mask, weight)[0])
+        assert np.array_equal(p.stiffness(u), W.stiffness([u])[0])
+        assert np.array_equal(p.stiffness(u, dssum=True), W.stiffness([u], True)[0])
+        ref = W.residual_norm([u])
+        assert abs(p.residual_norm(u) - ref) <= 1e-13 * ref
+    finally:
+        W.close()
+        p.close()
+
+
+@pytest.mark.parametrize("method", ["fcg", "gmres"])
+@pytest.mark.parametrize("rhs", ["sin", "seeded"])
+def test_outer_solve_without_preconditioner(setup, method, rhs):
+    """Config C1 plumbing: outer solver with use_preconditioner = false
+    (domain.tpp:648-651)."""
+    p = make_problem(E1, N1, RED1, False)
+    m = S.ArrayMesh.from_problem(p)  # oracle and product share the mesh arrays bit for bit
+    W = S.OracleWorld([m], N1)
+    try:
+        if rhs == "sin":
+            us = np.sin(np.pi * m.x) * np.sin(np.pi * m.y) * np.sin(np.pi * m.z)
+        else:
+            us = S.seeded_uniform(p.n, 1234)
+        u_star, f = p.make_rhs_from(us)
+        o_star = W.dssum([us], True, True)
+        o_f = W.stiffness(o_star)
+        assert np.array_equal(u_star, o_star[0]) and np.array_equal(f, o_f[0])
+
+        u, its, hist = p.solve(f, method)
+        ou, oits, ohist = W.solve(o_f, method)
+        assert its == oits and len(hist) == len(ohist)
+        assert np.abs(hist - ohist).max() <= 1e-8 * ohist[0]
+        assert np.abs(u - ou[0]).max() <= 1e-9 * np.abs(ou[0]).max()
+        # the check the reference omits: the manufactured solution is recovered
+        assert np.abs(u - u_star).max() <= 1e-3 * np.abs(u_star).max()
+    finally:
+        W.close()
+        p.close()
+
+
+def test_subdomain_operators(setup):
+    p = make_problem(E1, N1, RED1, True)
+    sd = oracle_subdomain(p, N1, RED1)
+    try:
+        assert p.info["num_levels"] == len(sd.deg) == 2
+        assert p.info["sub_num_values"] == sd.num_values
+        assert p.info["sub_num_dofs"] == sd.L.orc_subdomain_num_dofs(sd.s) == 11 ** 3
+        u = S.seeded_uniform(p.n, 77)
+        assert np.array_equal(p.sub_op("tree", u), sd.tree(u))
+        assert np.array_equal(p.sub_op("stiffness", u), sd.stiffness(u))
+        assert np.array_equal(p.sub_op("dssum", u), sd.dssum(u))
+        ref = sd.residual_norm(u)
+        assert abs(p.sub_residual_norm(u) - ref) <= 1e-13 * ref
+    finally:
+        sd.close()
+        p.close()
+
+
+@pytest.mark.parametrize("method", ["gmres", "fcg"])
+def test_preconditioner_application(setup, method):
+    """Subdomain::generalized_minimum_residual / flexible_conjugate_gradient
+    (subdomain.tpp:4309-4489 / 4161-4268), 4 inner iterations."""
+    p = make_problem(E1, N1, RED1, True)
+    sd = oracle_subdomain(p, N1, RED1)
+    try:
+        r = S.seeded_uniform(p.n, 5) - 0.5
+        z, hist = p.precond_apply(r, method)
+        oz, oits, ohist = sd.solve(r, method)
+        assert len(hist) == len(ohist) == 5
+        assert np.abs(hist - ohist).max() <= 1e-10 * ohist[0]
+        assert np.abs(z - oz).max() <= 1e-10 * np.abs(oz).max()
+    finally:
+        sd.close()
+        p.close()
+
+
+@pytest.mark.parametrize("outer", ["fcg", "gmres"])
+@pytest.mark.parametrize("inner", ["gmres", "fcg"])
+def test_fdd_preconditioned_solve(setup, outer, inner):
+    """Config C1 end to end: outer Krylov + FDD single-subdomain preconditioner
+    + stitching dssum (domain.tpp:697-706)."""
+    p = make_problem(E1, N1, RED1, True)
+    p.set_options(preconditioner_type=0 if inner == "fcg" else 1)
+    m = S.ArrayMesh.from_problem(p)  # oracle and product share the mesh arrays bit for bit
+    W = S.OracleWorld([m], N1)
+    sd = oracle_subdomain(p, N1, RED1)
+    try:
+        us = S.seeded_uniform(p.n, 1234)
+        u_star, f = p.make_rhs_from(us)
+        u, its, hist = p.solve(f, outer)
+
+        def pre(z, r):
+            out, _, _ = sd.solve(r[0], inner)
+            z[0][:] = out
+
+        ou, oits, ohist = W.solve([f], outer, precond=pre)
+        assert its == oits and len(hist) == len(ohist)
+        assert np.abs(hist - ohist).max() <= 1e-8 * ohist[0]
+        assert np.abs(u - ou[0]).max() <= 1e-9 * np.abs(ou[0]).max()
+        assert np.abs(u - u_star).max() <= 1e-3 * np.abs(u_star).max()
+    finally:
+        sd.close()
+        W.close()
+        p.close()
+
+
+def test_stepwise_pcg_equals_the_solver(setup):
+    """fcg_begin + fcg_step (what bench.py times) walks the same iterates as
+    flexible_conjugate_gradient."""
+    p = make_problem(E1, N1, RED1, True)
+    try:
+        _, f = p.make_rhs_from(S.seeded_uniform(p.n, 9))
+        p.set_options(max_iterations=6, tolerance=0.0)
+        u, its, hist = p.solve(f, "fcg")
+        p.pcg_begin(f)
+        last = p.pcg_steps(6)
+        assert its == 6 and last == hist[6]
+        assert np.array_equal(p.pcg_solution(), u)
+    finally:
+        p.close()
+
+
+def test_mesh_file_roundtrip(setup, tmp_path):
+    """The reference's on-disk input (domain.tpp:45-224): write the box mesh as
+    a Nek5000-style file set, read it back through Domain::initialize(dir, N)."""
+    import ctypes
+
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
+
+    d = str(tmp_path / "mesh")
+    E = (ctypes.c_int * 3)(3, 2, 2)
+    P = (ctypes.c_int * 3)(1, 1, 1)
+    for deg in (3, 1):
+        lib.host().call("fddh_write_box_mesh_files", d.encode(), E, P, deg, 0)
+    p = H.Problem.from_directory(d, 3, 2)
+    q = H.Problem.box((3, 2, 2), (1, 1, 1), 3, 2)
+    try:
+        for name in ("x", "glo_num", "node_degree", "p_mask", "g_1", "g_3"):
+            assert np.array_equal(p.mesh_array(name), q.mesh_array(name))
+        u = S.seeded_uniform(p.n, 3)
+        assert np.array_equal(p.stiffness(u, True), q.stiffness(u, True))
+    finally:
+        p.close()
+        q.close()
