@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config.
+
+    python bench.py --gpus N --steps K --warmup W
+
+metric : "PCG DOF-updates/sec + SpMV GB/s (%HBM peak), 3D Poisson N=7"
+workload: config C2 per GPU -- 3-D Poisson, 32^3 spectral elements of degree
+          N=7 per rank (16 777 216 GLL points / GPU), unit cube, homogeneous
+          Dirichlet; outer flexible PCG (Domain::flexible_conjugate_gradient)
+          preconditioned by the FDD subdomain solve (Subdomain::
+          generalized_minimum_residual, 4 inner iterations, polynomial
+          reduction 6) + stitching dssum.  N ranks = N rank blocks of the
+          cube (2 -> 64x32x32, 4 -> 64x64x32, 8 -> 64^3 = config C4), one
+          process per GPU: weak scaling.
+step    : one full outer PCG iteration (operator apply, gamma/theta dots,
+          u/r update, assembled residual norm, preconditioner application,
+          stitching, flexible dot, search update), vectors resident in HBM.
+value   : unique global nodes x K / (max over ranks of the time of exactly K
+          steps, bracketed by barrier + stream synchronise).
+roofline: the device kernel family with the largest total time in the timed
+          region, timed with HIP events on the rank's own stream; algorithmic
+          bytes per BASELINE.md section 4.
+cpu_baseline: the CPU oracle (serial restatement of the reference's
+          OCCA-Serial path) timed on this box's host cores on a bounded sample
+          (rank 0, N=1 only).  A reported baseline, not a target.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--elements", type=int, default=32, help="elements per direction PER GPU (32 = config C2)")
+    ap.add_argument("--degree", type=int, default=7)
+    ap.add_argument("--reduction", type=int, default=6)
+    ap.add_argument("--comm", choices=["torch", "rccl"], default="torch", help="N>1: torch.distributed(nccl=RCCL) callbacks, or RCCL called directly")
+    ap.add_argument("--no-precond", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-elements", type=int, default=20)
+    ap.add_argument("--cpu-sample-steps", type=int, default=12)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle timed on host cores: same solver structure on a smaller cube."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import support as S
+
+    e, N, red = args.cpu_sample_elements, args.degree, args.reduction
+    deg = S.level_degrees(N, red)
+    meshes = [S.BoxMesh((e, e, e), d) for d in deg]
+    W = S.OracleWorld([meshes[0]], N)
+    sd = None if args.no_precond else S.OracleSubdomain(None, N, red, meshes=meshes)
+    us = W.dssum([S.seeded_uniform(meshes[0].num_local_points, 1234)], True, True)
+    f = W.stiffness(us)
+
+    def pre(z, r):
+        out, _, _ = sd.solve(r[0], "gmres")
+        z[0][:] = out
+
+    steps = args.cpu_sample_steps
+    t0 = time.perf_counter()
+    _, its, _ = W.solve(f, "fcg", max_iterations=steps, tolerance=0.0, precond=None if sd is None else pre)
+    dt = time.perf_counter() - t0
+    nodes = meshes[0].global_nodes
+    W.close()
+    if sd is not None:
+        sd.close()
+    # orc_world_fcg runs `steps` full iterations plus the start-up residual norm
+    # and first preconditioner application, all inside dt (slightly pessimistic)
+    return {
+        "value": nodes * steps / dt,
+        "unit": "DOF-updates/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{e}^3 elements, N={N}, {steps} outer PCG iterations with the same FDD preconditioner (inner GMRES(4)), serial C oracle, {dt:.1f} s",
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
+
+    H.init(local_rank, use_torch_stream=True)
+    H.set_print(False)
+    if world == 1:
+        H.comm_single()
+    elif args.comm == "rccl":
+        H.comm_rccl_from_torch()
+    else:
+        H.comm_torch_callbacks(on_gpu=True)
+
+    P = H.rank_grid(world)
+    e = args.elements
+    E = tuple(e * p for p in P)
+    N = args.degree
+
+    t_setup = time.perf_counter()
+    prob = H.Problem.box(E, P, N, args.reduction, with_subdomain=not args.no_precond)
+    _, f = prob.make_rhs(function_id=4, seed=1234 + rank)  # rand()/RAND_MAX u*, poisson.cpp:211
+    t_setup = time.perf_counter() - t_setup
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    prob.pcg_begin(f)
+    prob.pcg_steps(args.warmup)
+
+    lib.host().call("fddh_profile_enable", 1)
+    H.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last_res = prob.pcg_steps(args.steps)
+    torch.cuda.synchronize()
+    H.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.host().call("fddh_profile_collect", buf, len(buf))
+    lib.host().call("fddh_profile_enable", 0)
+    kernels = json.loads(buf.value.decode())
+
+    info = prob.refresh()
+    nodes = info["num_total_nodes"]
+    value = nodes * args.steps / dt
+
+    # dominant instrumented kernel family of the timed region
+    roofline = None
+    table = {}
+    for name, st in kernels.items():
+        avg_ms = st["ms"] / st["count"]
+        gbps = st["bytes"] / (st["ms"] * 1e-3) / 1e9
+        table[name] = {"launches": st["count"], "avg_us": avg_ms * 1e3, "total_ms": st["ms"], "bytes_per_launch": st["bytes"] / st["count"], "GBps": gbps}
+    if table:
+        dom = max(table, key=lambda k: table[k]["total_ms"])
+        roofline = {
+            "bound": "hbm",
+            "kernel": dom,
+            "achieved": table[dom]["GBps"],
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": table[dom]["GBps"] / HBM_PEAK_GBPS,
+            "traffic": None,
+            "launches": table[dom]["launches"],
+            "avg_launch_us": table[dom]["avg_us"],
+            "algorithmic_bytes_per_launch": table[dom]["bytes_per_launch"],
+        }
+
+    out = {
+        "metric": "PCG DOF-updates/sec + SpMV GB/s (%HBM peak), 3D Poisson N=7",
+        "value": value,
+        "unit": "DOF-updates/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"3D Poisson, {E[0]}x{E[1]}x{E[2]} elements ({e}^3 per GPU), N={N}, flexible PCG + FDD preconditioner (own-element subdomain, inner GMRES(4), polynomial reduction {args.reduction})" + ("" if world == 1 else " [block-local FDD: no neighbour rings / superdomain]"),
+            "elements": list(E),
+            "rank_grid": list(P),
+            "poly_degree": N,
+            "points_per_gpu": info["num_local_points"],
+            "unique_nodes": nodes,
+            "preconditioner": "none" if args.no_precond else "fdd_gmres4",
+            "comm": "single" if world == 1 else args.comm,
+        },
+        "points_updates_per_s": info["num_local_points"] * world * args.steps / dt,
+        "last_residual_norm": last_res,
+        "setup_s": t_setup,
+        "roofline": roofline,
+        "kernels": table,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    else:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    prob.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,9 +23,11 @@ extern "C" {
 const char *fddh_last_error(void);
 
 /* Device and stream of this rank (OCCA_Initialize, poisson.cpp:127-148).
- * stream == NULL creates a private stream; pass torch's current stream to
- * share ordering with torch.distributed collectives. */
-int fddh_init(int device, void *stream);
+ * own_stream != 0 creates a private non-blocking stream (stream is ignored);
+ * otherwise every kernel runs on `stream` exactly as given -- NULL is the
+ * default stream.  Pass torch's current stream to share ordering with
+ * torch.distributed collectives. */
+int fddh_init(int device, void *stream, int own_stream);
 int fddh_set_print(int on); /* rank-0 residual history lines (rstdout) */
 int fddh_set_timer(int on); /* named timing regions (timer.hpp); off by default */
 int fddh_timer_total(const char *key, double *seconds);
@@ -114,6 +116,12 @@ int fddh_problem_sub_residual_norm(fddh_problem *p, const double *r, double *nor
 int fddh_problem_pcg_begin(fddh_problem *p, const double *f);
 int fddh_problem_pcg_steps(fddh_problem *p, int steps, double *last_residual);
 int fddh_problem_pcg_solution(fddh_problem *p, double *u);
+/* Per-kernel timing with HIP events on the rank's stream (bench.py's roofline
+ * object).  collect() synchronises and writes a JSON object
+ * {"<kernel family>": {"count": n, "ms": total, "bytes": algorithmic total}}. */
+int fddh_profile_enable(int on);
+int fddh_profile_collect(char *json, size_t json_len);
+
 int fddh_sync(void);   /* stream synchronise */
 int fddh_barrier(void); /* communicator barrier (stream-ordered, then synchronised) */
 

@@ -32,6 +32,7 @@ class CSR_Matrix
     DType sparse_tolerance = 1.0e-12;
     std::vector<std::tuple<int, int, DType>> entries;
     fdd_csr_plan *plan = nullptr;
+    int plan_kind = 0;
 
     void initialization_check()
     {
@@ -69,6 +70,9 @@ class CSR_Matrix
     }
 
     void reserve(size_t n) { entries.reserve(n); }
+
+    // val + col per non-zero, ptr + y per row, x once
+    double algorithmic_bytes(bool weighted) const { return 12.0 * num_nnz + 12.0 * num_rows + 8.0 * num_cols + (weighted ? 8.0 * num_rows : 0.0); }
 
     void add_entry(int row, int col_, DType val_)
     {
@@ -129,6 +133,7 @@ class CSR_Matrix
 
         if (plan) FDD_CALL(fdd_csr_plan_destroy(plan));
         FDD_CALL(fdd_csr_plan_create(&plan, ptr_hst.data(), num_rows, num_cols, num_nnz));
+        FDD_CALL(fdd_csr_plan_kind(plan, &plan_kind));
 
         entries.clear();
         entries.shrink_to_fit();
@@ -186,6 +191,7 @@ class CSR_Matrix
             FDD_CALL(fdd_set_to_value(Au.as<double>(), 0.0, num_rows, 0, fdd::dev().stream));
             return;
         }
+        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiPlain>" : "csr_block_kernel<EpiPlain>", algorithmic_bytes(false));
         FDD_CALL(fdd_csr_plan_multiply(plan, Au.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), u.as<double>(), nullptr, fdd::dev().stream));
     }
 
@@ -211,6 +217,7 @@ class CSR_Matrix
             FDD_CALL(fdd_set_to_value(Au.as<double>(), 0.0, num_rows, 0, fdd::dev().stream));
             return;
         }
+        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiWeight>" : "csr_block_kernel<EpiWeight>", algorithmic_bytes(true));
         FDD_CALL(fdd_csr_plan_multiply(plan, Au.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), u.as<double>(), weight.as<double>(), fdd::dev().stream));
     }
 };

@@ -521,6 +521,7 @@ class Domain
     {
         if (mesh.dim == 3 and poly_degree <= 15)
         {
+            fdd::ProfileScope prof("fused_stiffness_kernel", 64.0 * num_local_points);
             FDD_CALL(fdd_dom_stiffness_matrix(Au.as<double>(), u.as<double>(), D_hat.as<double>(), G_ptrs, num_local_elements, poly_degree, fdd::dev().stream));
         }
         else

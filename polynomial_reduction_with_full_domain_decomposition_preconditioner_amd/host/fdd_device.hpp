@@ -14,6 +14,9 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
+#include <utility>
+#include <vector>
 
 #include "fdd_hip.h"
 
@@ -96,6 +99,109 @@ inline memory device_t::malloc(size_t n)
     FDD_CALL(fdd_malloc(&p, n * sizeof(T)));
     return memory(p, n, sizeof(T), true);
 }
+
+// Per-kernel timing with HIP events on the rank's own stream (what bench.py's
+// `roofline` object reports).  Off by default; when on, two event records
+// bracket each instrumented launch -- no synchronisation until collect().
+// Keys are the device kernel families as rocprofv3 names them, so the averages
+// can be checked against a --kernel-trace --stats run of the same command.
+class KernelProfiler
+{
+  public:
+    struct Stat
+    {
+        long long count = 0;
+        double ms = 0.0;
+        double bytes = 0.0; // algorithmic bytes, summed over launches
+    };
+
+  private:
+    struct Rec
+    {
+        int key;
+        double bytes;
+        void *e0;
+        void *e1;
+    };
+    std::vector<std::string> keys_;
+    std::vector<Rec> recs_;
+    std::vector<void *> pool_;
+    size_t used_ = 0;
+
+    void *event()
+    {
+        if (used_ == pool_.size())
+        {
+            void *e = nullptr;
+            FDD_CALL(fdd_event_create(&e));
+            pool_.push_back(e);
+        }
+        return pool_[used_++];
+    }
+
+    int key_id(const char *key)
+    {
+        for (size_t i = 0; i < keys_.size(); i++)
+            if (keys_[i] == key) return (int)i;
+        keys_.push_back(key);
+        return (int)keys_.size() - 1;
+    }
+
+  public:
+    bool enabled = false;
+
+    void begin(const char *key, double bytes)
+    {
+        if (!enabled) return;
+        Rec r{key_id(key), bytes, event(), event()};
+        FDD_CALL(fdd_event_record(r.e0, dev().stream));
+        recs_.push_back(r);
+    }
+
+    void end()
+    {
+        if (!enabled) return;
+        FDD_CALL(fdd_event_record(recs_.back().e1, dev().stream));
+    }
+
+    void reset()
+    {
+        recs_.clear();
+        used_ = 0;
+    }
+
+    // synchronises, folds every recorded launch into per-key totals, clears
+    std::vector<std::pair<std::string, Stat>> collect()
+    {
+        dev().finish();
+        std::vector<Stat> stats(keys_.size());
+        for (const Rec &r : recs_)
+        {
+            float ms = 0.0f;
+            FDD_CALL(fdd_event_elapsed_ms(&ms, r.e0, r.e1));
+            stats[r.key].count++;
+            stats[r.key].ms += ms;
+            stats[r.key].bytes += r.bytes;
+        }
+        reset();
+        std::vector<std::pair<std::string, Stat>> out;
+        for (size_t i = 0; i < keys_.size(); i++)
+            if (stats[i].count) out.push_back(std::make_pair(keys_[i], stats[i]));
+        return out;
+    }
+};
+
+inline KernelProfiler &profiler()
+{
+    static KernelProfiler p;
+    return p;
+}
+
+struct ProfileScope
+{
+    ProfileScope(const char *key, double bytes) { profiler().begin(key, bytes); }
+    ~ProfileScope() { profiler().end(); }
+};
 
 } // namespace fdd
 

@@ -85,10 +85,10 @@ extern "C" {
 
 const char *fddh_last_error(void) { return g_err; }
 
-int fddh_init(int device, void *stream)
+int fddh_init(int device, void *stream, int own_stream)
 {
     if (fdd_set_device(device) != 0) return fail("fdd_set_device(%d): %s", device, fdd_last_error());
-    if (stream == nullptr)
+    if (own_stream)
     {
         void *s = nullptr;
         if (fdd_stream_create(&s) != 0) return fail("fdd_stream_create: %s", fdd_last_error());
@@ -549,6 +549,32 @@ int fddh_problem_pcg_solution(fddh_problem *p, double *u)
 {
     if (!p || !u) return fail("null argument");
     p->b.copyTo(u, (size_t)p->fine().num_local_points * sizeof(double));
+    return 0;
+}
+
+int fddh_profile_enable(int on)
+{
+    fdd::profiler().reset();
+    fdd::profiler().enabled = on != 0;
+    return 0;
+}
+
+int fddh_profile_collect(char *json, size_t json_len)
+{
+    if (!json || json_len < 3) return fail("bad buffer");
+    auto stats = fdd::profiler().collect();
+    std::string s = "{";
+    bool first = true;
+    for (auto &kv : stats)
+    {
+        char item[512];
+        snprintf(item, sizeof(item), "%s\"%s\": {\"count\": %lld, \"ms\": %.9g, \"bytes\": %.17g}", first ? "" : ", ", kv.first.c_str(), kv.second.count, kv.second.ms, kv.second.bytes);
+        s += item;
+        first = false;
+    }
+    s += "}";
+    if (s.size() + 1 > json_len) return fail("profile JSON needs %zu bytes", s.size() + 1);
+    memcpy(json, s.c_str(), s.size() + 1);
     return 0;
 }
 

@@ -59,7 +59,7 @@ int main(int argc, char *argv[])
     const int size = env_int("WORLD_SIZE", 1);
     const int local_rank = env_int("LOCAL_RANK", 0);
 
-    if (fddh_init(local_rank, nullptr)) die("fddh_init");
+    if (fddh_init(local_rank, nullptr, 1)) die("fddh_init");
     library_banner(rank);
 
     if (size > 1)

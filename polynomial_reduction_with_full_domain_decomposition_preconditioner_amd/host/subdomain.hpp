@@ -185,6 +185,7 @@ class Subdomain
 
                 if (dim == 3)
                 {
+                    fdd::ProfileScope prof("restriction_fused_kernel", 8.0 * levels[l].num_elements * ((double)n_f * n_f * n_f + (double)n_c * n_c * n_c));
                     FDD_CALL(fdd_sub_restriction(u_c.as<double>(), J.as<double>(), u_f.as<double>(), levels[l].num_elements, n_f, n_c, fdd::dev().stream));
                 }
                 else
@@ -523,8 +524,8 @@ class Subdomain
         {
             if (dim == 3 and ll.poly_degree <= 15)
             {
-                const int n3 = (ll.poly_degree + 1) * (ll.poly_degree + 1) * (ll.poly_degree + 1);
-                (void)n3;
+                const double n3 = (double)(ll.poly_degree + 1) * (ll.poly_degree + 1) * (ll.poly_degree + 1);
+                fdd::ProfileScope prof("fused_stiffness_kernel", 64.0 * n3 * ll.num_elements);
                 if (ll.contiguous)
                 {
                     const double *Gs[NUM_GEOM_FACTS];

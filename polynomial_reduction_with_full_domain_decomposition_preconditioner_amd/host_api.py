@@ -47,8 +47,8 @@ def init(device: int = 0, use_torch_stream: bool = True) -> None:
         import torch
 
         torch.cuda.set_device(device)
-        stream = vp(torch.cuda.current_stream().cuda_stream)
-    _H().call("fddh_init", device, stream)
+        stream = vp(torch.cuda.current_stream().cuda_stream)  # 0 = the default stream
+    _H().call("fddh_init", device, stream, 0 if use_torch_stream else 1)
 
 
 def set_print(on: bool) -> None:
