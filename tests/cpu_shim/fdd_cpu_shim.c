@@ -1,0 +1,208 @@
+/*
+ * fdd_cpu_shim.c -- TEST INFRASTRUCTURE, never shipped, never loaded by the
+ * product.  A stand-in for libfdd_hip.so that implements the same C-ABI
+ * (include/fdd_hip.h) on HOST memory by forwarding every kernel entry to the
+ * CPU oracle (oracle/fdd_oracle.h).  It exists for one purpose: to let the
+ * multi-rank logic of the C++ host layer (rank partition, boundary-first
+ * numbering, interface-slot exchange, scalar all-reduces, communication
+ * callbacks) run in world_size-2 `gloo` tests on a machine without a GPU
+ * (tests/test_cpu_multirank.py).  The product's loader
+ * (polynomial_..._amd/lib.py) only ever opens libfdd_hip.so and fails loudly
+ * without it.  In effect this is the reference's OCCA "Serial" mode.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "fdd_hip.h"
+#include "fdd_oracle.h"
+
+static char g_err[256] = "";
+#define REQ(c)                                                                  \
+    do                                                                          \
+    {                                                                           \
+        if (!(c))                                                               \
+        {                                                                       \
+            snprintf(g_err, sizeof(g_err), "invalid argument: %s", #c);         \
+            return FDD_ERR_INVALID_ARGUMENT;                                    \
+        }                                                                       \
+    } while (0)
+
+const char *fdd_version(void) { return "fdd_cpu_shim (oracle-backed, tests only)"; }
+const char *fdd_last_error(void) { return g_err; }
+int fdd_device_count(int *count) { *count = 1; return 0; }
+int fdd_set_device(int device) { (void)device; return 0; }
+int fdd_get_device(int *device) { *device = 0; return 0; }
+int fdd_device_name(char *buf, size_t n) { snprintf(buf, n, "cpu-shim"); return 0; }
+int fdd_malloc(void **ptr, size_t bytes) { *ptr = bytes ? calloc(1, bytes) : NULL; return (bytes && !*ptr) ? 2 : 0; }
+int fdd_free(void *ptr) { free(ptr); return 0; }
+int fdd_memcpy_h2d(void *d, const void *s, size_t b, void *st) { (void)st; if (b) memmove(d, s, b); return 0; }
+int fdd_memcpy_d2h(void *d, const void *s, size_t b, void *st) { (void)st; if (b) memmove(d, s, b); return 0; }
+int fdd_memcpy_d2d(void *d, const void *s, size_t b, void *st) { (void)st; if (b) memmove(d, s, b); return 0; }
+int fdd_memset(void *d, int v, size_t b, void *st) { (void)st; if (b) memset(d, v, b); return 0; }
+int fdd_stream_create(void **s) { *s = NULL; return 0; }
+int fdd_stream_destroy(void *s) { (void)s; return 0; }
+int fdd_stream_sync(void *s) { (void)s; return 0; }
+int fdd_device_sync(void) { return 0; }
+
+int fdd_event_create(void **e) { *e = calloc(1, sizeof(struct timespec)); return 0; }
+int fdd_event_destroy(void *e) { free(e); return 0; }
+int fdd_event_record(void *e, void *s) { (void)s; clock_gettime(CLOCK_MONOTONIC, (struct timespec *)e); return 0; }
+int fdd_event_elapsed_ms(float *ms, void *a, void *b)
+{
+    struct timespec *x = (struct timespec *)a, *y = (struct timespec *)b;
+    *ms = (float)((y->tv_sec - x->tv_sec) * 1e3 + (y->tv_nsec - x->tv_nsec) * 1e-6);
+    return 0;
+}
+
+/* ---- csr ---- */
+int fdd_csr_multiply(double *Au, const int *p, const int *c, const double *v, const double *u, int n, void *s) { (void)s; REQ(n >= 0); orc_csr_multiply(Au, p, c, v, u, n); return 0; }
+int fdd_csr_multiply_range(double *Au, const int *p, const int *c, const double *v, const double *u, int r0, int r1, void *s) { (void)s; REQ(r0 >= 0 && r1 >= r0); orc_csr_multiply_range(Au, p, c, v, u, r0, r1); return 0; }
+int fdd_csr_multiply_weight(double *Au, const int *p, const int *c, const double *v, const double *u, const double *w, int n, void *s) { (void)s; REQ(n >= 0); orc_csr_multiply_weight(Au, p, c, v, u, w, n); return 0; }
+
+struct fdd_csr_plan { int num_rows, num_cols, num_nnz; };
+int fdd_csr_plan_create(fdd_csr_plan **plan, const int *ptr, int rows, int cols, int nnz)
+{
+    (void)ptr;
+    *plan = (fdd_csr_plan *)calloc(1, sizeof(fdd_csr_plan));
+    (*plan)->num_rows = rows; (*plan)->num_cols = cols; (*plan)->num_nnz = nnz;
+    return 0;
+}
+int fdd_csr_plan_destroy(fdd_csr_plan *plan) { free(plan); return 0; }
+int fdd_csr_plan_num_blocks(const fdd_csr_plan *plan, int *nb) { (void)plan; *nb = 0; return 0; }
+int fdd_csr_plan_kind(const fdd_csr_plan *plan, int *kind) { (void)plan; *kind = 0; return 0; }
+int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *p, const int *c, const double *v, const double *u, const double *w, void *s)
+{
+    (void)s;
+    if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
+    if (w) orc_csr_multiply_weight(Au, p, c, v, u, w, plan->num_rows);
+    else orc_csr_multiply(Au, p, c, v, u, plan->num_rows);
+    return 0;
+}
+
+/* ---- math ---- */
+int fdd_set_to_value(double *u, double a, int n, int off, void *s) { (void)s; REQ(n >= 0); orc_set_to_value(u, a, n, off); return 0; }
+int fdd_invert_vector_elements(double *u, int n, void *s) { (void)s; REQ(n >= 0); orc_invert_vector_elements(u, n); return 0; }
+int fdd_vector_vector_addition(double *uv, double a, const double *u, double b, const double *v, int n, void *s) { (void)s; REQ(n >= 0); orc_vector_vector_addition(uv, a, u, b, v, n); return 0; }
+int fdd_vector_scaling(double *au, double a, const double *u, int n, void *s) { (void)s; REQ(n >= 0); orc_vector_scaling(au, a, u, n); return 0; }
+
+/* ---- domain ---- */
+int fdd_dom_stiffness_matrix_1(double *const GDu[3], const double *u, const double *D, const double *const G[6], int np, int N, int dim, void *s) { (void)s; orc_dom_stiffness_matrix_1(GDu, u, D, G, np, N, dim); return 0; }
+int fdd_dom_stiffness_matrix_2(double *Au, const double *const GDu[3], const double *D, int np, int N, int dim, void *s) { (void)s; orc_dom_stiffness_matrix_2(Au, GDu, D, np, N, dim); return 0; }
+
+static int fused(double *Au, const double *u, const double *D, const double *const G[6], const int *eo, int ne, int N)
+{
+    int n3 = (N + 1) * (N + 1) * (N + 1);
+    double *w[3];
+    for (int k = 0; k < 3; k++) w[k] = (double *)malloc(sizeof(double) * (size_t)n3);
+    for (int e = 0; e < ne; e++)
+    {
+        size_t o = eo ? (size_t)eo[e] : (size_t)e * n3;
+        const double *Ge[6];
+        for (int g = 0; g < 6; g++) Ge[g] = G[g] + o;
+        orc_dom_stiffness_matrix_1(w, u + o, D, Ge, n3, N, 3);
+        orc_dom_stiffness_matrix_2(Au + o, (const double *const *)w, D, n3, N, 3);
+    }
+    for (int k = 0; k < 3; k++) free(w[k]);
+    return 0;
+}
+int fdd_dom_stiffness_matrix(double *Au, const double *u, const double *D, const double *const G[6], int ne, int N, void *s) { (void)s; return fused(Au, u, D, G, NULL, ne, N); }
+int fdd_sub_stiffness_matrix(double *Au, const double *u, const double *D, const double *const G[6], const int *eo, int ne, int N, void *s) { (void)s; return fused(Au, u, D, G, eo, ne, N); }
+int fdd_dom_initialize_arrays(double *u, double *r, const double *f, int n, void *s) { (void)s; orc_dom_initialize_arrays(u, r, f, n); return 0; }
+
+size_t fdd_reduce_workspace_doubles(void) { return 2 * (size_t)FDD_REDUCE_MAX_BLOCKS; }
+
+/* reductions: the oracle's 128-wide tree + in-order block sum */
+#define NB(n) (((n) + ORC_BLOCK_SIZE - 1) / ORC_BLOCK_SIZE)
+int fdd_dom_residual_norm(double *out, double *ws, const double *r, const double *q, const double *m, int n, void *s)
+{
+    (void)s; (void)ws;
+    double *b = (double *)calloc((size_t)NB(n) + 1, sizeof(double));
+    orc_dom_residual_norm(b, r, q, m, n, NB(n)); out[0] = orc_block_sum(b, NB(n)); free(b); return 0;
+}
+int fdd_dom_projection_inner_products(double *out, double *ws, const double *z, const double *r, const double *p, const double *q, int n, void *s)
+{
+    (void)s; (void)ws;
+    double *b = (double *)calloc(2 * (size_t)NB(n) + 2, sizeof(double));
+    orc_dom_projection_inner_products(b, z, r, p, q, n, NB(n));
+    out[0] = orc_block_sum(b, NB(n)); out[1] = orc_block_sum(b + NB(n), NB(n)); free(b); return 0;
+}
+int fdd_dom_inner_product_flexible(double *out, double *ws, const double *r, const double *r1, const double *z, int n, void *s)
+{
+    (void)s; (void)ws;
+    double *b = (double *)calloc((size_t)NB(n) + 1, sizeof(double));
+    orc_dom_inner_product_flexible(b, r, r1, z, n, NB(n)); out[0] = orc_block_sum(b, NB(n)); free(b); return 0;
+}
+int fdd_dom_inner_product(double *out, double *ws, const double *u, const double *v, const double *m, int n, void *s)
+{
+    (void)s; (void)ws;
+    double *b = (double *)calloc((size_t)NB(n) + 1, sizeof(double));
+    orc_dom_inner_product(b, u, v, m, n, NB(n)); out[0] = orc_block_sum(b, NB(n)); free(b); return 0;
+}
+int fdd_dom_solution_and_residual_update(double *u, double *r1, const double *r, const double *p, const double *q, double a, int n, void *s) { (void)s; orc_dom_solution_and_residual_update(u, r1, r, p, q, a, n); return 0; }
+int fdd_dom_residual_and_search_update(double *p, double *r, const double *z, const double *r1, double b, int n, void *s) { (void)s; orc_dom_residual_and_search_update(p, r, z, r1, b, n); return 0; }
+int fdd_dom_solution_and_residual_update_dev(double *u, double *r1, const double *r, const double *p, const double *q, const double *num, const double *den, int n, void *s) { (void)s; orc_dom_solution_and_residual_update(u, r1, r, p, q, num[0] / den[0], n); return 0; }
+int fdd_dom_residual_and_search_update_dev(double *p, double *r, const double *z, const double *r1, const double *num, const double *den, int n, void *s) { (void)s; orc_dom_residual_and_search_update(p, r, z, r1, num[0] / den[0], n); return 0; }
+
+/* ---- subdomain ---- */
+int fdd_sub_stiffness_matrix_1(double *const GDu[3], const double *u, const double *const *Dp, const int *off, const int *vert, const int *lev, const int *pd, int nl, const double *const G[6], int np, int dim, void *s) { (void)s; (void)nl; orc_sub_stiffness_matrix_1(GDu, u, Dp, off, vert, lev, pd, G, np, dim); return 0; }
+int fdd_sub_stiffness_matrix_2(double *Au, const double *const GDu[3], const double *const *Dp, const int *off, const int *vert, const int *lev, const int *pd, int nl, int np, int dim, void *s) { (void)s; (void)nl; orc_sub_stiffness_matrix_2(Au, GDu, Dp, off, vert, lev, pd, np, dim); return 0; }
+int fdd_sub_inner_product(double *out, double *ws, const double *u, const double *v, int n, void *s)
+{
+    (void)s; (void)ws;
+    double *b = (double *)calloc((size_t)NB(n) + 1, sizeof(double));
+    orc_sub_inner_product(b, u, v, n, NB(n)); out[0] = orc_block_sum(b, NB(n)); free(b); return 0;
+}
+int fdd_sub_weighted_inner_product(double *out, double *ws, const double *u, const double *v, const double *w, int n, void *s)
+{
+    (void)s; (void)ws;
+    double *b = (double *)calloc((size_t)NB(n) + 1, sizeof(double));
+    orc_sub_weighted_inner_product(b, u, v, w, n, NB(n)); out[0] = orc_block_sum(b, NB(n)); free(b); return 0;
+}
+int fdd_sub_projection_inner_products(double *out, double *ws, const double *z, const double *r, const double *p, const double *q, const double *w, int n, void *s)
+{
+    (void)s; (void)ws;
+    double *b = (double *)calloc(2 * (size_t)NB(n) + 2, sizeof(double));
+    orc_sub_projection_inner_products(b, z, r, p, q, w, n, NB(n));
+    out[0] = orc_block_sum(b, NB(n)); out[1] = orc_block_sum(b + NB(n), NB(n)); free(b); return 0;
+}
+int fdd_sub_search_update_inner_product(double *out, double *ws, const double *r, const double *r1, const double *z, const double *w, int n, void *s)
+{
+    (void)s; (void)ws;
+    double *b = (double *)calloc((size_t)NB(n) + 1, sizeof(double));
+    orc_sub_search_update_inner_product(b, r, r1, z, w, n, NB(n)); out[0] = orc_block_sum(b, NB(n)); free(b); return 0;
+}
+int fdd_sub_initialize_arrays(double *u, double *r, const double *f, int n, void *s) { (void)s; orc_sub_initialize_arrays(u, r, f, n); return 0; }
+int fdd_sub_solution_and_residual_update(double *u, double *r1, const double *r, const double *p, const double *q, double a, int n, void *s) { (void)s; orc_sub_solution_and_residual_update(u, r1, r, p, q, a, n); return 0; }
+int fdd_sub_residual_and_search_update(double *p, double *r, const double *z, const double *r1, double b, int n, void *s) { (void)s; orc_sub_residual_and_search_update(p, r, z, r1, b, n); return 0; }
+int fdd_sub_copy_f64_f64(double *u, const double *v, int n, void *s) { (void)s; orc_sub_copy_f64_f64(u, v, n); return 0; }
+int fdd_sub_copy_f32_f64(float *u, const double *v, int n, void *s) { (void)s; orc_sub_copy_f32_f64(u, v, n); return 0; }
+int fdd_sub_copy_f64_f32(double *u, const float *v, int n, void *s) { (void)s; orc_sub_copy_f64_f32(u, v, n); return 0; }
+int fdd_sub_restriction_1(double *Ju, const double *J, const double *u, int np, int nf, int nc, int dim, void *s) { (void)s; orc_sub_restriction_1(Ju, J, u, np, nf, nc, dim); return 0; }
+int fdd_sub_restriction_2(double *Ju, const double *J, const double *u, int np, int nf, int nc, int dim, void *s) { (void)s; orc_sub_restriction_2(Ju, J, u, np, nf, nc, dim); return 0; }
+int fdd_sub_restriction_3(double *Ju, const double *J, const double *u, int np, int nf, int nc, void *s) { (void)s; orc_sub_restriction_3(Ju, J, u, np, nf, nc); return 0; }
+int fdd_sub_restriction(double *uc, const double *J, const double *uf, int ne, int nf, int nc, void *s)
+{
+    (void)s;
+    double *w1 = (double *)malloc(sizeof(double) * (size_t)ne * nf * nf * nc);
+    double *w2 = (double *)malloc(sizeof(double) * (size_t)ne * nf * nc * nc);
+    orc_sub_restriction_1(w1, J, uf, ne * nf * nf * nc, nf, nc, 3);
+    orc_sub_restriction_2(w2, J, w1, ne * nf * nc * nc, nf, nc, 3);
+    orc_sub_restriction_3(uc, J, w2, ne * nc * nc * nc, nf, nc);
+    free(w1); free(w2);
+    return 0;
+}
+
+/* ---- AMG ---- */
+int fdd_amg_vector_set_to_value(double *d, double v, int n, void *s) { (void)s; orc_amg_vector_set_to_value(d, v, n); return 0; }
+int fdd_amg_main_scaled_residual(double *Sr, double *w, const double *f, const double *S, double a, int n, void *s) { (void)s; orc_amg_main_scaled_residual(Sr, w, f, S, a, n); return 0; }
+int fdd_amg_main_polynomial_evaluation(double *w, double *v, const double *r, const double *D, double a, int n, void *s) { (void)s; orc_amg_main_polynomial_evaluation(w, v, r, D, a, n); return 0; }
+int fdd_amg_main_update_field(double *u, const double *w, const double *D, int n, void *s) { (void)s; orc_amg_main_update_field(u, w, D, n); return 0; }
+int fdd_amg_vector_multiplication(double *uv, const double *u, const double *v, int n, void *s) { (void)s; orc_amg_vector_multiplication(uv, u, v, n); return 0; }
+int fdd_amg_matvec(double *y, const int *p, const int *c, const double *v, const double *x, double a, double b, int n, void *s) { (void)s; orc_amg_matvec(y, p, c, v, x, a, b, n); return 0; }
+int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int n, void *s) { return fdd_sub_inner_product(out, ws, x, y, n, s); }
+
+/* ---- interface exchange ---- */
+int fdd_interface_pack(double *slots, const int *slot_of, const double *prefix, int n, void *s) { (void)s; for (int i = 0; i < n; i++) slots[slot_of[i]] = prefix[i]; return 0; }
+int fdd_interface_unpack(double *prefix, const double *slots, const int *slot_of, int n, void *s) { (void)s; for (int i = 0; i < n; i++) prefix[i] = slots[slot_of[i]]; return 0; }

@@ -1,0 +1,149 @@
+"""Multi-rank path on CPU: world_size-2 (and 4) `gloo` process groups drive the
+product's C++ host layer -- rank partition, boundary-first numbering,
+interface-slot exchange (pack -> all-reduce -> unpack), scalar all-reduces and
+the torch.distributed communication callbacks -- exactly as bench.py does on
+GPUs with backend "nccl" (= RCCL).
+
+No GPU here, so the kernel C-ABI is served by tests/cpu_shim (the CPU oracle
+behind include/fdd_hip.h: test infrastructure, never loaded by the product);
+the host-layer sources are the product's own.  The reference result is the
+oracle's R-rank world simulated in one process.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import support as S
+
+SHIM_DIR = os.path.join(S.HERE, "cpu_shim")
+HOST_CPU_SO = os.path.join(SHIM_DIR, "_build", "libfdd_host_cpu.so")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, E, N, red, with_sub):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
+
+    # test-only: serve include/fdd_host.h from the CPU build of the host layer
+    lib._host = lib._Lib(HOST_CPU_SO, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H.init(0, use_torch_stream=False)
+        H.set_print(False)
+        H.comm_torch_callbacks(on_gpu=False)
+
+        Pg = S.rank_grid(world)
+        p = H.Problem.box(E, Pg, N, red, with_sub)
+        for lvl in range(p.info["num_levels"]):
+            p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
+
+        # oracle: all ranks simulated in this process, from the numpy mesh statement
+        meshes = [S.BoxMesh(E, N, Pg, r) for r in range(world)]
+        W = S.OracleWorld(meshes, N)
+        mine = meshes[rank]
+
+        assert np.array_equal(p.mesh_array("glo_num"), mine.glo_num)
+        assert np.array_equal(p.mesh_array("node_degree"), mine.node_degree)
+        assert p.info["num_bdary_nodes"] == W.num_bdary(rank)
+        assert p.info["num_local_nodes"] == W.num_nodes(rank)
+        assert p.info["num_interface_slots"] == W.L.orc_world_num_interface_slots(W.w)
+        assert p.info["num_total_nodes"] == mine.global_nodes
+        assert np.abs(p.assembled_weight() - W.assembled_weight(rank)).max() == 0.0
+
+        def field(mm):
+            return np.sin(3 * mm.x + 1) * np.cos(2 * mm.y) + mm.z * mm.x
+
+        us = [field(mm) for mm in meshes]
+        for mask, weight in ((True, False), (True, True)):
+            got = p.dssum(us[rank], mask, weight)
+            ref = W.dssum(us, mask, weight)[rank]
+            assert np.abs(got - ref).max() <= 1e-14 * np.abs(ref).max()
+        ref = W.residual_norm(us)
+        assert abs(p.residual_norm(us[rank]) - ref) <= 1e-13 * ref
+
+        o_star = W.dssum(us, True, True)
+        o_f = W.stiffness(o_star)
+        u_star, f = p.make_rhs_from(us[rank])
+        assert np.abs(f - o_f[rank]).max() <= 1e-13 * np.abs(o_f[rank]).max()
+
+        sds = [S.OracleSubdomain(E, N, red, Pg, r) for r in range(world)] if with_sub else None
+
+        def pre(z, r):
+            for k in range(world):
+                out, _, _ = sds[k].solve(r[k], "gmres")
+                z[k][:] = out
+
+        for method in ("fcg", "gmres"):
+            u, its, hist = p.solve(f, method)
+            ou, oits, ohist = W.solve(o_f, method, precond=pre if with_sub else None)
+            assert its == oits, (method, its, oits)
+            assert np.abs(hist - ohist).max() <= 1e-8 * ohist[0]
+            assert np.abs(u - ou[rank]).max() <= 1e-8 * np.abs(ou[rank]).max()
+        p.close()
+        W.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def cpu_host_lib():
+    subprocess.check_call(["make", "-C", S.ORACLE_DIR, "-s"])
+    subprocess.check_call(["make", "-C", SHIM_DIR, "-s"])
+    assert os.path.exists(HOST_CPU_SO)
+    return HOST_CPU_SO
+
+
+@pytest.mark.parametrize("world,with_sub", [(2, False), (2, True), (4, False)])
+def test_host_layer_multirank_gloo(cpu_host_lib, world, with_sub):
+    import torch.multiprocessing as mp
+
+    E, N, red = (4, 4, 4), 3, 2
+    mp.spawn(_worker, args=(world, _free_port(), E, N, red, with_sub), nprocs=world, join=True)
+
+
+def test_single_rank_cpu_shim_equals_oracle(cpu_host_lib):
+    """The shim-backed host layer reproduces the oracle's C1 golden histories
+    bit for bit (same kernels, same reduction tree): a check of the host
+    layer's solver logic that needs no GPU."""
+    code = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import support as S
+from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H, lib
+lib._host = lib._Lib(%r, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
+H.init(0, use_torch_stream=False); H.comm_single(); H.set_print(False)
+gold = json.load(open(os.path.join(S.GOLDEN_DIR, "oracle_c1.json")))
+p = H.Problem.box((4, 4, 4), (1, 1, 1), 3, 2, True)
+for lvl in range(p.info["num_levels"]):
+    p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
+m = S.ArrayMesh.from_problem(p)
+W = S.OracleWorld([m], 3)
+us = W.dssum([S.seeded_uniform(p.n, 1234)], True, True)
+f = W.stiffness(us)[0]
+for key, method, inner in (("fcg+gmres", "fcg", 1), ("gmres+fcg", "gmres", 0)):
+    p.set_options(preconditioner_type=inner)
+    u, its, hist = p.solve(f, method)
+    g = gold["solves"][key]
+    assert its == g["iterations"], (key, its, g["iterations"])
+    assert np.abs(hist - np.array(g["history"])).max() <= 1e-9 * g["history"][0], key
+print("ok")
+""" % (S.ROOT, S.HERE, HOST_CPU_SO)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

@@ -1,0 +1,302 @@
+"""CPU tests of the oracle itself (no GPU): the reference-pinned GLL tables,
+the C restatement against independent dense numpy statements of the same
+operators, the solvers against the manufactured solution, multi-rank
+equivalence, and the committed golden fixture."""
+import ctypes
+import hashlib
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import support as S
+
+P = S._p
+vp = ctypes.c_void_p
+
+
+# ------------------------------------------------------------------ GLL tables
+def test_golden_gll_tables_match_reference_speclib():
+    """tests/golden/gll_tables.json is what the reference's own
+    special_functions.f returns (compiled by oracle/Makefile `ref`).  Runs where
+    oracle/_ref exists (build container; the .so also travels to the GPU box)."""
+    if not os.path.exists(S.SPECLIB_REF_SO):
+        pytest.skip("oracle/_ref/libspeclib_ref.so not built (needs /root/reference)")
+    L = ctypes.CDLL(S.SPECLIB_REF_SO)
+    L.hgll_.restype = ctypes.c_double
+    for N in range(1, 16):
+        n = N + 1
+        z, w, Dh = S.gll(N)
+        zz, ww = np.zeros(n), np.zeros(n)
+        cn = ctypes.c_int(n)
+        L.zwgll_(P(zz), P(ww), ctypes.byref(cn))
+        Dt, D = np.zeros(n * n), np.zeros(n * n)
+        L.dgll_(P(Dt), P(D), P(zz), ctypes.byref(cn), ctypes.byref(cn))
+        assert np.array_equal(z, zz) and np.array_equal(w, ww) and np.array_equal(Dh, D)
+    zc = np.ascontiguousarray(S.gll(3)[0])
+    zf = S.gll(7)[0]
+    J = S.J_cf(3, 7).reshape(8, 4)
+    for i in range(8):
+        for j in range(1, 5):
+            x = ctypes.c_double(zf[i])
+            v = L.hgll_(ctypes.byref(ctypes.c_int(j)), ctypes.byref(x), P(zc), ctypes.byref(ctypes.c_int(4)))
+            assert v == J[i, j - 1]
+
+
+@pytest.mark.parametrize("N", range(1, 16))
+def test_gll_table_properties(N):
+    """Reference-independent sanity of the tables: quadrature and
+    differentiation exactness on polynomials."""
+    z, w, D = S.gll(N)
+    n = N + 1
+    D = D.reshape(n, n)
+    assert abs(w.sum() - 2.0) < 1e-13
+    assert np.allclose(z, -z[::-1], atol=1e-14) and z[0] == -1.0 and z[-1] == 1.0
+    # GLL quadrature integrates x^(2N-1) exactly
+    for k in range(0, 2 * N):
+        exact = 0.0 if k % 2 else 2.0 / (k + 1)
+        assert abs((w * z**k).sum() - exact) < 1e-12
+    # D differentiates polynomials of degree <= N exactly: D[i, j] = l_j'(z_i)
+    for k in range(0, N + 1):
+        d = D @ z**k
+        ref = k * z ** max(k - 1, 0) if k else np.zeros(n)
+        assert np.abs(d - ref).max() < 1e-10 * max(1, N**2)
+
+
+@pytest.mark.parametrize("Nc,Nf", [(1, 7), (3, 7), (5, 7), (1, 3), (9, 15), (1, 2)])
+def test_interpolator_properties(Nc, Nf):
+    J = S.J_cf(Nc, Nf).reshape(Nf + 1, Nc + 1)
+    zc, zf = S.gll(Nc)[0], S.gll(Nf)[0]
+    assert np.abs(J.sum(1) - 1.0).max() < 1e-12  # partition of unity
+    for k in range(Nc + 1):  # exact on degree <= Nc
+        assert np.abs(J @ zc**k - zf**k).max() < 1e-11
+
+
+# ------------------------------------------------- kernels vs dense numpy
+def dense_stiffness(u, G, D, n):
+    """Au = D^T G D u per element with einsum, independent of the oracle loops."""
+    E = len(u) // n**3
+    U = u.reshape(E, n, n, n)  # [e, k, j, i]
+    g = [a.reshape(E, n, n, n) for a in G]
+    ur = np.einsum("ip,ekjp->ekji", D, U)
+    us = np.einsum("jp,ekpi->ekji", D, U)
+    ut = np.einsum("kp,epji->ekji", D, U)
+    wr = g[0] * ur + g[3] * us + g[4] * ut
+    ws = g[3] * ur + g[1] * us + g[5] * ut
+    wt = g[4] * ur + g[5] * us + g[2] * ut
+    out = np.einsum("pi,ekjp->ekji", D, wr) + np.einsum("pj,ekpi->ekji", D, ws) + np.einsum("pk,epji->ekji", D, wt)
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 11])
+def test_oracle_stiffness_against_dense(N):
+    L = S.oracle()
+    n = N + 1
+    E = 5
+    rng = np.random.default_rng(N)
+    npts = E * n**3
+    u = rng.uniform(-1, 1, npts)
+    G = [rng.uniform(0.1, 1, npts) if k < 3 else rng.uniform(-0.3, 0.3, npts) for k in range(6)]
+    D = np.ascontiguousarray(S.gll(N)[2])
+    GDu = [np.zeros(npts) for _ in range(3)]
+    Au = np.zeros(npts)
+    gd = (vp * 3)(*[a.ctypes.data for a in GDu])
+    gg = (vp * 6)(*[a.ctypes.data for a in G])
+    L.orc_dom_stiffness_matrix_1(gd, P(u), P(D), gg, npts, N, 3)
+    L.orc_dom_stiffness_matrix_2(P(Au), gd, P(D), npts, N, 3)
+    ref = dense_stiffness(u, G, D.reshape(n, n), n)
+    assert np.abs(Au - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_oracle_restriction_against_dense():
+    L = S.oracle()
+    Nf, Nc, E = 7, 3, 6
+    n_f, n_c = Nf + 1, Nc + 1
+    J = np.ascontiguousarray(S.J_cf(Nc, Nf))
+    u = np.random.default_rng(0).uniform(-1, 1, E * n_f**3)
+    w1 = np.zeros(E * n_f * n_f * n_c)
+    w2 = np.zeros(E * n_f * n_c * n_c)
+    uc = np.zeros(E * n_c**3)
+    L.orc_sub_restriction_1(P(w1), P(J), P(u), len(w1), n_f, n_c, 3)
+    L.orc_sub_restriction_2(P(w2), P(J), P(w1), len(w2), n_f, n_c, 3)
+    L.orc_sub_restriction_3(P(uc), P(J), P(w2), len(uc), n_f, n_c)
+    Jm = J.reshape(n_f, n_c)
+    ref = np.einsum("li,mj,nk,enml->ekji", Jm, Jm, Jm, u.reshape(E, n_f, n_f, n_f)).reshape(-1)
+    assert np.abs(uc - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_oracle_csr_and_assembly():
+    import scipy.sparse as sp
+
+    L = S.oracle()
+    rng = np.random.default_rng(3)
+    rows, cols, n = 40, 30, 500
+    r = rng.integers(0, rows, n).astype(np.int32)
+    c = rng.integers(0, cols, n).astype(np.int32)
+    v = rng.uniform(-1, 1, n)
+    v[::17] = 1e-13  # dropped by the 1e-12 tolerance (csr_matrix.tpp:61-64,79)
+    A = S.OrcCsr()
+    assert L.orc_csr_assemble(ctypes.byref(A), rows, cols, P(r), P(c), P(v), n) == 0
+    ptr, col, val = A.to_numpy()
+    keep = np.abs(v) > 1e-12
+    ref = sp.coo_matrix((v[keep], (r[keep], c[keep])), shape=(rows, cols)).tocsr()
+    ref.sum_duplicates()
+    ref.sort_indices()
+    assert np.array_equal(ptr, ref.indptr) and np.array_equal(col, ref.indices)
+    assert np.abs(val - ref.data).max() < 1e-15
+    x = rng.uniform(-1, 1, cols)
+    y = np.zeros(rows)
+    L.orc_csr_multiply(P(y), P(ptr), P(col), P(val), P(x), rows)
+    assert np.abs(y - ref @ x).max() < 1e-14
+    # out-of-range entry is an error (csr_matrix.tpp:72-76)
+    bad = np.array([rows], np.int32)
+    B = S.OrcCsr()
+    assert L.orc_csr_assemble(ctypes.byref(B), rows, cols, P(bad), P(np.zeros(1, np.int32)), P(np.ones(1)), 1) == -1
+    # transpose
+    At = S.OrcCsr()
+    L.orc_csr_transpose(ctypes.byref(A), ctypes.byref(At))
+    tp, tc, tv = At.to_numpy()
+    rt = ref.T.tocsr()
+    rt.sort_indices()
+    assert np.array_equal(tp, rt.indptr) and np.array_equal(tc, rt.indices)
+    L.orc_csr_free(ctypes.byref(A))
+    L.orc_csr_free(ctypes.byref(At))
+
+
+@pytest.mark.parametrize("n", [1, 127, 128, 129, 1000, 33333])
+def test_oracle_reductions_follow_the_reference_tree(n):
+    """128-wide pairwise tree then in-order block sum (domain.okl:125-131,
+    domain.tpp:926): within rounding of an exactly rounded sum, and equal to an
+    independent numpy statement of the same tree."""
+    L = S.oracle()
+    rng = np.random.default_rng(n)
+    a, b, w = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), rng.uniform(0, 1, n)
+    nb = (n + 127) // 128
+    block = np.zeros(nb)
+    L.orc_dom_inner_product(P(block), P(a), P(b), P(w), n, nb)
+    got = L.orc_block_sum(P(block), nb)
+    t = np.zeros(nb * 128)
+    t[:n] = a * b * w
+    t = t.reshape(nb, 128).copy()
+    alive = 64
+    while alive > 0:
+        t[:, :alive] += t[:, alive:2 * alive]
+        alive //= 2
+    ref = 0.0
+    for x in t[:, 0]:
+        ref += x
+    assert got == ref
+    assert abs(got - math.fsum(a * b * w)) <= 1e-13 * np.abs(a * b * w).sum()
+
+
+# ------------------------------------------------------------ solver level
+def test_domain_numbering_boundary_first_two_ranks():
+    """domain.tpp:236-281: nodes whose local multiplicity differs from the
+    global one are numbered first."""
+    ms = [S.BoxMesh((4, 2, 2), 3, (2, 1, 1), r) for r in range(2)]
+    W = S.OracleWorld(ms, 3)
+    try:
+        for r in range(2):
+            assert W.num_bdary(r) == 7 * 7
+            ptr, col, val = W.Q(r)
+            assert np.all(np.diff(ptr) == 1) and np.all(val == 1.0)
+            # the points on the shared plane x = 0.5 map to the prefix
+            on_plane = np.abs(ms[r].x - 0.5) < 1e-12
+            assert col[on_plane].max() < 49 and col[~on_plane].min() >= 49
+        assert W.L.orc_world_num_interface_slots(W.w) == 49
+        # assembled weight = 1 / global multiplicity
+        for r in range(2):
+            ptr, col, _ = W.Q(r)
+            assert np.array_equal(W.assembled_weight(r)[col], 1.0 / ms[r].node_degree)
+    finally:
+        W.close()
+
+
+def test_operator_is_symmetric_positive_on_assembled_space():
+    m = S.BoxMesh((2, 2, 2), 3)
+    W = S.OracleWorld([m], 3)
+    try:
+        rng = np.random.default_rng(1)
+        a = W.dssum([rng.uniform(-1, 1, m.num_local_points)], True, True)
+        b = W.dssum([rng.uniform(-1, 1, m.num_local_points)], True, True)
+        Aa, Ab = W.stiffness(a), W.stiffness(b)
+        assert abs(a[0] @ Ab[0] - b[0] @ Aa[0]) <= 1e-12 * abs(a[0] @ Ab[0])
+        assert a[0] @ Aa[0] > 0
+    finally:
+        W.close()
+
+
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_multi_rank_oracle_equals_single_rank(ranks):
+    E, N = (4, 4, 4), 3
+    Pg = S.rank_grid(ranks)
+    m1 = S.BoxMesh(E, N)
+    W1 = S.OracleWorld([m1], N)
+    ms = [S.BoxMesh(E, N, Pg, r) for r in range(ranks)]
+    WR = S.OracleWorld(ms, N)
+    try:
+        def rhs(W, meshes):
+            us = [np.sin(np.pi * mm.x) * np.sin(2 * np.pi * mm.y) * np.sin(np.pi * mm.z) + mm.x * mm.y for mm in meshes]
+            us = W.dssum(us, True, True)
+            return us, W.stiffness(us)
+
+        _, f1 = rhs(W1, [m1])
+        _, fR = rhs(WR, ms)
+        for method in ("fcg", "gmres"):
+            u1, i1, h1 = W1.solve(f1, method)
+            uR, iR, hR = WR.solve(fR, method)
+            assert i1 == iR
+            assert np.abs(h1 - hR).max() <= 1e-10 * h1[0]
+    finally:
+        W1.close()
+        WR.close()
+
+
+def test_golden_fixture_is_reproduced():
+    """The committed oracle outputs on config C1 (tests/golden/oracle_c1.json)."""
+    with open(os.path.join(S.GOLDEN_DIR, "oracle_c1.json")) as fh:
+        gold = json.load(fh)
+    E, N, red = tuple(gold["config"]["E"]), gold["config"]["N"], gold["config"]["reduction"]
+    m = S.BoxMesh(E, N)
+    W = S.OracleWorld([m], N)
+    sd = S.OracleSubdomain(E, N, red)
+    try:
+        u = S.seeded_uniform(m.num_local_points, gold["config"]["seed"])
+
+        def dig(a):
+            return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+        assert dig(W.dssum([u], True, True)[0]) == gold["operators"]["dssum_mask_weight"]["sha256"]
+        assert dig(W.stiffness([u])[0]) == gold["operators"]["stiffness"]["sha256"]
+        assert dig(sd.stiffness(u)) == gold["operators"]["sub_stiffness"]["sha256"]
+        assert dig(sd.tree(u)) == gold["operators"]["sub_tree"]["sha256"]
+        assert W.residual_norm([u]) == gold["operators"]["residual_norm"]
+
+        us = W.dssum([u], True, True)
+        f = W.stiffness(us)
+        assert dig(f[0]) == gold["rhs"]["f_sha256"]
+
+        def pre(z, r):
+            o, _, _ = sd.solve(r[0], "gmres")
+            z[0][:] = o
+
+        for key, kwargs in (("fcg+none", dict(method="fcg")), ("gmres+none", dict(method="gmres")), ("fcg+gmres", dict(method="fcg", precond=pre))):
+            uu, its, hist = W.solve(f, **kwargs)
+            g = gold["solves"][key]
+            assert its == g["iterations"]
+            assert np.array_equal(hist, np.array(g["history"]))
+            assert np.abs(uu[0] - us[0]).max() <= 5e-6  # manufactured solution recovered
+    finally:
+        sd.close()
+        W.close()
+
+
+def test_fdd_preconditioner_cuts_iterations():
+    with open(os.path.join(S.GOLDEN_DIR, "oracle_c1.json")) as fh:
+        gold = json.load(fh)["solves"]
+    assert gold["fcg+gmres"]["iterations"] < gold["fcg+none"]["iterations"] / 2
+    assert gold["gmres+gmres"]["iterations"] < gold["gmres+none"]["iterations"] / 2
+    h = gold["precond_gmres"]["history"]
+    assert all(h[i + 1] <= h[i] for i in range(len(h) - 1))  # GMRES residual estimate is monotone
