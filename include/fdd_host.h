@@ -41,6 +41,8 @@ typedef int (*fddh_allgather_fn)(void *ctx, const void *send, void *recv, long l
 typedef int (*fddh_barrier_fn)(void *ctx);
 int fddh_comm_callbacks(int rank, int size, void *ctx, fddh_allreduce_fn allreduce_sum_f64, fddh_allreduce_fn allreduce_max_f64, fddh_allgather_fn allgather_bytes, fddh_barrier_fn barrier);
 int fddh_comm_info(int *rank, int *size, char *name, size_t name_len);
+/* run every collective of the active communicator once on n doubles and verify the results */
+int fddh_comm_selftest(int n);
 
 /* A "problem" = what run_simulation builds (poisson.cpp:176-206): Domains for
  * the levels N, N-r, ..., 1 of this rank and, optionally, the Subdomain

@@ -160,6 +160,53 @@ int fddh_comm_callbacks(int rank, int size, void *ctx, fddh_allreduce_fn allredu
     return 0;
 }
 
+// Drives every collective of the active communicator once, bypassing the
+// "size == 1" shortcuts of the solver, and checks the results.
+int fddh_comm_selftest(int n)
+{
+    if (n < 1) return fail("n must be positive");
+    fdd::Comm &c = fdd::comm();
+    const int R = c.size, me = c.rank;
+    std::vector<double> h(n);
+    for (int i = 0; i < n; i++) h[i] = (double)(me + 1) * (i + 1);
+    fdd::memory d = fdd::dev().malloc<double>(n);
+    fdd::memory g = fdd::dev().malloc<double>((size_t)n * R);
+
+    d.copyFrom(h.data(), n * sizeof(double));
+    c.allreduce_sum(d.as<double>(), n);
+    std::vector<double> out(n);
+    d.copyTo(out.data(), n * sizeof(double));
+    const double tri = 0.5 * R * (R + 1);
+    for (int i = 0; i < n; i++)
+        if (out[i] != tri * (i + 1)) return fail("allreduce_sum: element %d is %g, expected %g", i, out[i], tri * (i + 1));
+
+    d.copyFrom(h.data(), n * sizeof(double));
+    c.allreduce_max(d.as<double>(), n);
+    d.copyTo(out.data(), n * sizeof(double));
+    for (int i = 0; i < n; i++)
+        if (out[i] != (double)R * (i + 1)) return fail("allreduce_max: element %d is %g", i, out[i]);
+
+    d.copyFrom(h.data(), n * sizeof(double));
+    c.allgather(d.ptr(), g.ptr(), n * sizeof(double));
+    std::vector<double> all((size_t)n * R);
+    g.copyTo(all.data(), all.size() * sizeof(double));
+    for (int p = 0; p < R; p++)
+        for (int i = 0; i < n; i++)
+            if (all[(size_t)p * n + i] != (double)(p + 1) * (i + 1)) return fail("allgather: rank %d element %d is %g", p, i, all[(size_t)p * n + i]);
+
+    std::vector<long long> mine(me + 2, 100 + me);
+    std::vector<int> counts;
+    std::vector<long long> cat = c.allgatherv_host(mine, counts);
+    size_t expect = 0;
+    for (int p = 0; p < R; p++) expect += p + 2;
+    if (cat.size() != expect) return fail("allgatherv_host: %zu entries, expected %zu", cat.size(), expect);
+
+    c.barrier();
+    d.free();
+    g.free();
+    return 0;
+}
+
 int fddh_comm_info(int *rank, int *size, char *name, size_t name_len)
 {
     if (rank) *rank = fdd::comm().rank;

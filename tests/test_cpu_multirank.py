@@ -47,6 +47,7 @@ def _worker(rank, world, port, E, N, red, with_sub):
         H.init(0, use_torch_stream=False)
         H.set_print(False)
         H.comm_torch_callbacks(on_gpu=False)
+        lib.host().call("fddh_comm_selftest", 1000)  # all-reduce sum/max, all-gather, all-gatherv, barrier
 
         Pg = S.rank_grid(world)
         p = H.Problem.box(E, Pg, N, red, with_sub)
