@@ -178,6 +178,37 @@ int fdd_amg_matvec(double *y, const int *ptr, const int *col, const double *val,
 int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int size, void *stream);
 
 /* ------------------------------------------------------------------ */
+/* multi-vector forms of the Gram-Schmidt sweep of the Krylov solvers   */
+/* (same per-element arithmetic as the launch-per-vector reference       */
+/* sequence; vectors are read once)                                      */
+/* ------------------------------------------------------------------ */
+#define FDD_MULTI_MAX 8
+/* out[i] = sum a*b[i]*w, i < m <= 8: the (j+1) weighted_inner_product launches of one
+ * Arnoldi step (subdomain.tpp:4389-4394).  b is a HOST array of m device pointers. */
+int fdd_multi_weighted_inner_product(double *out, double *ws, const double *a, const double *const *b, int m, const double *w, int n, void *stream);
+/* q = 1.0*q + coeffs[0]*v[0]; q = 1.0*q + coeffs[1]*v[1]; ... (m <= 8) in one pass: the successive
+ * vector_vector_addition launches of domain.tpp:817-822,902-907 / subdomain.tpp:4396-4401,4473-4478.
+ * coeffs is a HOST array, v a HOST array of device pointers (none may alias q). */
+int fdd_multi_axpy(double *q, const double *coeffs, const double *const *v, int m, int n, void *stream);
+/* out[0] = sum_nodes s*s*w with s = (Qt u)[node]*w[node]: Subdomain::residual_norm
+ * (subdomain.tpp:4491-4515: multiply_weight + weighted_inner_product) without the dof vector */
+int fdd_gather_weighted_norm2(double *out, double *ws, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, int num_nodes, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* fused direct-stiffness summation (gather-scatter)                    */
+/* ------------------------------------------------------------------ */
+/* direct_stiffness_summation (domain.tpp:582-600, subdomain.tpp:3969-3985) is
+ *   t = (Qt u) .* node_weight ; [gs_add on the boundary prefix] ; out = (Q t) .* point_mask
+ * with boolean Qt (all values 1.0) and Q = Qt^T.  One lane per assembled node
+ * gathers its points and scatters the sum back: ~36 B/point instead of two
+ * SpMVs (66-74 B/point), same arithmetic, bit-identical.  node_weight /
+ * point_mask / t may be NULL.  QQtu may alias u.  Nodes [node_start, node_end). */
+int fdd_dssum_fused(double *QQtu, double *t, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, const double *point_mask, int node_start, int node_end, void *stream);
+int fdd_dssum_gather(double *t, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, int node_start, int node_end, void *stream);      /* t = (Qt u) .* w on a node range */
+int fdd_dssum_scatter(double *QQtu, const double *t, const int *Qt_ptr, const int *Qt_col, const double *point_mask, int node_start, int node_end, void *stream);  /* out = (Q t) .* mask on a node range */
+int fdd_fill_indexed(double *out, const int *idx, double value, int n, void *stream); /* out[idx[i]] = value (points without a dof) */
+
+/* ------------------------------------------------------------------ */
 /* interface exchange helpers: gslib gs(gs_add) on the boundary-node    */
 /* prefix (domain.tpp:590-594) becomes pack -> all-reduce -> unpack on a */
 /* dense interface-slot vector                                           */

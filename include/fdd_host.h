@@ -92,6 +92,13 @@ int fddh_problem_get_D_hat(const fddh_problem *p, int level, double *D_hat, int 
  * values (and NaN tolerance) leave a field unchanged. */
 int fddh_problem_set_options(fddh_problem *p, int max_iterations, double tolerance, int num_vectors, int use_preconditioner, int preconditioner_type, int sub_num_vectors, int sub_max_iterations, int sub_build_tree);
 
+/* Implementation switches (results are identical either way; the reference-shaped
+ * launch sequences stay available for comparison):
+ *   "fused_dssum"              1: one gather-scatter kernel per dssum (default), 0: the Qt / Q SpMV pair
+ *   "restructured_inner_solve" 1: inner GMRES with cached assembled vectors, multi-dot / multi-axpy (default),
+ *                              0: the reference's launch-by-launch sequence (subdomain.tpp:4309-4489) */
+int fddh_problem_set_flag(fddh_problem *p, const char *name, int value);
+
 /* Domain operations on host vectors of num_local_points */
 int fddh_problem_dssum(fddh_problem *p, double *out, const double *in, int apply_mask, int apply_weight);          /* Domain::direct_stiffness_summation */
 int fddh_problem_stiffness(fddh_problem *p, double *out, const double *in, int apply_dssum);                       /* Domain::stiffness_matrix */

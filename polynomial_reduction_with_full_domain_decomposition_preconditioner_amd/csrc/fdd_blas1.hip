@@ -214,6 +214,53 @@ struct CopyF64F32Op // subdomain.okl:276-282, DType = float
     __device__ void one(long long i) const { u[i] = (double)v[i]; }
 };
 
+// q <- (...((1.0*q + c_0 v_0) + c_1 v_1)...) + c_{M-1} v_{M-1}: the M successive
+// vector_vector_addition(q, 1.0, q, c_i, v_i) launches of a Gram-Schmidt
+// sweep (domain.tpp:817-822, subdomain.tpp:4396-4401) or of the solution
+// update (domain.tpp:902-907) in one pass: q is read and written once, each
+// element goes through the same operations in the same order.
+template <int M>
+struct MultiAxpyOp
+{
+    double *q;
+    const double *v[M];
+    double c[M];
+    __device__ void vec2(long long i) const
+    {
+        double2 x = ld2(q, i);
+#pragma unroll
+        for (int k = 0; k < M; k++)
+        {
+            const double2 b = ld2(v[k], i);
+            x.x = 1.0 * x.x + c[k] * b.x;
+            x.y = 1.0 * x.y + c[k] * b.y;
+        }
+        st2(q, i, x);
+    }
+    __device__ void one(long long i) const
+    {
+        double x = q[i];
+#pragma unroll
+        for (int k = 0; k < M; k++) x = 1.0 * x + c[k] * v[k][i];
+        q[i] = x;
+    }
+};
+
+template <int M>
+int launch_multi_axpy(double *q, const double *coeffs, const double *const *v, int n, void *stream)
+{
+    MultiAxpyOp<M> op;
+    op.q = q;
+    bool al = fdd_aligned16(q);
+    for (int k = 0; k < M; k++)
+    {
+        op.v[k] = v[k];
+        op.c[k] = coeffs[k];
+        al = al && fdd_aligned16(v[k]);
+    }
+    return launch_ew(op, n, al, stream);
+}
+
 // ------------------------------------------------------------ AMG/kernels.cu
 struct ScaledResidualOp // AMG/kernels.cu:25-41
 {
@@ -417,6 +464,25 @@ int fdd_sub_copy_f64_f32(double *u, const float *v, int num_points, void *stream
     FDD_REQUIRE(u != nullptr && v != nullptr);
     bool al = fdd_aligned16(u) && ((reinterpret_cast<uintptr_t>(v) & 7u) == 0);
     return launch_ew(CopyF64F32Op{u, v}, num_points, al, stream);
+}
+
+int fdd_multi_axpy(double *q, const double *coeffs, const double *const *v, int m, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0 && m >= 1 && m <= FDD_MULTI_MAX);
+    if (n == 0) return 0;
+    FDD_REQUIRE(q != nullptr && coeffs != nullptr && v != nullptr);
+    for (int k = 0; k < m; k++) FDD_REQUIRE(v[k] != nullptr && v[k] != q);
+    switch (m)
+    {
+    case 1: return launch_multi_axpy<1>(q, coeffs, v, n, stream);
+    case 2: return launch_multi_axpy<2>(q, coeffs, v, n, stream);
+    case 3: return launch_multi_axpy<3>(q, coeffs, v, n, stream);
+    case 4: return launch_multi_axpy<4>(q, coeffs, v, n, stream);
+    case 5: return launch_multi_axpy<5>(q, coeffs, v, n, stream);
+    case 6: return launch_multi_axpy<6>(q, coeffs, v, n, stream);
+    case 7: return launch_multi_axpy<7>(q, coeffs, v, n, stream);
+    default: return launch_multi_axpy<8>(q, coeffs, v, n, stream);
+    }
 }
 
 int fdd_amg_vector_set_to_value(double *data, double value, int size, void *stream)

@@ -52,4 +52,56 @@ static inline int fdd_stream_grid(long long work_items, int block, int max_block
 
 static inline bool fdd_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// XCD-aware workgroup order for indexed (gather/scatter) kernels.  Workgroups
+// are dealt round-robin over the 8 XCDs (b and b+8 share one, each XCD has its
+// own 4 MiB L2): remapping so that every XCD walks one contiguous eighth of
+// the index range keeps the lines shared by neighbouring elements (the
+// partner points of an interface node) in ONE L2, so scattered 8-byte stores
+// merge there into full lines and partner loads hit instead of being fetched
+// by two XCDs.  Bijective for any grid size; speed only, never correctness.
+// Row sum of a CSR row by ONE lane with the loads of up to kRowChunk entries
+// in flight at once.  A plain `for (j = j0; j < j1; j++) s += val[j]*u[col[j]]`
+// is a chain of dependent loads (col -> u) per entry, and a wavefront runs as
+// many serial round trips as its longest row: with 1-8 entries per row (the
+// boolean gather matrices) that, not bandwidth, sets the time.  Here every
+// lane first issues all its col (and val) loads of a chunk, then all its u
+// gathers, then adds the products in column order -- the reference's
+// summation order, so the result is unchanged.  Lanes past the end of their
+// row issue nothing.
+#define FDD_ROW_CHUNK 8
+template <bool UNIT>
+__device__ __forceinline__ double fdd_row_sum(const int *__restrict__ A_col, const double *__restrict__ A_val, const double *u, int j0, int j1)
+{
+    double s = 0.0;
+    for (int jb = j0; jb < j1; jb += FDD_ROW_CHUNK)
+    {
+        int c[FDD_ROW_CHUNK];
+        double a[FDD_ROW_CHUNK];
+        double x[FDD_ROW_CHUNK];
+#pragma unroll
+        for (int k = 0; k < FDD_ROW_CHUNK; k++)
+        {
+            const bool on = jb + k < j1;
+            c[k] = on ? A_col[jb + k] : 0;
+            a[k] = (UNIT || !on) ? 1.0 : A_val[jb + k];
+        }
+#pragma unroll
+        for (int k = 0; k < FDD_ROW_CHUNK; k++) x[k] = (jb + k < j1) ? u[c[k]] : 0.0;
+#pragma unroll
+        for (int k = 0; k < FDD_ROW_CHUNK; k++)
+            if (jb + k < j1) s += a[k] * x[k];
+    }
+    return s;
+}
+
+#define FDD_NUM_XCD 8
+__device__ __forceinline__ int fdd_xcd_chunked_block(int bid, int nblocks)
+{
+    const int per = nblocks / FDD_NUM_XCD;
+    const int rem = nblocks % FDD_NUM_XCD;
+    const int xcd = bid % FDD_NUM_XCD;
+    const int idx = bid / FDD_NUM_XCD;
+    return xcd * per + (xcd < rem ? xcd : rem) + idx;
+}
+
 #endif

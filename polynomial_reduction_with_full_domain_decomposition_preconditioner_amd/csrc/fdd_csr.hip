@@ -48,13 +48,14 @@ struct EpiAxpby // AMG/csr_matrix.cpp:112-134
 template <typename Epi>
 __global__ __launch_bounds__(kBlock) void csr_row_kernel(double *__restrict__ Au, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const double *__restrict__ A_val, const double *__restrict__ u, Epi epi, int row_start, int row_end)
 {
-    const int stride = gridDim.x * kBlock;
-    for (int i = row_start + blockIdx.x * kBlock + threadIdx.x; i < row_end; i += stride)
+    // one row per lane, workgroups in XCD-chunked order: the x gathers of the
+    // boolean gather/scatter matrices then stay inside one L2 (fdd_common.h)
+    const int i = row_start + fdd_xcd_chunked_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    if (i < row_end)
     {
         const int j0 = A_ptr[i];
         const int j1 = A_ptr[i + 1];
-        double Au_i = 0.0;
-        for (int j = j0; j < j1; j++) Au_i += A_val[j] * u[A_col[j]];
+        const double Au_i = fdd_row_sum<false>(A_col, A_val, u, j0, j1); // column order, loads of the row in flight together
         Au[i] = epi.apply(Au_i, i, Au);
     }
 }
@@ -120,7 +121,7 @@ template <typename Epi>
 int launch_rows(double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const Epi &epi, int row_start, int row_end, void *stream)
 {
     if (row_end <= row_start) return 0;
-    int grid = fdd_stream_grid((long long)row_end - row_start, kBlock, 8 * FDD_REDUCE_MAX_BLOCKS);
+    int grid = (int)(((long long)row_end - row_start + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(csr_row_kernel<Epi>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, A_ptr, A_col, A_val, u, epi, row_start, row_end);
     FDD_LAUNCH_CHECK();
     return 0;

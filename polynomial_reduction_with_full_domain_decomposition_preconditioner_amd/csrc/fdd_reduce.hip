@@ -239,11 +239,72 @@ struct FlexWOp // subdomain.okl:229-258
 
 inline bool al2(const void *a, const void *b) { return fdd_aligned16(a) && fdd_aligned16(b); }
 
+// out[i] = sum a * b_i * w for i < M: `a` and `w` are read once for all M dots
+// (the reference launches weighted_inner_product once per pair, subdomain.tpp:4389-4394)
+template <int M>
+struct MultiDotWOp
+{
+    static constexpr int NV = M;
+    const double *a, *w;
+    const double *b[M];
+    __device__ void vec2(long long i, Acc<M> &acc) const
+    {
+        const double2 aa = ld2(a, i), ww = ld2(w, i);
+#pragma unroll
+        for (int k = 0; k < M; k++)
+        {
+            const double2 bb = ld2(b[k], i);
+            acc.v[k] += aa.x * bb.x * ww.x;
+            acc.v[k] += aa.y * bb.y * ww.y;
+        }
+    }
+    __device__ void one(long long i, Acc<M> &acc) const
+    {
+#pragma unroll
+        for (int k = 0; k < M; k++) acc.v[k] += a[i] * b[k][i] * w[i];
+    }
+};
+
+template <int M>
+int launch_multi_dot(double *out, double *ws, const double *a, const double *const *b, const double *w, int n, void *stream)
+{
+    MultiDotWOp<M> op;
+    op.a = a;
+    op.w = w;
+    bool al = al2(a, w);
+    for (int k = 0; k < M; k++)
+    {
+        op.b[k] = b[k];
+        al = al && fdd_aligned16(b[k]);
+    }
+    return launch_reduce(op, out, ws, n, al, stream);
+}
+
+// ||Qt_w u||^2 in one pass: per assembled node s = (sum_j 1.0*u[col_j]) * w,
+// accumulate s*s*w -- the gather of multiply_weight (csr_matrix.okl:35-48) and
+// the weighted_inner_product (subdomain.okl:134-163) of Subdomain::residual_norm
+// (subdomain.tpp:4491-4515) without the intermediate dof vector.
+__global__ __launch_bounds__(kBlock) void gather_norm2_kernel(double *ws, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const double *__restrict__ u, const double *__restrict__ w, int n)
+{
+    Acc<1> a;
+    a.v[0] = 0.0;
+    const int stride = gridDim.x * kBlock;
+    for (int node = blockIdx.x * kBlock + threadIdx.x; node < n; node += stride)
+    {
+        const int j0 = Qt_ptr[node], j1 = Qt_ptr[node + 1];
+        double s = fdd_row_sum<true>(Qt_col, nullptr, u, j0, j1);
+        const double wn = w[node];
+        s = s * wn;
+        a.v[0] += s * s * wn;
+    }
+    block_reduce_store<1>(a, ws, FDD_REDUCE_MAX_BLOCKS);
+}
+
 } // namespace
 
 extern "C" {
 
-size_t fdd_reduce_workspace_doubles(void) { return 2 * (size_t)FDD_REDUCE_MAX_BLOCKS; }
+size_t fdd_reduce_workspace_doubles(void) { return FDD_MULTI_MAX * (size_t)FDD_REDUCE_MAX_BLOCKS; }
 
 int fdd_dom_residual_norm(double *out, double *ws, const double *r_k, const double *QQt_r_k, const double *dirichlet_mask, int num_points, void *stream)
 {
@@ -306,6 +367,38 @@ int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int s
     FDD_REQUIRE(out != nullptr && ws != nullptr && size >= 0);
     FDD_REQUIRE(size == 0 || (x != nullptr && y != nullptr));
     return launch_reduce(Dot2Op{x, y}, out, ws, size, al2(x, y), stream);
+}
+
+int fdd_multi_weighted_inner_product(double *out, double *ws, const double *a, const double *const *b, int m, const double *w, int n, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && ws != nullptr && n >= 0 && m >= 1 && m <= FDD_MULTI_MAX && b != nullptr);
+    FDD_REQUIRE(n == 0 || (a != nullptr && w != nullptr));
+    for (int k = 0; k < m; k++) FDD_REQUIRE(n == 0 || b[k] != nullptr);
+    switch (m)
+    {
+    case 1: return launch_multi_dot<1>(out, ws, a, b, w, n, stream);
+    case 2: return launch_multi_dot<2>(out, ws, a, b, w, n, stream);
+    case 3: return launch_multi_dot<3>(out, ws, a, b, w, n, stream);
+    case 4: return launch_multi_dot<4>(out, ws, a, b, w, n, stream);
+    case 5: return launch_multi_dot<5>(out, ws, a, b, w, n, stream);
+    case 6: return launch_multi_dot<6>(out, ws, a, b, w, n, stream);
+    case 7: return launch_multi_dot<7>(out, ws, a, b, w, n, stream);
+    default: return launch_multi_dot<8>(out, ws, a, b, w, n, stream);
+    }
+}
+
+int fdd_gather_weighted_norm2(double *out, double *ws, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, int num_nodes, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && ws != nullptr && num_nodes >= 0);
+    hipStream_t s = fdd_stream(stream);
+    if (num_nodes == 0) return (int)hipMemsetAsync(out, 0, sizeof(double), s);
+    FDD_REQUIRE(Qt_ptr != nullptr && Qt_col != nullptr && u != nullptr && node_weight != nullptr);
+    const int grid = fdd_stream_grid(num_nodes, kBlock);
+    hipLaunchKernelGGL(gather_norm2_kernel, dim3(grid), dim3(kBlock), 0, s, ws, Qt_ptr, Qt_col, u, node_weight, num_nodes);
+    FDD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_final_kernel<1>, dim3(1), dim3(kBlock), 0, s, out, ws, grid);
+    FDD_LAUNCH_CHECK();
+    return 0;
 }
 
 } // extern "C"

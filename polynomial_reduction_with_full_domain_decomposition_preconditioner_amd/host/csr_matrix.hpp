@@ -47,6 +47,8 @@ class CSR_Matrix
     int num_rows = 0;
     int num_cols = 0;
     int num_nnz = 0;
+    bool unit_values = false; // every stored value is exactly 1.0 (boolean gather/scatter matrices)
+    bool is_identity = false;
     fdd::memory ptr;
     fdd::memory col;
     fdd::memory val;
@@ -122,6 +124,17 @@ class CSR_Matrix
 
         for (int i = 1; i <= num_rows; i++) ptr_hst[i] += ptr_hst[i - 1];
         num_nnz = (int)col_hst.size();
+
+        unit_values = true;
+        for (const DType v : val_hst)
+            if (v != (DType)1.0)
+            {
+                unit_values = false;
+                break;
+            }
+        is_identity = unit_values and (num_rows == num_cols) and (num_nnz == num_rows);
+        for (int i = 0; is_identity and i < num_rows; i++)
+            if (col_hst[i] != i) is_identity = false;
 
         ptr = fdd::dev().malloc<int>(num_rows + 1);
         col = fdd::dev().malloc<int>(num_nnz);

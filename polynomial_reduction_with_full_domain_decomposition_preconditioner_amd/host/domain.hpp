@@ -206,6 +206,7 @@ class Domain
     int max_iterations = 500;
     int preconditioner_type = 1;
     bool use_preconditioner = true;
+    bool fused_dssum = true; // gather-scatter kernel instead of the reference's Qt / Q SpMV pair
     DType tolerance = 1.0e-07;
     std::vector<DType> residual_history; // what the reference prints per iteration
 
@@ -503,6 +504,29 @@ class Domain
     // domain.tpp:582-600
     void direct_stiffness_summation(fdd::memory &QQtu, fdd::memory &u, bool apply_dirichlet_mask = true, bool apply_assembled_weight = false)
     {
+        if (fused_dssum and Qt.unit_values)
+        {
+            // One gather-scatter pass over the assembled nodes instead of the
+            // Qt and Q SpMVs (same arithmetic, bit-identical; fdd_hip.h).  The
+            // boundary prefix is gathered first, exchanged, and scattered last.
+            const double *w = apply_assembled_weight ? assembled_weight.as<double>() : nullptr;
+            const double *m = apply_dirichlet_mask ? dirichlet_mask.as<double>() : nullptr;
+            const int nb = (fdd::comm().size > 1 and num_interface_slots > 0) ? num_bdary_nodes : 0;
+            if (nb > 0)
+            {
+                FDD_CALL(fdd_dssum_gather(work_dev[0].as<double>(), Qt.ptr.template as<int>(), Qt.col.template as<int>(), u.as<double>(), w, 0, nb, fdd::dev().stream));
+                gs_add_boundary(work_dev[0]);
+            }
+            {
+                // ptr 4 B/node, col 4 B/pt, u in 8 B/pt, out 8 B/pt, + mask 8 B/pt, + weight 8 B/node
+                const double bytes = 4.0 * (num_local_nodes - nb) + 20.0 * num_local_points + (m ? 8.0 * num_local_points : 0.0) + (w ? 8.0 * (num_local_nodes - nb) : 0.0);
+                fdd::ProfileScope prof("dssum_kernel<fused>", bytes);
+                FDD_CALL(fdd_dssum_fused(QQtu.as<double>(), nullptr, Qt.ptr.template as<int>(), Qt.col.template as<int>(), u.as<double>(), w, m, nb, num_local_nodes, fdd::dev().stream));
+            }
+            if (nb > 0) FDD_CALL(fdd_dssum_scatter(QQtu.as<double>(), work_dev[0].as<double>(), Qt.ptr.template as<int>(), Qt.col.template as<int>(), m, 0, nb, fdd::dev().stream));
+            return;
+        }
+
         if (apply_assembled_weight)
             Qt.multiply_weight(work_dev[0], u, assembled_weight);
         else

@@ -412,6 +412,24 @@ int fddh_problem_set_options(fddh_problem *p, int max_iterations, double toleran
     return 0;
 }
 
+int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
+{
+    if (!p || !name) return fail("null argument");
+    const std::string s(name);
+    if (s == "fused_dssum")
+    {
+        for (auto &kv : p->domains) kv.second.fused_dssum = value != 0;
+        if (p->subdomain) p->subdomain->fused_dssum = value != 0;
+    }
+    else if (s == "restructured_inner_solve")
+    {
+        if (p->subdomain) p->subdomain->restructured = value != 0;
+    }
+    else
+        return fail("unknown flag '%s'", name);
+    return 0;
+}
+
 int fddh_problem_dssum(fddh_problem *p, double *out, const double *in, int apply_mask, int apply_weight)
 {
     if (!p || !out || !in) return fail("null argument");

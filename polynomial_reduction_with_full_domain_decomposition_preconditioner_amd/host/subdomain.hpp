@@ -125,6 +125,12 @@ class Subdomain
     fdd::memory reduce_ws;
     fdd::memory scalars;
 
+    std::vector<fdd::memory> VA; // assembled (dof-space) copies Qt_w V[i] of the Krylov basis
+    fdd::memory qa;              // Qt_w q
+
+    fdd::memory points_without_dof; // Dirichlet points: empty rows of Q
+    int num_points_without_dof = 0;
+
     Math<DType> math;
     int dim = 3;
 
@@ -298,6 +304,8 @@ class Subdomain
     int level_cutoff = 5;
 
     bool build_tree = true;               // run the degree-tree restrictions as the reference always does
+    bool fused_dssum = true;              // gather-scatter kernel instead of the Qt / QQt_int / Q SpMV chain
+    bool restructured = true;             // inner GMRES with cached assembled basis, multi-dot / multi-axpy
     std::vector<DType> residual_history;  // inner history of the last application
 
     int num_values = 0;
@@ -401,6 +409,14 @@ class Subdomain
             if (tmp[p] > 0.0) subdomain_operator.Q.add_entry(p, (int)tmp[p] - 1, 1.0);
         subdomain_operator.Q.assemble();
         subdomain_operator.Q.transpose(subdomain_operator.Qt);
+        {
+            std::vector<int> no_dof;
+            for (int p = 0; p < P; p++)
+                if (!(tmp[p] > 0.0)) no_dof.push_back(p);
+            num_points_without_dof = (int)no_dof.size();
+            points_without_dof = fdd::dev().malloc<int>(std::max(num_points_without_dof, 1));
+            points_without_dof.copyFrom(no_dof.data(), no_dof.size() * sizeof(int));
+        }
         std::vector<double>().swap(tmp);
 
         subdomain_operator.num_dofs = max_dof;
@@ -502,6 +518,17 @@ class Subdomain
     // subdomain.tpp:3969-3985
     void direct_stiffness_summation(fdd::memory &QQtu, fdd::memory &u)
     {
+        if (fused_dssum and subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0)
+        {
+            // Q * I * Qt in one gather-scatter pass over the dofs; points without
+            // a dof (Dirichlet: empty rows of Q) get the 0.0 the SpMV writes.
+            const double bytes = 4.0 * subdomain_operator.num_extended_dofs + 20.0 * subdomain_operator.num_points;
+            fdd::ProfileScope prof("dssum_kernel<fused>", bytes);
+            FDD_CALL(fdd_dssum_fused(QQtu.as<double>(), nullptr, subdomain_operator.Qt.ptr.template as<int>(), subdomain_operator.Qt.col.template as<int>(), u.as<double>(), nullptr, nullptr, 0, subdomain_operator.num_extended_dofs, fdd::dev().stream));
+            FDD_CALL(fdd_fill_indexed(QQtu.as<double>(), points_without_dof.template as<int>(), 0.0, num_points_without_dof, fdd::dev().stream));
+            return;
+        }
+
         fdd::memory u_sub_l = u.slice(0, subdomain_operator.num_points);
         subdomain_operator.Qt.multiply(work_dev[0], u_sub_l);
         // u_sup -> work_dev[0] tail: empty
@@ -644,9 +671,191 @@ class Subdomain
         timer.stop("subdomain.vector_operations");
     }
 
+    // The same flexible GMRES(m) as below (subdomain.tpp:4309-4489), same
+    // arithmetic per vector element, restructured around HBM traffic:
+    //   - the assembled copy Qt_w V[i] of every basis vector is computed once
+    //     and kept (the reference recomputes it inside each of the
+    //     (j+1)(j+2)/2 assembled_inner_product calls, subdomain.tpp:4285-4293);
+    //   - Qt_w q is computed once per step; the (j+1) dots read it once
+    //     (fdd_multi_weighted_inner_product) and come back in one D2H copy;
+    //   - the (j+1) Gram-Schmidt updates are one pass over q (fdd_multi_axpy);
+    //   - ||q|| is a gather-and-reduce pass with no dof vector in between;
+    //   - dssum is the gather-scatter kernel; identity QQt_int is skipped.
+    // 4 node passes per step instead of 3 + 2(j+1) + 1 SpMVs.
+    bool can_restructure() const
+    {
+        return subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0 and not use_preconditioner and num_vectors + 1 <= FDD_MULTI_MAX;
+    }
+
+    void gather_weighted(fdd::memory &t, fdd::memory &v)
+    {
+        const int nd = subdomain_operator.num_extended_dofs;
+        fdd::ProfileScope prof("dssum_kernel<gather>", 4.0 * nd + 12.0 * subdomain_operator.Qt.num_nnz + 16.0 * nd);
+        FDD_CALL(fdd_dssum_gather(t.as<double>(), subdomain_operator.Qt.ptr.template as<int>(), subdomain_operator.Qt.col.template as<int>(), v.as<double>(), norm_weight.as<double>(), 0, nd, fdd::dev().stream));
+    }
+
+    void gather_norm(DType &r_norm, fdd::memory &r)
+    {
+        const int nd = subdomain_operator.num_extended_dofs;
+        {
+            fdd::ProfileScope prof("gather_norm2_kernel", 4.0 * nd + 12.0 * subdomain_operator.Qt.num_nnz + 8.0 * nd);
+            FDD_CALL(fdd_gather_weighted_norm2(scalars.as<double>(), reduce_ws.as<double>(), subdomain_operator.Qt.ptr.template as<int>(), subdomain_operator.Qt.col.template as<int>(), r.as<double>(), norm_weight.as<double>(), nd, fdd::dev().stream));
+        }
+        fetch_scalars(&r_norm, 1);
+        r_norm = std::sqrt(r_norm);
+    }
+
+    void gmres_restructured(fdd::memory &u_l, fdd::memory &f_l, bool print_history, bool use_relative)
+    {
+        const int nd = subdomain_operator.num_extended_dofs;
+        if ((int)Z.size() != num_vectors) allocate_krylov();
+        if ((int)VA.size() != num_vectors + 1)
+        {
+            for (auto &m : VA) m.free();
+            VA.resize(num_vectors + 1);
+            for (auto &m : VA) m = fdd::dev().malloc<DType>(std::max(nd, 1));
+            qa.free();
+            qa = fdd::dev().malloc<DType>(std::max(nd, 1));
+        }
+        residual_history.clear();
+
+        tree_operator(f, f_l);
+        initialize_arrays(u_k, r_k, f);
+
+        DType r_norm;
+        DType r_0_norm;
+        gather_norm(r_0_norm, r_k);
+        residual_history.push_back(r_0_norm);
+        if (print_history) pstdout("- Iter %3d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", 0, r_0_norm, 1.0);
+
+        bool converged = false;
+        int iter = 0;
+        int j;
+        DType alpha_j, beta_j, gamma_j, gamma_k;
+        std::vector<double> coeffs(num_vectors + 1);
+        std::vector<const double *> ptrs(num_vectors + 1);
+
+        while (iter < max_iterations)
+        {
+            if (iter > 0)
+            {
+                stiffness_matrix(r_k, u_k);
+                math.vector_vector_addition(r_k, 1.0, f, -1.0, r_k, num_values);
+                gather_norm(r_norm, r_k);
+                gamma[0] = r_norm;
+            }
+            else
+            {
+                gamma[0] = r_0_norm;
+            }
+
+            math.vector_scaling(V[0], 1.0 / gamma[0], r_k, num_values);
+            gather_weighted(VA[0], V[0]);
+
+            for (j = 0; j < num_vectors; j++)
+            {
+                iter++;
+
+                direct_stiffness_summation(Z[j], V[j]);
+                stiffness_matrix(q_k, Z[j]);
+
+                // H[0..j][j] = <q, V[i]> for all i from the same q (classical Gram-Schmidt)
+                gather_weighted(qa, q_k);
+                for (int i = 0; i < j + 1; i++) ptrs[i] = VA[i].template as<double>();
+                {
+                    fdd::ProfileScope prof("reduce_vec2_kernel<MultiDotW>", 8.0 * nd * (j + 3));
+                    FDD_CALL(fdd_multi_weighted_inner_product(scalars.as<double>(), reduce_ws.as<double>(), qa.as<double>(), ptrs.data(), j + 1, norm_weight.as<double>(), nd, fdd::dev().stream));
+                }
+                fetch_scalars(coeffs.data(), j + 1);
+                for (int i = 0; i < j + 1; i++)
+                {
+                    H[i][j] = coeffs[i];
+                    coeffs[i] = -H[i][j];
+                    ptrs[i] = V[i].template as<double>();
+                }
+                {
+                    fdd::ProfileScope prof("ew_vec2_kernel<MultiAxpy>", 8.0 * num_values * (j + 3));
+                    FDD_CALL(fdd_multi_axpy(q_k.as<double>(), coeffs.data(), ptrs.data(), j + 1, num_values, fdd::dev().stream));
+                }
+
+                for (int i = 0; i < j; i++)
+                {
+                    DType h_ij = H[i][j];
+                    H[i][j] = c_gmres[i] * h_ij + s_gmres[i] * H[i + 1][j];
+                    H[i + 1][j] = -s_gmres[i] * h_ij + c_gmres[i] * H[i + 1][j];
+                }
+
+                gather_norm(alpha_j, q_k);
+
+                if (std::abs(alpha_j) == 0.0)
+                {
+                    converged = true;
+                    break;
+                }
+
+                beta_j = std::sqrt(H[j][j] * H[j][j] + alpha_j * alpha_j);
+                gamma_j = 1.0 / beta_j;
+                c_gmres[j] = H[j][j] * gamma_j;
+                s_gmres[j] = alpha_j * gamma_j;
+                H[j][j] = beta_j;
+                gamma[j + 1] = -s_gmres[j] * gamma[j];
+                gamma[j] = c_gmres[j] * gamma[j];
+
+                r_norm = std::abs(gamma[j + 1]);
+                residual_history.push_back(r_norm);
+                if (print_history) pstdout("- Iter %3d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", iter, r_norm, r_norm / r_0_norm);
+
+                if (use_relative ? (r_norm / r_0_norm < tolerance) : (r_norm < tolerance))
+                {
+                    converged = true;
+                    break;
+                }
+
+                if (iter >= max_iterations)
+                {
+                    converged = true;
+                    break;
+                }
+
+                math.vector_scaling(V[j + 1], 1.0 / alpha_j, q_k, num_values);
+                gather_weighted(VA[j + 1], V[j + 1]);
+            }
+
+            if (j == num_vectors) j--;
+
+            for (int k = j; k >= 0; k--)
+            {
+                gamma_k = gamma[k];
+                for (int i = j; i > k; i--) gamma_k -= H[k][i] * c_gmres[i];
+                c_gmres[k] = gamma_k / H[k][k];
+            }
+
+            for (int i = 0; i < j + 1; i++)
+            {
+                coeffs[i] = c_gmres[i];
+                ptrs[i] = Z[i].template as<double>();
+            }
+            {
+                fdd::ProfileScope prof("ew_vec2_kernel<MultiAxpy>", 8.0 * num_values * (j + 3));
+                FDD_CALL(fdd_multi_axpy(u_k.as<double>(), coeffs.data(), ptrs.data(), j + 1, num_values, fdd::dev().stream));
+            }
+
+            if (converged) break;
+        }
+
+        FDD_CALL(fdd_sub_copy_f64_f64(u_l.as<double>(), u_k.as<double>(), levels[0].num_points, fdd::dev().stream));
+        num_iterations += iter;
+    }
+
     // subdomain.tpp:4309-4489
     void generalized_minimum_residual(fdd::memory &u_l, fdd::memory &f_l, bool print_history = true, bool use_relative = false)
     {
+        if (restructured and fused_dssum and can_restructure())
+        {
+            gmres_restructured(u_l, f_l, print_history, use_relative);
+            return;
+        }
+
         if ((int)Z.size() != num_vectors) allocate_krylov();
         residual_history.clear();
 

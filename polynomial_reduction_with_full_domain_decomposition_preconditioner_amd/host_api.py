@@ -231,6 +231,9 @@ class Problem:
     def set_options(self, max_iterations=-1, tolerance=float("nan"), num_vectors=-1, use_preconditioner=-1, preconditioner_type=-1, sub_num_vectors=-1, sub_max_iterations=-1, sub_build_tree=-1):
         _H().call("fddh_problem_set_options", self.h, max_iterations, tolerance, num_vectors, int(use_preconditioner), preconditioner_type, sub_num_vectors, sub_max_iterations, int(sub_build_tree))
 
+    def set_flag(self, name, value):
+        _H().call("fddh_problem_set_flag", self.h, name.encode(), int(value))
+
     def dssum(self, u, mask=True, weight=False):
         out = np.zeros(self.n)
         _H().call("fddh_problem_dssum", self.h, _dp(out), _dp(np.ascontiguousarray(u)), int(mask), int(weight))

@@ -203,6 +203,65 @@ int fdd_amg_vector_multiplication(double *uv, const double *u, const double *v, 
 int fdd_amg_matvec(double *y, const int *p, const int *c, const double *v, const double *x, double a, double b, int n, void *s) { (void)s; orc_amg_matvec(y, p, c, v, x, a, b, n); return 0; }
 int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int n, void *s) { return fdd_sub_inner_product(out, ws, x, y, n, s); }
 
+/* ---- multi-vector forms: the reference's launch-per-vector sequences ---- */
+int fdd_multi_weighted_inner_product(double *out, double *ws, const double *a, const double *const *b, int m, const double *w, int n, void *s)
+{
+    for (int k = 0; k < m; k++) fdd_sub_weighted_inner_product(out + k, ws, a, b[k], w, n, s);
+    return 0;
+}
+int fdd_multi_axpy(double *q, const double *c, const double *const *v, int m, int n, void *s)
+{
+    (void)s;
+    for (int k = 0; k < m; k++) orc_vector_vector_addition(q, 1.0, q, c[k], v[k], n);
+    return 0;
+}
+int fdd_gather_weighted_norm2(double *out, double *ws, const int *p, const int *c, const double *u, const double *w, int n, void *s)
+{
+    double *t = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    orc_csr_multiply_weight(t, p, c, NULL, u, w, 0); /* n = 0: keeps the symbol referenced, computes nothing */
+    for (int i = 0; i < n; i++)
+    {
+        double acc = 0.0;
+        for (int j = p[i]; j < p[i + 1]; j++) acc += 1.0 * u[c[j]];
+        t[i] = acc * w[i];
+    }
+    fdd_sub_weighted_inner_product(out, ws, t, t, w, n, s);
+    free(t);
+    return 0;
+}
+
+/* ---- fused dssum: the two reference SpMVs, restricted to a node range ---- */
+static void gather_range(double *t, const int *p, const int *c, const double *u, const double *w, int n0, int n1)
+{
+    for (int i = n0; i < n1; i++)
+    {
+        double s = 0.0;
+        for (int j = p[i]; j < p[i + 1]; j++) s += 1.0 * u[c[j]];
+        t[i] = w ? s * w[i] : s;
+    }
+}
+static void scatter_range(double *out, const double *t, const int *p, const int *c, const double *m, int n0, int n1)
+{
+    for (int i = n0; i < n1; i++)
+        for (int j = p[i]; j < p[i + 1]; j++)
+        {
+            double v = 0.0 + 1.0 * t[i];
+            out[c[j]] = m ? v * m[c[j]] : v;
+        }
+}
+int fdd_dssum_fused(double *out, double *t, const int *p, const int *c, const double *u, const double *w, const double *m, int n0, int n1, void *s)
+{
+    (void)s;
+    double *tmp = t ? t : (double *)malloc(sizeof(double) * (size_t)(n1 > 0 ? n1 : 1));
+    gather_range(tmp, p, c, u, w, n0, n1);
+    scatter_range(out, tmp, p, c, m, n0, n1);
+    if (!t) free(tmp);
+    return 0;
+}
+int fdd_dssum_gather(double *t, const int *p, const int *c, const double *u, const double *w, int n0, int n1, void *s) { (void)s; gather_range(t, p, c, u, w, n0, n1); return 0; }
+int fdd_dssum_scatter(double *out, const double *t, const int *p, const int *c, const double *m, int n0, int n1, void *s) { (void)s; scatter_range(out, t, p, c, m, n0, n1); return 0; }
+int fdd_fill_indexed(double *out, const int *idx, double v, int n, void *s) { (void)s; for (int i = 0; i < n; i++) out[idx[i]] = v; return 0; }
+
 /* ---- interface exchange ---- */
 int fdd_interface_pack(double *slots, const int *slot_of, const double *prefix, int n, void *s) { (void)s; for (int i = 0; i < n; i++) slots[slot_of[i]] = prefix[i]; return 0; }
 int fdd_interface_unpack(double *prefix, const double *slots, const int *slot_of, int n, void *s) { (void)s; for (int i = 0; i < n; i++) prefix[i] = slots[slot_of[i]]; return 0; }

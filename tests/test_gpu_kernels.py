@@ -601,6 +601,143 @@ def test_amg_elementwise(gpu):
     assert np.all(host(duv) == -2.5)
 
 
+# ------------------------------------- fused dssum / multi-vector forms
+def boolean_gather(nodes, points, seed, empty_points=0):
+    """Qt of a boolean scatter: every point belongs to exactly one node (or, for
+    `empty_points` of them, to none: Dirichlet points of a Subdomain Q)."""
+    rng = np.random.default_rng(seed)
+    owner = rng.integers(0, nodes, points)
+    owner[:nodes] = np.arange(nodes)  # every node has at least one point
+    rng.shuffle(owner)
+    keep = np.ones(points, bool)
+    keep[rng.choice(points, empty_points, replace=False)] = False
+    order = np.argsort(owner[keep], kind="stable")
+    pts = np.nonzero(keep)[0][order].astype(np.int32)
+    ptr = np.zeros(nodes + 1, np.int32)
+    np.add.at(ptr, owner[keep] + 1, 1)
+    ptr = np.cumsum(ptr).astype(np.int32)
+    return ptr, pts, np.nonzero(~keep)[0].astype(np.int32)
+
+
+@pytest.mark.parametrize("weighted,masked", [(False, False), (True, False), (False, True), (True, True)])
+def test_dssum_fused_equals_two_spmvs(gpu, weighted, masked):
+    L = S.oracle()
+    nodes, points = 40000, 90000
+    tptr, tcol, _ = boolean_gather(nodes, points, 1)
+    tval = np.ones(points)
+    # Q = Qt^T: one entry per point
+    qcol = np.zeros(points, np.int32)
+    for nd in range(nodes):
+        qcol[tcol[tptr[nd]:tptr[nd + 1]]] = nd
+    qptr = np.arange(points + 1, dtype=np.int32)
+    u, w, m = rnd(points, 2), rnd(nodes, 3) + 2, (rnd(points, 4) > 0).astype(float)
+
+    t = np.zeros(nodes)
+    if weighted:
+        L.orc_csr_multiply_weight(P(t), P(tptr), P(tcol), P(tval), P(u), P(w), nodes)
+    else:
+        L.orc_csr_multiply(P(t), P(tptr), P(tcol), P(tval), P(u), nodes)
+    ref = np.zeros(points)
+    if masked:
+        L.orc_csr_multiply_weight(P(ref), P(qptr), P(qcol), P(tval), P(t), P(m), points)
+    else:
+        L.orc_csr_multiply(P(ref), P(qptr), P(qcol), P(tval), P(t), points)
+
+    dptr, dcol, du = dev(tptr, gpu), dev(tcol, gpu), dev(u, gpu)
+    dw = dev(w, gpu) if weighted else None
+    dm = dev(m, gpu) if masked else None
+    out = torch.full((points,), 9.0, dtype=torch.float64, device=gpu)
+    dt = torch.zeros(nodes, dtype=torch.float64, device=gpu)
+    k("fdd_dssum_fused", out, dt, dptr, dcol, du, dw, dm, 0, nodes)
+    assert np.array_equal(host(out), ref) and np.array_equal(host(dt), t)
+
+    # in place, and split into gather(prefix) / fused(rest) / scatter(prefix)
+    nb = 1234
+    inplace = dev(u, gpu)
+    k("fdd_dssum_gather", dt, dptr, dcol, inplace, dw, 0, nb)
+    k("fdd_dssum_fused", inplace, None, dptr, dcol, inplace, dw, dm, nb, nodes)
+    k("fdd_dssum_scatter", inplace, dt, dptr, dcol, dm, 0, nb)
+    assert np.array_equal(host(inplace), ref)
+
+
+def test_dssum_fused_with_points_without_dof(gpu):
+    """Subdomain Q has empty rows on Dirichlet points (subdomain.tpp:1517-1520):
+    they receive the 0.0 the SpMV writes."""
+    L = S.oracle()
+    nodes, points = 30000, 70000
+    tptr, tcol, no_dof = boolean_gather(nodes, points, 5, empty_points=5000)
+    nnz = len(tcol)
+    qptr = np.zeros(points + 1, np.int32)
+    qcol = np.zeros(nnz, np.int32)
+    has = np.ones(points, bool)
+    has[no_dof] = False
+    qptr[1:] = np.cumsum(has)
+    owner = np.zeros(points, np.int32)
+    for nd in range(nodes):
+        owner[tcol[tptr[nd]:tptr[nd + 1]]] = nd
+    qcol[:] = owner[has]
+    u = rnd(points, 6)
+    ones = np.ones(nnz)
+    t, ref = np.zeros(nodes), np.full(points, 5.0)
+    L.orc_csr_multiply(P(t), P(tptr), P(tcol), P(ones), P(u), nodes)
+    L.orc_csr_multiply(P(ref), P(qptr), P(qcol), P(ones), P(t), points)
+    out = torch.full((points,), 5.0, dtype=torch.float64, device=gpu)
+    k("fdd_dssum_fused", out, None, dev(tptr, gpu), dev(tcol, gpu), dev(u, gpu), None, None, 0, nodes)
+    k("fdd_fill_indexed", out, dev(no_dof, gpu), 0.0, len(no_dof))
+    assert np.array_equal(host(out), ref)
+
+
+@pytest.mark.parametrize("m", [1, 2, 5, 8])
+def test_multi_axpy_equals_successive_axpys(gpu, m):
+    L = S.oracle()
+    for n in (1, 1001, 400003):
+        q = rnd(n, 7)
+        V = [rnd(n, 10 + i) for i in range(m)]
+        c = rnd(m, 8)
+        ref = q.copy()
+        for i in range(m):
+            L.orc_vector_vector_addition(P(ref), ctypes.c_double(1.0), P(ref), ctypes.c_double(c[i]), P(V[i]), n)
+        dq = dev(q, gpu)
+        k("fdd_multi_axpy", dq, (ctypes.c_double * m)(*c), [dev(v, gpu) for v in V], m, n)
+        assert np.array_equal(host(dq), ref)
+
+
+@pytest.mark.parametrize("m", [1, 3, 5, 8])
+def test_multi_weighted_inner_product(gpu, m):
+    L = S.oracle()
+    n = 700001
+    nb = (n + 127) // 128
+    a, w = rnd(n, 20), np.abs(rnd(n, 21))
+    B = [rnd(n, 30 + i) for i in range(m)]
+    ws = reduce_workspace(gpu)
+    out = torch.zeros(8, dtype=torch.float64, device=gpu)
+    k("fdd_multi_weighted_inner_product", out, ws, dev(a, gpu), [dev(b, gpu) for b in B], m, dev(w, gpu), n)
+    got = host(out)
+    block = np.zeros(nb)
+    for i in range(m):
+        L.orc_sub_weighted_inner_product(P(block), P(a), P(B[i]), P(w), n, nb)
+        ref = L.orc_block_sum(P(block), nb)
+        assert abs(got[i] - ref) <= 1e-13 * np.abs(a * B[i] * w).sum()
+
+
+def test_gather_weighted_norm2(gpu):
+    L = S.oracle()
+    nodes, points = 50000, 120000
+    tptr, tcol, _ = boolean_gather(nodes, points, 9)
+    u, w = rnd(points, 40), (rnd(nodes, 41) > -0.5).astype(float)
+    t = np.zeros(nodes)
+    ones = np.ones(points)
+    L.orc_csr_multiply_weight(P(t), P(tptr), P(tcol), P(ones), P(u), P(w), nodes)
+    nb = (nodes + 127) // 128
+    block = np.zeros(nb)
+    L.orc_sub_weighted_inner_product(P(block), P(t), P(t), P(w), nodes, nb)
+    ref = L.orc_block_sum(P(block), nb)
+    ws = reduce_workspace(gpu)
+    out = torch.zeros(1, dtype=torch.float64, device=gpu)
+    k("fdd_gather_weighted_norm2", out, ws, dev(tptr, gpu), dev(tcol, gpu), dev(u, gpu), dev(w, gpu), nodes)
+    assert abs(host(out)[0] - ref) <= 1e-13 * ref
+
+
 # -------------------------------------------------------------- runtime
 def test_runtime_memory_roundtrip(gpu):
     L = lib.hip()

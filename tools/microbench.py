@@ -168,6 +168,14 @@ def main():
         report("csr.Q multiply (scatter, 1 nnz/row)", bytes_Q, timeit(lambda: k("fdd_csr_plan_multiply", planQ, y_pts, qp, qc, qv, x_nodes, None)), results)
         report("csr.Q multiply_weight", bytes_Q + 8 * Pq, timeit(lambda: k("fdd_csr_plan_multiply", planQ, y_pts, qp, qc, qv, x_nodes, a)), results)
         report("csr.Qt multiply (gather, 1-8 nnz/row)", bytes_Qt, timeit(lambda: k("fdd_csr_plan_multiply", planQt, x_nodes, tp, tc, tv, y_pts, None)), results)
+        # fused gather-scatter dssum and the gather passes of the restructured inner solve
+        wn = torch.rand(nodes, dtype=torch.float64, device=dev)
+        b_ds = 4.0 * nodes + 20.0 * Pq
+        report("dssum.fused (plain)", b_ds, timeit(lambda: k("fdd_dssum_fused", y_pts, None, tp, tc, b, None, None, 0, nodes)), results)
+        report("dssum.fused (weight+mask)", b_ds + 8.0 * Pq + 8.0 * nodes, timeit(lambda: k("fdd_dssum_fused", y_pts, None, tp, tc, b, wn, a, 0, nodes)), results)
+        report("dssum.fused in place (weight+mask)", b_ds + 8.0 * Pq + 8.0 * nodes, timeit(lambda: k("fdd_dssum_fused", b, None, tp, tc, b, wn, a, 0, nodes)), results)
+        report("dssum.gather (weight)", 4.0 * nodes + 12.0 * Pq + 16.0 * nodes, timeit(lambda: k("fdd_dssum_gather", x_nodes, tp, tc, b, wn, 0, nodes)), results)
+        report("dssum.gather_weighted_norm2", 4.0 * nodes + 12.0 * Pq + 8.0 * nodes, timeit(lambda: k("fdd_gather_weighted_norm2", out, ws, tp, tc, b, wn, nodes)), results)
         del qp, qc, qv, tp, tc, tv
         m = 97 if args.quick else args.stencil
         sp, sc, sv = stencil27(m, dev)
