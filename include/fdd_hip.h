@@ -88,6 +88,10 @@ int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows
 int fdd_csr_plan_destroy(fdd_csr_plan *plan);
 int fdd_csr_plan_num_blocks(const fdd_csr_plan *plan, int *num_blocks);
 int fdd_csr_plan_kind(const fdd_csr_plan *plan, int *kind); /* 0 = thread-per-row, 1 = LDS-staged row blocks */
+/* Tell the plan that every stored value is exactly 1.0 (the boolean gather / scatter matrices Q, Qt,
+ * Q_int, ...; CSR_Matrix::assemble checks its host values): the kernels then skip the val array --
+ * 1.0*x is x, so results are unchanged and 8 of the 12 bytes per non-zero are not moved. */
+int fdd_csr_plan_set_unit_values(fdd_csr_plan *plan, int unit_values);
 /* weight may be NULL (multiply) or a device vector of num_rows (multiply_weight) */
 int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const double *weight, void *stream);
 
@@ -207,6 +211,11 @@ int fdd_dssum_fused(double *QQtu, double *t, const int *Qt_ptr, const int *Qt_co
 int fdd_dssum_gather(double *t, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, int node_start, int node_end, void *stream);      /* t = (Qt u) .* w on a node range */
 int fdd_dssum_scatter(double *QQtu, const double *t, const int *Qt_ptr, const int *Qt_col, const double *point_mask, int node_start, int node_end, void *stream);  /* out = (Q t) .* mask on a node range */
 int fdd_fill_indexed(double *out, const int *idx, double value, int n, void *stream); /* out[idx[i]] = value (points without a dof) */
+/* The same three operations on the row blocks of Qt's SpMV plan (unit-value plans only): entries are
+ * staged through LDS so that no global access depends on a row length.  mode 0 = gather + scatter,
+ * 1 = gather only (t out), 2 = scatter only (t in); nodes [row_lo, row_hi).  Same bits as above. */
+int fdd_csr_plan_dssum(const fdd_csr_plan *plan, double *QQtu, double *t, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, const double *point_mask, int row_lo, int row_hi, int mode, void *stream);
+int fdd_csr_plan_gather_weighted_norm2(const fdd_csr_plan *plan, double *out, double *ws, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, void *stream);
 
 /* ------------------------------------------------------------------ */
 /* interface exchange helpers: gslib gs(gs_add) on the boundary-node    */

@@ -94,6 +94,48 @@ __device__ __forceinline__ double fdd_row_sum(const int *__restrict__ A_col, con
     return s;
 }
 
+// The same for NPT rows per lane: all col loads of a CH-wide slice of all NPT
+// rows are issued, then all u gathers, then each row adds its products in
+// column order.  NPT*CH gathers in flight per lane is what it takes to cover
+// the HBM latency with three dependent round trips (ptr -> col -> u) per row.
+// Rows to skip are passed with j0 == j1.
+template <int NPT, int CH, bool UNIT>
+__device__ __forceinline__ void fdd_multi_row_sum(const int *__restrict__ A_col, const double *__restrict__ A_val, const double *u, const int (&j0)[NPT], const int (&j1)[NPT], double (&s)[NPT])
+{
+    int len_max = 0;
+#pragma unroll
+    for (int r = 0; r < NPT; r++)
+    {
+        s[r] = 0.0;
+        len_max = (j1[r] - j0[r] > len_max) ? j1[r] - j0[r] : len_max;
+    }
+    for (int off = 0; off < len_max; off += CH)
+    {
+        int c[NPT][CH];
+        double a[NPT][CH];
+        double x[NPT][CH];
+#pragma unroll
+        for (int r = 0; r < NPT; r++)
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+            {
+                const int j = j0[r] + off + k;
+                const bool on = j < j1[r];
+                c[r][k] = on ? A_col[j] : 0;
+                a[r][k] = (UNIT || !on) ? 1.0 : A_val[j];
+            }
+#pragma unroll
+        for (int r = 0; r < NPT; r++)
+#pragma unroll
+            for (int k = 0; k < CH; k++) x[r][k] = (j0[r] + off + k < j1[r]) ? u[c[r][k]] : 0.0;
+#pragma unroll
+        for (int r = 0; r < NPT; r++)
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+                if (j0[r] + off + k < j1[r]) s[r] += a[r][k] * x[r][k];
+    }
+}
+
 #define FDD_NUM_XCD 8
 __device__ __forceinline__ int fdd_xcd_chunked_block(int bid, int nblocks)
 {

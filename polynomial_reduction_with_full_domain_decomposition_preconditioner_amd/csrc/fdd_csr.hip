@@ -21,6 +21,8 @@
 //    tree; order differs).
 #include "fdd_common.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace
@@ -45,19 +47,29 @@ struct EpiAxpby // AMG/csr_matrix.cpp:112-134
     __device__ double apply(double s, int row, const double *y_old) const { return alpha * s + beta * y_old[row]; }
 };
 
-template <typename Epi>
+// Lane-per-row SpMV.  Each lane owns NPT rows (strided by the workgroup size,
+// so every access stays coalesced across lanes) and keeps the column loads,
+// then the x gathers, of all of them in flight together (fdd_multi_row_sum);
+// sums are in column order.  UNIT: every stored value is 1.0 (the plan knows),
+// val is not read and 1.0*x is x.  Workgroups in XCD-chunked order.
+template <typename Epi, bool UNIT, int NPT>
 __global__ __launch_bounds__(kBlock) void csr_row_kernel(double *__restrict__ Au, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const double *__restrict__ A_val, const double *__restrict__ u, Epi epi, int row_start, int row_end)
 {
-    // one row per lane, workgroups in XCD-chunked order: the x gathers of the
-    // boolean gather/scatter matrices then stay inside one L2 (fdd_common.h)
-    const int i = row_start + fdd_xcd_chunked_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
-    if (i < row_end)
+    const int tile = fdd_xcd_chunked_block(blockIdx.x, gridDim.x) * (kBlock * NPT);
+    int row[NPT], j0[NPT], j1[NPT];
+    double s[NPT];
+#pragma unroll
+    for (int r = 0; r < NPT; r++)
     {
-        const int j0 = A_ptr[i];
-        const int j1 = A_ptr[i + 1];
-        const double Au_i = fdd_row_sum<false>(A_col, A_val, u, j0, j1); // column order, loads of the row in flight together
-        Au[i] = epi.apply(Au_i, i, Au);
+        row[r] = row_start + tile + r * kBlock + threadIdx.x;
+        const bool on = row[r] < row_end;
+        j0[r] = on ? A_ptr[row[r]] : 0;
+        j1[r] = on ? A_ptr[row[r] + 1] : 0;
     }
+    fdd_multi_row_sum<NPT, 4, UNIT>(A_col, A_val, u, j0, j1, s);
+#pragma unroll
+    for (int r = 0; r < NPT; r++)
+        if (row[r] < row_end) Au[row[r]] = epi.apply(s[r], row[r], Au);
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -67,25 +79,42 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-template <typename Epi>
+template <typename Epi, bool UNIT>
 __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ Au, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const double *__restrict__ A_val, const double *__restrict__ u, Epi epi, const int *__restrict__ row_blocks)
 {
     __shared__ double prod[kBlockNnz];
     __shared__ double wsum[kBlock / FDD_WAVE];
 
-    const int r0 = row_blocks[blockIdx.x];
-    const int r1 = row_blocks[blockIdx.x + 1];
+    // Row blocks in plain dispatch order: the val/col streams of the 8 XCDs then
+    // advance through adjacent memory (XCD-chunked order measured 9 % slower on
+    // the 27-point stencil; the x window fits every XCD's L2 either way).
+    const int b = blockIdx.x;
+    const int r0 = row_blocks[b];
+    const int r1 = row_blocks[b + 1];
     const int base = A_ptr[r0];
     const int nnz = A_ptr[r1] - base;
 
     if (nnz <= kBlockNnz)
     {
-        // phase 1: coalesced stream of the block's non-zeros
+        // phase 1: coalesced stream of the block's non-zeros: all column (and
+        // value) loads first, then all x gathers, flat over the non-zeros --
+        // no dependence on row lengths, every lane has 8 loads in flight
+        constexpr int kIts = kBlockNnz / kBlock;
+        int c[kIts];
+        double a[kIts];
 #pragma unroll
-        for (int it = 0; it < kBlockNnz / kBlock; it++)
+        for (int it = 0; it < kIts; it++)
         {
             const int k = threadIdx.x + it * kBlock;
-            if (k < nnz) prod[k] = A_val[base + k] * u[A_col[base + k]];
+            const bool on = k < nnz;
+            c[it] = on ? A_col[base + k] : 0;
+            a[it] = (UNIT || !on) ? 1.0 : A_val[base + k];
+        }
+#pragma unroll
+        for (int it = 0; it < kIts; it++)
+        {
+            const int k = threadIdx.x + it * kBlock;
+            if (k < nnz) prod[k] = a[it] * u[c[it]];
         }
         __syncthreads();
 
@@ -103,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
     {
         // a single long row (the plan guarantees r1 == r0 + 1)
         double s = 0.0;
-        for (int k = threadIdx.x; k < nnz; k += kBlock) s += A_val[base + k] * u[A_col[base + k]];
+        for (int k = threadIdx.x; k < nnz; k += kBlock) s += (UNIT ? 1.0 : A_val[base + k]) * u[A_col[base + k]];
         s = wave_sum(s);
         if ((threadIdx.x & (FDD_WAVE - 1)) == 0) wsum[threadIdx.x / FDD_WAVE] = s;
         __syncthreads();
@@ -118,13 +147,185 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
 }
 
 template <typename Epi>
-int launch_rows(double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const Epi &epi, int row_start, int row_end, void *stream)
+int launch_rows(double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const Epi &epi, int row_start, int row_end, void *stream, bool unit_values = false)
 {
     if (row_end <= row_start) return 0;
-    int grid = (int)(((long long)row_end - row_start + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(csr_row_kernel<Epi>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, A_ptr, A_col, A_val, u, epi, row_start, row_end);
+    const long long rows = (long long)row_end - row_start;
+    if (unit_values)
+    {
+        constexpr int NPT = 4;
+        const int grid = (int)((rows + kBlock * NPT - 1) / (kBlock * NPT));
+        hipLaunchKernelGGL((csr_row_kernel<Epi, true, NPT>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, A_ptr, A_col, A_val, u, epi, row_start, row_end);
+    }
+    else
+    {
+        constexpr int NPT = 2;
+        const int grid = (int)((rows + kBlock * NPT - 1) / (kBlock * NPT));
+        hipLaunchKernelGGL((csr_row_kernel<Epi, false, NPT>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, A_ptr, A_col, A_val, u, epi, row_start, row_end);
+    }
     FDD_LAUNCH_CHECK();
     return 0;
+}
+
+// ---------------------------------------------------------------------------
+// LDS-staged gather-scatter (dssum) on the row blocks of a boolean gather
+// matrix Qt: the balanced form of fdd_dssum.hip's lane-per-node kernel.
+//   phase 1 (gather):  flat over the block's entries, x[k] = u[col[k]] -> LDS
+//   phase 2:           one lane per node: s = sum of its x in column order,
+//                      s *= weight[node], t[node] = s; s is written back over
+//                      the node's LDS entries
+//   phase 3 (scatter): flat over the entries, out[col[k]] = (0.0+1.0*s)*mask
+// Global accesses never depend on row lengths (8 independent loads per lane per
+// phase), only the LDS phase sees the raggedness.  Rows [row_lo, row_hi) only:
+// the boundary prefix of a multi-rank Domain is gathered / scattered apart.
+// MODE 0: gather + scatter, 1: gather only, 2: scatter only (s read from t).
+// ---------------------------------------------------------------------------
+template <int MODE, bool WEIGHT, bool MASK>
+__global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double *__restrict__ t, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const double *u, const double *__restrict__ node_weight, const double *__restrict__ point_mask, const int *__restrict__ row_blocks, int block_first, int row_lo, int row_hi)
+{
+    __shared__ double x[kBlockNnz];
+    constexpr int kIts = kBlockNnz / kBlock;
+
+    const int b = block_first + blockIdx.x;
+    const int r0 = row_blocks[b] > row_lo ? row_blocks[b] : row_lo;
+    const int r1 = row_blocks[b + 1] < row_hi ? row_blocks[b + 1] : row_hi;
+    if (r1 <= r0) return;
+    const int base = Qt_ptr[r0];
+    const int nnz = Qt_ptr[r1] - base; // <= kBlockNnz: boolean gather rows are short (the plan checks)
+
+    int c[kIts];
+#pragma unroll
+    for (int it = 0; it < kIts; it++)
+    {
+        const int k = threadIdx.x + it * kBlock;
+        c[it] = (k < nnz) ? Qt_col[base + k] : 0;
+    }
+    if (MODE != 2)
+    {
+#pragma unroll
+        for (int it = 0; it < kIts; it++)
+        {
+            const int k = threadIdx.x + it * kBlock;
+            if (k < nnz) x[k] = 1.0 * u[c[it]];
+        }
+        __syncthreads();
+    }
+
+    for (int row = r0 + threadIdx.x; row < r1; row += kBlock)
+    {
+        const int j0 = Qt_ptr[row] - base;
+        const int j1 = Qt_ptr[row + 1] - base;
+        double s;
+        if (MODE != 2)
+        {
+            s = 0.0;
+            for (int j = j0; j < j1; j++) s += x[j];
+            if (WEIGHT) s = s * node_weight[row];
+            if (t) t[row] = s;
+        }
+        else
+        {
+            s = t[row];
+        }
+        if (MODE != 1)
+            for (int j = j0; j < j1; j++) x[j] = s;
+    }
+
+    if (MODE != 1)
+    {
+        __syncthreads();
+        double mk[kIts];
+        if (MASK)
+        {
+#pragma unroll
+            for (int it = 0; it < kIts; it++)
+            {
+                const int k = threadIdx.x + it * kBlock;
+                mk[it] = (k < nnz) ? point_mask[c[it]] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kIts; it++)
+        {
+            const int k = threadIdx.x + it * kBlock;
+            if (k < nnz)
+            {
+                const double v = 0.0 + 1.0 * x[k];
+                out[c[it]] = MASK ? v * mk[it] : v;
+            }
+        }
+    }
+}
+
+// sum_nodes s*s*w with s = (Qt u)[node]*w[node], on the same row blocks; a
+// capped grid strides over the blocks, one partial per workgroup
+__global__ __launch_bounds__(kBlock) void gather_norm2_block_kernel(double *__restrict__ ws, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const double *__restrict__ u, const double *__restrict__ w, const int *__restrict__ row_blocks, int num_blocks)
+{
+    __shared__ double x[kBlockNnz];
+    __shared__ double wsum[kBlock / FDD_WAVE];
+    constexpr int kIts = kBlockNnz / kBlock;
+    double acc = 0.0;
+
+    for (int b = blockIdx.x; b < num_blocks; b += gridDim.x)
+    {
+        const int r0 = row_blocks[b];
+        const int r1 = row_blocks[b + 1];
+        const int base = Qt_ptr[r0];
+        const int nnz = Qt_ptr[r1] - base;
+        int c[kIts];
+#pragma unroll
+        for (int it = 0; it < kIts; it++)
+        {
+            const int k = threadIdx.x + it * kBlock;
+            c[it] = (k < nnz) ? Qt_col[base + k] : 0;
+        }
+        __syncthreads(); // previous block's readers of x are done
+#pragma unroll
+        for (int it = 0; it < kIts; it++)
+        {
+            const int k = threadIdx.x + it * kBlock;
+            if (k < nnz) x[k] = 1.0 * u[c[it]];
+        }
+        __syncthreads();
+        for (int row = r0 + threadIdx.x; row < r1; row += kBlock)
+        {
+            const int j0 = Qt_ptr[row] - base;
+            const int j1 = Qt_ptr[row + 1] - base;
+            double s = 0.0;
+            for (int j = j0; j < j1; j++) s += x[j];
+            const double wn = w[row];
+            s = s * wn;
+            acc += s * s * wn;
+        }
+    }
+
+    acc = wave_sum(acc);
+    if ((threadIdx.x & (FDD_WAVE - 1)) == 0) wsum[threadIdx.x / FDD_WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double tsum = wsum[0];
+#pragma unroll
+        for (int k = 1; k < kBlock / FDD_WAVE; k++) tsum += wsum[k];
+        ws[blockIdx.x] = tsum;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void fold_partials_kernel(double *out, const double *ws, int n)
+{
+    __shared__ double wsum[kBlock / FDD_WAVE];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += kBlock) s += ws[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & (FDD_WAVE - 1)) == 0) wsum[threadIdx.x / FDD_WAVE] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double tsum = wsum[0];
+#pragma unroll
+        for (int k = 1; k < kBlock / FDD_WAVE; k++) tsum += wsum[k];
+        out[0] = tsum;
+    }
 }
 
 } // namespace
@@ -135,8 +336,11 @@ struct fdd_csr_plan
     int num_cols;
     int num_nnz;
     int kind; // 0: thread-per-row, 1: LDS-staged row blocks
+    int unit_values; // every stored value is exactly 1.0: val need not be read
+    int has_long_rows; // some row exceeds a block (workgroup-reduced in SpMV)
     int num_blocks;
     int *row_blocks_dev; // num_blocks + 1
+    std::vector<int> row_blocks_host;
 };
 
 extern "C" {
@@ -184,11 +388,18 @@ int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows
     p->num_cols = num_cols;
     p->num_nnz = num_nnz;
     p->kind = 0;
+    p->unit_values = 0;
+    p->has_long_rows = 0;
     p->num_blocks = 0;
     p->row_blocks_dev = nullptr;
 
     // boolean gather/scatter matrices: thread-per-row is already minimal traffic
-    if (num_rows == 0 || (double)num_nnz <= 4.0 * (double)num_rows)
+    // rows with exactly one entry (the scatter matrices Q): lane-per-row is minimal
+    // traffic and perfectly balanced.  Anything with longer / ragged rows goes
+    // through LDS row staging.  FDD_TUNE_CSR_ROW_BLOCK_THRESHOLD overrides (development).
+    double threshold = 1.0;
+    if (const char *e = getenv("FDD_TUNE_CSR_ROW_BLOCK_THRESHOLD")) threshold = atof(e);
+    if (num_rows == 0 || (double)num_nnz <= threshold * (double)num_rows)
     {
         *plan = p;
         return 0;
@@ -202,13 +413,18 @@ int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows
         const int base = A_ptr_host[r];
         int e = r;
         while (e < num_rows && (e - r) < kBlockRowsMax && A_ptr_host[e + 1] - base <= kBlockNnz) e++;
-        if (e == r) e = r + 1; // one row longer than a block: workgroup-reduced
+        if (e == r)
+        {
+            e = r + 1; // one row longer than a block: workgroup-reduced
+            p->has_long_rows = 1;
+        }
         blocks.push_back(e);
         r = e;
     }
 
     p->kind = 1;
     p->num_blocks = (int)blocks.size() - 1;
+    p->row_blocks_host = blocks;
 
     hipError_t err = hipMalloc((void **)&p->row_blocks_dev, blocks.size() * sizeof(int));
     if (err == hipSuccess) err = hipMemcpy(p->row_blocks_dev, blocks.data(), blocks.size() * sizeof(int), hipMemcpyHostToDevice);
@@ -239,6 +455,84 @@ int fdd_csr_plan_num_blocks(const fdd_csr_plan *plan, int *num_blocks)
     return 0;
 }
 
+// dssum on a plan of the boolean gather matrix Qt; mode 0 = gather + scatter,
+// 1 = gather only (t out), 2 = scatter only (t in); rows [row_lo, row_hi)
+int fdd_csr_plan_dssum(const fdd_csr_plan *plan, double *QQtu, double *t, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, const double *point_mask, int row_lo, int row_hi, int mode, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr && mode >= 0 && mode <= 2);
+    FDD_REQUIRE(row_lo >= 0 && row_hi >= row_lo && row_hi <= plan->num_rows);
+    if (row_hi == row_lo) return 0;
+    FDD_REQUIRE(plan->unit_values != 0); // boolean matrices only
+    FDD_REQUIRE(Qt_ptr != nullptr && Qt_col != nullptr);
+    FDD_REQUIRE(mode == 1 || QQtu != nullptr);
+    FDD_REQUIRE(mode == 2 || u != nullptr);
+    FDD_REQUIRE(mode == 0 || t != nullptr);
+
+    if (plan->kind == 0 || plan->has_long_rows)
+    {
+        // no row blocks (rows of one entry) or rows longer than a block: lane-per-node form
+        if (mode == 0) return fdd_dssum_fused(QQtu, t, Qt_ptr, Qt_col, u, node_weight, point_mask, row_lo, row_hi, stream);
+        if (mode == 1) return fdd_dssum_gather(t, Qt_ptr, Qt_col, u, node_weight, row_lo, row_hi, stream);
+        return fdd_dssum_scatter(QQtu, t, Qt_ptr, Qt_col, point_mask, row_lo, row_hi, stream);
+    }
+
+    // blocks overlapping the row range
+    const std::vector<int> &rb = plan->row_blocks_host;
+    int first = (int)(std::upper_bound(rb.begin(), rb.end(), row_lo) - rb.begin()) - 1;
+    int last = (int)(std::lower_bound(rb.begin(), rb.end(), row_hi) - rb.begin()); // exclusive
+    if (first < 0) first = 0;
+    if (last > plan->num_blocks) last = plan->num_blocks;
+    if (last <= first) return 0;
+
+    const dim3 grid(last - first), block(kBlock);
+    hipStream_t s = fdd_stream(stream);
+    const bool W = node_weight != nullptr && mode != 2, M = point_mask != nullptr && mode != 1;
+#define FDD_DSB(MODE, WW, MM) hipLaunchKernelGGL((dssum_block_kernel<MODE, WW, MM>), grid, block, 0, s, QQtu, t, Qt_ptr, Qt_col, u, node_weight, point_mask, plan->row_blocks_dev, first, row_lo, row_hi)
+    if (mode == 0)
+    {
+        if (W && M) FDD_DSB(0, true, true);
+        else if (W) FDD_DSB(0, true, false);
+        else if (M) FDD_DSB(0, false, true);
+        else FDD_DSB(0, false, false);
+    }
+    else if (mode == 1)
+    {
+        if (W) FDD_DSB(1, true, false);
+        else FDD_DSB(1, false, false);
+    }
+    else
+    {
+        if (M) FDD_DSB(2, false, true);
+        else FDD_DSB(2, false, false);
+    }
+#undef FDD_DSB
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[0] = sum_nodes s*s*w, s = (Qt u)[node]*w[node], on the plan's row blocks
+int fdd_csr_plan_gather_weighted_norm2(const fdd_csr_plan *plan, double *out, double *ws, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr && out != nullptr && ws != nullptr);
+    hipStream_t s = fdd_stream(stream);
+    if (plan->num_rows == 0) return (int)hipMemsetAsync(out, 0, sizeof(double), s);
+    FDD_REQUIRE(plan->unit_values != 0 && Qt_ptr != nullptr && Qt_col != nullptr && u != nullptr && node_weight != nullptr);
+    if (plan->kind == 0 || plan->has_long_rows) return fdd_gather_weighted_norm2(out, ws, Qt_ptr, Qt_col, u, node_weight, plan->num_rows, stream);
+    const int grid = plan->num_blocks < FDD_REDUCE_MAX_BLOCKS ? plan->num_blocks : FDD_REDUCE_MAX_BLOCKS;
+    hipLaunchKernelGGL(gather_norm2_block_kernel, dim3(grid), dim3(kBlock), 0, s, ws, Qt_ptr, Qt_col, u, node_weight, plan->row_blocks_dev, plan->num_blocks);
+    FDD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(kBlock), 0, s, out, ws, grid);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fdd_csr_plan_set_unit_values(fdd_csr_plan *plan, int unit_values)
+{
+    FDD_REQUIRE(plan != nullptr);
+    plan->unit_values = unit_values != 0;
+    return 0;
+}
+
 int fdd_csr_plan_kind(const fdd_csr_plan *plan, int *kind)
 {
     FDD_REQUIRE(plan != nullptr && kind != nullptr);
@@ -254,14 +548,26 @@ int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr
 
     if (plan->kind == 0)
     {
-        if (weight) return launch_rows(Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, 0, plan->num_rows, stream);
-        return launch_rows(Au, A_ptr, A_col, A_val, u, EpiPlain{}, 0, plan->num_rows, stream);
+        if (weight) return launch_rows(Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, 0, plan->num_rows, stream, plan->unit_values != 0);
+        return launch_rows(Au, A_ptr, A_col, A_val, u, EpiPlain{}, 0, plan->num_rows, stream, plan->unit_values != 0);
     }
 
-    if (weight)
-        hipLaunchKernelGGL(csr_block_kernel<EpiWeight>, dim3(plan->num_blocks), dim3(kBlock), 0, fdd_stream(stream), Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev);
+    const dim3 grid(plan->num_blocks), block(kBlock);
+    hipStream_t s = fdd_stream(stream);
+    if (plan->unit_values)
+    {
+        if (weight)
+            hipLaunchKernelGGL((csr_block_kernel<EpiWeight, true>), grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev);
+        else
+            hipLaunchKernelGGL((csr_block_kernel<EpiPlain, true>), grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev);
+    }
     else
-        hipLaunchKernelGGL(csr_block_kernel<EpiPlain>, dim3(plan->num_blocks), dim3(kBlock), 0, fdd_stream(stream), Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev);
+    {
+        if (weight)
+            hipLaunchKernelGGL((csr_block_kernel<EpiWeight, false>), grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev);
+        else
+            hipLaunchKernelGGL((csr_block_kernel<EpiPlain, false>), grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev);
+    }
     FDD_LAUNCH_CHECK();
     return 0;
 }

@@ -6,9 +6,15 @@
 //     out = (Q t) .* point_mask
 // i.e. (12 nnz + 12 rows + 8 cols) bytes twice, 66-74 B per GLL point.  Q is the
 // transpose of Qt with a single 1.0 per row, so the scatter needs no second
-// matrix: one lane per assembled node sums its points (gather) and writes the
+// matrix: a lane sums the points of an assembled node (gather) and writes the
 // sum back to the same points (scatter).  4 B/node of ptr, 4 B/point of col,
 // 8 B/point in, 8 B/point out (+ 8 B/point mask, 8 B/node weight): ~36 B/point.
+//
+// Latency, not bandwidth, is what has to be engineered here: a node is three
+// dependent round trips (ptr -> col -> u).  Each lane therefore owns kNpt
+// nodes and keeps kNpt*kCh column loads, then kNpt*kCh gathers, in flight
+// (fdd_multi_row_sum); workgroups walk the node range in XCD-chunked order so
+// the partner points of interface nodes are served by one L2.
 //
 // Arithmetic is the reference's, operation for operation, so the result is
 // bit-identical to the two SpMVs: the node sum starts from 0.0 and adds
@@ -22,62 +28,84 @@
 // fused kernel does both for the rank-interior nodes.
 #include "fdd_common.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace
 {
 constexpr int kBlock = 256;
-
 // MODE 0: gather + scatter, 1: gather only (t out), 2: scatter only (t in)
-template <int MODE, bool WEIGHT, bool MASK>
+// kNpt nodes per lane, kCh entries of a node per round
+template <int MODE, bool WEIGHT, bool MASK, int kNpt, int kCh>
 __global__ __launch_bounds__(kBlock) void dssum_kernel(double *out, double *__restrict__ t, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const double *u, const double *__restrict__ node_weight, const double *__restrict__ point_mask, int node_start, int node_end)
 {
-    // one node per lane, workgroups in XCD-chunked order (fdd_common.h)
-    const int node = node_start + fdd_xcd_chunked_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
-    if (node < node_end)
+    const int tile = fdd_xcd_chunked_block(blockIdx.x, gridDim.x) * (kBlock * kNpt);
+
+    int node[kNpt], j0[kNpt], j1[kNpt];
+    double w[kNpt], s[kNpt];
+#pragma unroll
+    for (int r = 0; r < kNpt; r++)
     {
-        const int j0 = Qt_ptr[node];
-        const int j1 = Qt_ptr[node + 1];
+        node[r] = node_start + tile + r * kBlock + threadIdx.x;
+        const bool on = node[r] < node_end;
+        j0[r] = on ? Qt_ptr[node[r]] : 0;
+        j1[r] = on ? Qt_ptr[node[r] + 1] : 0;
+        if (MODE != 2 && WEIGHT) w[r] = on ? node_weight[node[r]] : 0.0;
+        if (MODE == 2) s[r] = on ? t[node[r]] : 0.0;
+    }
 
-        double s;
-        if (MODE != 2)
+    if (MODE != 2)
+    {
+        fdd_multi_row_sum<kNpt, kCh, true>(Qt_col, nullptr, u, j0, j1, s);
+#pragma unroll
+        for (int r = 0; r < kNpt; r++)
         {
-            s = fdd_row_sum<true>(Qt_col, nullptr, u, j0, j1); // all loads of the row in flight at once
-            if (WEIGHT) s = s * node_weight[node];
-            if (t) t[node] = s;
+            if (WEIGHT) s[r] = s[r] * w[r];
+            if (t && node[r] < node_end) t[node[r]] = s[r];
         }
-        else
-        {
-            s = t[node];
-        }
+    }
 
-        if (MODE != 1)
+    if (MODE != 1)
+    {
+        int len_max = 0;
+#pragma unroll
+        for (int r = 0; r < kNpt; r++) len_max = (j1[r] - j0[r] > len_max) ? j1[r] - j0[r] : len_max;
+
+        for (int off = 0; off < len_max; off += kCh)
         {
-            const double v = 0.0 + 1.0 * s;
-            for (int jb = j0; jb < j1; jb += FDD_ROW_CHUNK)
+            int p[kNpt][kCh];
+            double mk[kNpt][kCh];
+#pragma unroll
+            for (int r = 0; r < kNpt; r++)
+#pragma unroll
+                for (int k = 0; k < kCh; k++) p[r][k] = (j0[r] + off + k < j1[r]) ? Qt_col[j0[r] + off + k] : 0;
+            if (MASK)
             {
-                int p[FDD_ROW_CHUNK];
-                double mk[FDD_ROW_CHUNK];
 #pragma unroll
-                for (int k = 0; k < FDD_ROW_CHUNK; k++) p[k] = (jb + k < j1) ? Qt_col[jb + k] : 0;
-                if (MASK)
-                {
+                for (int r = 0; r < kNpt; r++)
 #pragma unroll
-                    for (int k = 0; k < FDD_ROW_CHUNK; k++) mk[k] = (jb + k < j1) ? point_mask[p[k]] : 0.0;
-                }
+                    for (int k = 0; k < kCh; k++) mk[r][k] = (j0[r] + off + k < j1[r]) ? point_mask[p[r][k]] : 0.0;
+            }
 #pragma unroll
-                for (int k = 0; k < FDD_ROW_CHUNK; k++)
-                    if (jb + k < j1) out[p[k]] = MASK ? v * mk[k] : v;
+            for (int r = 0; r < kNpt; r++)
+            {
+                const double v = 0.0 + 1.0 * s[r];
+#pragma unroll
+                for (int k = 0; k < kCh; k++)
+                    if (j0[r] + off + k < j1[r]) out[p[r][k]] = MASK ? v * mk[r][k] : v;
             }
         }
     }
 }
 
-template <int MODE>
-int launch(double *out, double *t, const int *Qt_ptr, const int *Qt_col, const double *u, const double *w, const double *m, int n0, int n1, void *stream)
+template <int MODE, int kNpt, int kCh>
+int launch_variant(double *out, double *t, const int *Qt_ptr, const int *Qt_col, const double *u, const double *w, const double *m, int n0, int n1, void *stream)
 {
     if (n1 <= n0) return 0;
-    const int grid = (int)(((long long)n1 - n0 + kBlock - 1) / kBlock);
+    const int per_block = kBlock * kNpt;
+    const int grid = (int)(((long long)n1 - n0 + per_block - 1) / per_block);
     hipStream_t s = fdd_stream(stream);
-#define FDD_DSSUM_LAUNCH(W, M) hipLaunchKernelGGL((dssum_kernel<MODE, W, M>), dim3(grid), dim3(kBlock), 0, s, out, t, Qt_ptr, Qt_col, u, w, m, n0, n1)
+#define FDD_DSSUM_LAUNCH(W, M) hipLaunchKernelGGL((dssum_kernel<MODE, W, M, kNpt, kCh>), dim3(grid), dim3(kBlock), 0, s, out, t, Qt_ptr, Qt_col, u, w, m, n0, n1)
     if (w && m)
         FDD_DSSUM_LAUNCH(true, true);
     else if (w)
@@ -89,6 +117,41 @@ int launch(double *out, double *t, const int *Qt_ptr, const int *Qt_col, const d
 #undef FDD_DSSUM_LAUNCH
     FDD_LAUNCH_CHECK();
     return 0;
+}
+
+// Tuning knob (development): FDD_TUNE_DSSUM=<nodes per lane>x<entries per round>
+inline int dssum_variant()
+{
+    static int v = -1;
+    if (v < 0)
+    {
+        const char *e = getenv("FDD_TUNE_DSSUM");
+        v = 0;
+        if (e)
+        {
+            if (!strcmp(e, "1x8")) v = 1;
+            else if (!strcmp(e, "2x8")) v = 2;
+            else if (!strcmp(e, "4x4")) v = 3;
+            else if (!strcmp(e, "2x4")) v = 4;
+            else if (!strcmp(e, "4x8")) v = 5;
+            else if (!strcmp(e, "1x4")) v = 6;
+        }
+    }
+    return v;
+}
+
+template <int MODE>
+int launch(double *out, double *t, const int *Qt_ptr, const int *Qt_col, const double *u, const double *w, const double *m, int n0, int n1, void *stream)
+{
+    switch (dssum_variant())
+    {
+    case 1: return launch_variant<MODE, 1, 8>(out, t, Qt_ptr, Qt_col, u, w, m, n0, n1, stream);
+    case 3: return launch_variant<MODE, 4, 4>(out, t, Qt_ptr, Qt_col, u, w, m, n0, n1, stream);
+    case 4: return launch_variant<MODE, 2, 4>(out, t, Qt_ptr, Qt_col, u, w, m, n0, n1, stream);
+    case 5: return launch_variant<MODE, 4, 8>(out, t, Qt_ptr, Qt_col, u, w, m, n0, n1, stream);
+    case 6: return launch_variant<MODE, 1, 4>(out, t, Qt_ptr, Qt_col, u, w, m, n0, n1, stream);
+    default: return launch_variant<MODE, 2, 8>(out, t, Qt_ptr, Qt_col, u, w, m, n0, n1, stream);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void fill_indexed_kernel(double *__restrict__ out, const int *__restrict__ idx, double value, int n)

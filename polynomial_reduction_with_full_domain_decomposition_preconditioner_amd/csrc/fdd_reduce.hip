@@ -288,14 +288,28 @@ __global__ __launch_bounds__(kBlock) void gather_norm2_kernel(double *ws, const 
 {
     Acc<1> a;
     a.v[0] = 0.0;
-    const int stride = gridDim.x * kBlock;
-    for (int node = blockIdx.x * kBlock + threadIdx.x; node < n; node += stride)
+    constexpr int NPT = 4;
+    const int stride = gridDim.x * kBlock * NPT;
+    for (int tile = blockIdx.x * kBlock * NPT; tile < n; tile += stride)
     {
-        const int j0 = Qt_ptr[node], j1 = Qt_ptr[node + 1];
-        double s = fdd_row_sum<true>(Qt_col, nullptr, u, j0, j1);
-        const double wn = w[node];
-        s = s * wn;
-        a.v[0] += s * s * wn;
+        int j0[NPT], j1[NPT];
+        double wn[NPT], s[NPT];
+#pragma unroll
+        for (int r = 0; r < NPT; r++)
+        {
+            const int node = tile + r * kBlock + threadIdx.x;
+            const bool on = node < n;
+            j0[r] = on ? Qt_ptr[node] : 0;
+            j1[r] = on ? Qt_ptr[node + 1] : 0;
+            wn[r] = on ? w[node] : 0.0;
+        }
+        fdd_multi_row_sum<NPT, 4, true>(Qt_col, nullptr, u, j0, j1, s);
+#pragma unroll
+        for (int r = 0; r < NPT; r++)
+        {
+            const double sw = s[r] * wn[r];
+            a.v[0] += sw * sw * wn[r];
+        }
     }
     block_reduce_store<1>(a, ws, FDD_REDUCE_MAX_BLOCKS);
 }
@@ -393,7 +407,7 @@ int fdd_gather_weighted_norm2(double *out, double *ws, const int *Qt_ptr, const 
     hipStream_t s = fdd_stream(stream);
     if (num_nodes == 0) return (int)hipMemsetAsync(out, 0, sizeof(double), s);
     FDD_REQUIRE(Qt_ptr != nullptr && Qt_col != nullptr && u != nullptr && node_weight != nullptr);
-    const int grid = fdd_stream_grid(num_nodes, kBlock);
+    const int grid = fdd_stream_grid((num_nodes + 3) / 4, kBlock); // 4 nodes per lane per pass
     hipLaunchKernelGGL(gather_norm2_kernel, dim3(grid), dim3(kBlock), 0, s, ws, Qt_ptr, Qt_col, u, node_weight, num_nodes);
     FDD_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_final_kernel<1>, dim3(1), dim3(kBlock), 0, s, out, ws, grid);

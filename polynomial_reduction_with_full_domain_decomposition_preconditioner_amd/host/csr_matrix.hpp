@@ -147,6 +147,7 @@ class CSR_Matrix
         if (plan) FDD_CALL(fdd_csr_plan_destroy(plan));
         FDD_CALL(fdd_csr_plan_create(&plan, ptr_hst.data(), num_rows, num_cols, num_nnz));
         FDD_CALL(fdd_csr_plan_kind(plan, &plan_kind));
+        FDD_CALL(fdd_csr_plan_set_unit_values(plan, unit_values ? 1 : 0));
 
         entries.clear();
         entries.shrink_to_fit();
@@ -193,6 +194,28 @@ class CSR_Matrix
                     break;
                 }
         D.copyFrom(work.data(), num_rows * sizeof(DType));
+    }
+
+    // --- boolean gather matrices only (unit_values): fused forms on the SpMV plan ---
+    // out = Q (w .* (Qt u)) .* m with Q = (this)^T: one gather-scatter pass (fdd_hip.h);
+    // mode 0 gather + scatter, 1 gather only (t out), 2 scatter only (t in); rows [row_lo, row_hi)
+    void gather_scatter(double *out, double *t, const double *u, const double *node_weight, const double *point_mask, int row_lo, int row_hi, int mode)
+    {
+        if (row_hi <= row_lo or num_nnz == 0) return;
+        const double rows = row_hi - row_lo, frac = rows / std::max(num_rows, 1);
+        const double bytes = 4.0 * rows + frac * num_nnz * (4.0 + (mode != 2 ? 8.0 : 0.0) + (mode != 1 ? 8.0 : 0.0) + ((point_mask and mode != 1) ? 8.0 : 0.0)) +
+                             ((node_weight and mode != 2) ? 8.0 * rows : 0.0) + ((t or mode != 0) ? 8.0 * rows : 0.0);
+        const char *key = (plan_kind == 0) ? (mode == 0 ? "dssum_kernel<fused>" : mode == 1 ? "dssum_kernel<gather>" : "dssum_kernel<scatter>")
+                                           : (mode == 0 ? "dssum_block_kernel<fused>" : mode == 1 ? "dssum_block_kernel<gather>" : "dssum_block_kernel<scatter>");
+        fdd::ProfileScope prof(key, bytes);
+        FDD_CALL(fdd_csr_plan_dssum(plan, out, t, ptr.as<int>(), col.as<int>(), u, node_weight, point_mask, row_lo, row_hi, mode, fdd::dev().stream));
+    }
+
+    // out_dev[0] = sum_rows s*s*w with s = (this u)[row]*w[row]
+    void gather_weighted_norm2(double *out_dev, double *ws, const double *u, const double *node_weight)
+    {
+        fdd::ProfileScope prof(plan_kind == 0 ? "gather_norm2_kernel" : "gather_norm2_block_kernel", 4.0 * num_rows + 12.0 * num_nnz + 8.0 * num_rows);
+        FDD_CALL(fdd_csr_plan_gather_weighted_norm2(plan, out_dev, ws, ptr.as<int>(), col.as<int>(), u, node_weight, fdd::dev().stream));
     }
 
     void multiply(fdd::memory &Au, fdd::memory &u)

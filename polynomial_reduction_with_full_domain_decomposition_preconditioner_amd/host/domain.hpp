@@ -514,16 +514,11 @@ class Domain
             const int nb = (fdd::comm().size > 1 and num_interface_slots > 0) ? num_bdary_nodes : 0;
             if (nb > 0)
             {
-                FDD_CALL(fdd_dssum_gather(work_dev[0].as<double>(), Qt.ptr.template as<int>(), Qt.col.template as<int>(), u.as<double>(), w, 0, nb, fdd::dev().stream));
+                Qt.gather_scatter(nullptr, work_dev[0].as<double>(), u.as<double>(), w, nullptr, 0, nb, 1);
                 gs_add_boundary(work_dev[0]);
             }
-            {
-                // ptr 4 B/node, col 4 B/pt, u in 8 B/pt, out 8 B/pt, + mask 8 B/pt, + weight 8 B/node
-                const double bytes = 4.0 * (num_local_nodes - nb) + 20.0 * num_local_points + (m ? 8.0 * num_local_points : 0.0) + (w ? 8.0 * (num_local_nodes - nb) : 0.0);
-                fdd::ProfileScope prof("dssum_kernel<fused>", bytes);
-                FDD_CALL(fdd_dssum_fused(QQtu.as<double>(), nullptr, Qt.ptr.template as<int>(), Qt.col.template as<int>(), u.as<double>(), w, m, nb, num_local_nodes, fdd::dev().stream));
-            }
-            if (nb > 0) FDD_CALL(fdd_dssum_scatter(QQtu.as<double>(), work_dev[0].as<double>(), Qt.ptr.template as<int>(), Qt.col.template as<int>(), m, 0, nb, fdd::dev().stream));
+            Qt.gather_scatter(QQtu.as<double>(), nullptr, u.as<double>(), w, m, nb, num_local_nodes, 0);
+            if (nb > 0) Qt.gather_scatter(QQtu.as<double>(), work_dev[0].as<double>(), nullptr, nullptr, m, 0, nb, 2);
             return;
         }
 

@@ -522,9 +522,7 @@ class Subdomain
         {
             // Q * I * Qt in one gather-scatter pass over the dofs; points without
             // a dof (Dirichlet: empty rows of Q) get the 0.0 the SpMV writes.
-            const double bytes = 4.0 * subdomain_operator.num_extended_dofs + 20.0 * subdomain_operator.num_points;
-            fdd::ProfileScope prof("dssum_kernel<fused>", bytes);
-            FDD_CALL(fdd_dssum_fused(QQtu.as<double>(), nullptr, subdomain_operator.Qt.ptr.template as<int>(), subdomain_operator.Qt.col.template as<int>(), u.as<double>(), nullptr, nullptr, 0, subdomain_operator.num_extended_dofs, fdd::dev().stream));
+            subdomain_operator.Qt.gather_scatter(QQtu.as<double>(), nullptr, u.as<double>(), nullptr, nullptr, 0, subdomain_operator.num_extended_dofs, 0);
             FDD_CALL(fdd_fill_indexed(QQtu.as<double>(), points_without_dof.template as<int>(), 0.0, num_points_without_dof, fdd::dev().stream));
             return;
         }
@@ -689,18 +687,12 @@ class Subdomain
 
     void gather_weighted(fdd::memory &t, fdd::memory &v)
     {
-        const int nd = subdomain_operator.num_extended_dofs;
-        fdd::ProfileScope prof("dssum_kernel<gather>", 4.0 * nd + 12.0 * subdomain_operator.Qt.num_nnz + 16.0 * nd);
-        FDD_CALL(fdd_dssum_gather(t.as<double>(), subdomain_operator.Qt.ptr.template as<int>(), subdomain_operator.Qt.col.template as<int>(), v.as<double>(), norm_weight.as<double>(), 0, nd, fdd::dev().stream));
+        subdomain_operator.Qt.gather_scatter(nullptr, t.as<double>(), v.as<double>(), norm_weight.as<double>(), nullptr, 0, subdomain_operator.num_extended_dofs, 1);
     }
 
     void gather_norm(DType &r_norm, fdd::memory &r)
     {
-        const int nd = subdomain_operator.num_extended_dofs;
-        {
-            fdd::ProfileScope prof("gather_norm2_kernel", 4.0 * nd + 12.0 * subdomain_operator.Qt.num_nnz + 8.0 * nd);
-            FDD_CALL(fdd_gather_weighted_norm2(scalars.as<double>(), reduce_ws.as<double>(), subdomain_operator.Qt.ptr.template as<int>(), subdomain_operator.Qt.col.template as<int>(), r.as<double>(), norm_weight.as<double>(), nd, fdd::dev().stream));
-        }
+        subdomain_operator.Qt.gather_weighted_norm2(scalars.as<double>(), reduce_ws.as<double>(), r.as<double>(), norm_weight.as<double>());
         fetch_scalars(&r_norm, 1);
         r_norm = std::sqrt(r_norm);
     }

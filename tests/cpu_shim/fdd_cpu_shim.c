@@ -72,6 +72,7 @@ int fdd_csr_plan_create(fdd_csr_plan **plan, const int *ptr, int rows, int cols,
 int fdd_csr_plan_destroy(fdd_csr_plan *plan) { free(plan); return 0; }
 int fdd_csr_plan_num_blocks(const fdd_csr_plan *plan, int *nb) { (void)plan; *nb = 0; return 0; }
 int fdd_csr_plan_kind(const fdd_csr_plan *plan, int *kind) { (void)plan; *kind = 0; return 0; }
+int fdd_csr_plan_set_unit_values(fdd_csr_plan *plan, int unit) { (void)plan; (void)unit; return 0; }
 int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *p, const int *c, const double *v, const double *u, const double *w, void *s)
 {
     (void)s;
@@ -261,6 +262,18 @@ int fdd_dssum_fused(double *out, double *t, const int *p, const int *c, const do
 int fdd_dssum_gather(double *t, const int *p, const int *c, const double *u, const double *w, int n0, int n1, void *s) { (void)s; gather_range(t, p, c, u, w, n0, n1); return 0; }
 int fdd_dssum_scatter(double *out, const double *t, const int *p, const int *c, const double *m, int n0, int n1, void *s) { (void)s; scatter_range(out, t, p, c, m, n0, n1); return 0; }
 int fdd_fill_indexed(double *out, const int *idx, double v, int n, void *s) { (void)s; for (int i = 0; i < n; i++) out[idx[i]] = v; return 0; }
+
+int fdd_csr_plan_dssum(const fdd_csr_plan *plan, double *out, double *t, const int *p, const int *c, const double *u, const double *w, const double *m, int r0, int r1, int mode, void *s)
+{
+    (void)plan;
+    if (mode == 0) return fdd_dssum_fused(out, t, p, c, u, w, m, r0, r1, s);
+    if (mode == 1) return fdd_dssum_gather(t, p, c, u, w, r0, r1, s);
+    return fdd_dssum_scatter(out, t, p, c, m, r0, r1, s);
+}
+int fdd_csr_plan_gather_weighted_norm2(const fdd_csr_plan *plan, double *out, double *ws, const int *p, const int *c, const double *u, const double *w, void *s)
+{
+    return fdd_gather_weighted_norm2(out, ws, p, c, u, w, plan->num_rows, s);
+}
 
 /* ---- interface exchange ---- */
 int fdd_interface_pack(double *slots, const int *slot_of, const double *prefix, int n, void *s) { (void)s; for (int i = 0; i < n; i++) slots[slot_of[i]] = prefix[i]; return 0; }

@@ -347,6 +347,14 @@ def run_csr_case(gpu, ptr, col, val, ncols, expect_kind=None, exact=True):
         same(host(out), ref)
         k("fdd_csr_plan_multiply", plan, out, dptr, dcol, dval, du, dw)
         same(host(out), refw)
+        if len(val) and np.all(val == 1.0):
+            # boolean matrix: the plan may skip the val array, same bits
+            lib.hip().call("fdd_csr_plan_set_unit_values", plan, 1)
+            out.fill_(7.0)
+            k("fdd_csr_plan_multiply", plan, out, dptr, dcol, None, du, None)
+            same(host(out), ref)
+            k("fdd_csr_plan_multiply", plan, out, dptr, dcol, None, du, dw)
+            same(host(out), refw)
     finally:
         lib.hip().call("fdd_csr_plan_destroy", plan)
 
@@ -367,7 +375,7 @@ def test_csr_boolean_gather_scatter(gpu):
         run_csr_case(gpu, ptr, col, val, W.num_nodes(0), expect_kind=0)
         ptr, col, val = W.Qt(0)
         assert np.diff(ptr).max() == 8
-        run_csr_case(gpu, ptr, col, val, m.num_local_points, expect_kind=0)
+        run_csr_case(gpu, ptr, col, val, m.num_local_points, expect_kind=1)  # ragged rows: LDS row staging
     finally:
         W.close()
 
@@ -658,6 +666,36 @@ def test_dssum_fused_equals_two_spmvs(gpu, weighted, masked):
     k("fdd_dssum_fused", inplace, None, dptr, dcol, inplace, dw, dm, nb, nodes)
     k("fdd_dssum_scatter", inplace, dt, dptr, dcol, dm, 0, nb)
     assert np.array_equal(host(inplace), ref)
+
+    # the same on the row blocks of Qt's SpMV plan (LDS-staged, balanced)
+    plan = vp()
+    lib.hip().call("fdd_csr_plan_create", ctypes.byref(plan), P(tptr), nodes, points, points)
+    lib.hip().call("fdd_csr_plan_set_unit_values", plan, 1)
+    try:
+        kind = ctypes.c_int(-1)
+        lib.hip().call("fdd_csr_plan_kind", plan, ctypes.byref(kind))
+        assert kind.value == 1
+        out.fill_(9.0)
+        dt.zero_()
+        k("fdd_csr_plan_dssum", plan, out, dt, dptr, dcol, du, dw, dm, 0, nodes, 0)
+        assert np.array_equal(host(out), ref) and np.array_equal(host(dt), t)
+        for nb2 in (1234, 2048 * 3, 1):  # prefix boundaries inside and on row-block edges
+            inplace = dev(u, gpu)
+            dt.zero_()
+            k("fdd_csr_plan_dssum", plan, None, dt, dptr, dcol, inplace, dw, None, 0, nb2, 1)
+            assert np.array_equal(host(dt)[:nb2], t[:nb2]) and not host(dt)[nb2:].any()
+            k("fdd_csr_plan_dssum", plan, inplace, None, dptr, dcol, inplace, dw, dm, nb2, nodes, 0)
+            k("fdd_csr_plan_dssum", plan, inplace, dt, dptr, dcol, None, None, dm, 0, nb2, 2)
+            assert np.array_equal(host(inplace), ref)
+        if weighted:
+            ws = reduce_workspace(gpu)
+            o1 = torch.zeros(1, dtype=torch.float64, device=gpu)
+            o2 = torch.zeros(1, dtype=torch.float64, device=gpu)
+            k("fdd_gather_weighted_norm2", o1, ws, dptr, dcol, du, dw, nodes)
+            k("fdd_csr_plan_gather_weighted_norm2", plan, o2, ws, dptr, dcol, du, dw)
+            assert abs(host(o1)[0] - host(o2)[0]) <= 1e-13 * abs(host(o1)[0])
+    finally:
+        lib.hip().call("fdd_csr_plan_destroy", plan)
 
 
 def test_dssum_fused_with_points_without_dof(gpu):

@@ -98,10 +98,12 @@ def stencil27(m, dev):
     return ptr, col, val
 
 
-def make_plan(ptr_dev, rows, cols, nnz):
+def make_plan(ptr_dev, rows, cols, nnz, unit_values=False):
     ptr_h = ptr_dev.cpu().numpy()
     plan = ctypes.c_void_p()
     lib.hip().call("fdd_csr_plan_create", ctypes.byref(plan), ctypes.c_void_p(ptr_h.ctypes.data), rows, cols, nnz)
+    if unit_values:
+        lib.hip().call("fdd_csr_plan_set_unit_values", plan, 1)
     return plan
 
 
@@ -165,6 +167,11 @@ def main():
         bytes_Qt = 12 * Pq + 12 * nodes + 8 * Pq
         planQ = make_plan(qp, Pq, nodes, Pq)
         planQt = make_plan(tp, nodes, Pq, Pq)
+        planQu = make_plan(qp, Pq, nodes, Pq, unit_values=True)
+        planQtu = make_plan(tp, nodes, Pq, Pq, unit_values=True)
+        report("csr.Q multiply, unit-value plan", bytes_Q, timeit(lambda: k("fdd_csr_plan_multiply", planQu, y_pts, qp, qc, qv, x_nodes, None)), results)
+        report("csr.Q multiply_weight, unit-value plan", bytes_Q + 8 * Pq, timeit(lambda: k("fdd_csr_plan_multiply", planQu, y_pts, qp, qc, qv, x_nodes, a)), results)
+        report("csr.Qt multiply, unit-value plan", bytes_Qt, timeit(lambda: k("fdd_csr_plan_multiply", planQtu, x_nodes, tp, tc, tv, y_pts, None)), results)
         report("csr.Q multiply (scatter, 1 nnz/row)", bytes_Q, timeit(lambda: k("fdd_csr_plan_multiply", planQ, y_pts, qp, qc, qv, x_nodes, None)), results)
         report("csr.Q multiply_weight", bytes_Q + 8 * Pq, timeit(lambda: k("fdd_csr_plan_multiply", planQ, y_pts, qp, qc, qv, x_nodes, a)), results)
         report("csr.Qt multiply (gather, 1-8 nnz/row)", bytes_Qt, timeit(lambda: k("fdd_csr_plan_multiply", planQt, x_nodes, tp, tc, tv, y_pts, None)), results)
@@ -176,6 +183,11 @@ def main():
         report("dssum.fused in place (weight+mask)", b_ds + 8.0 * Pq + 8.0 * nodes, timeit(lambda: k("fdd_dssum_fused", b, None, tp, tc, b, wn, a, 0, nodes)), results)
         report("dssum.gather (weight)", 4.0 * nodes + 12.0 * Pq + 16.0 * nodes, timeit(lambda: k("fdd_dssum_gather", x_nodes, tp, tc, b, wn, 0, nodes)), results)
         report("dssum.gather_weighted_norm2", 4.0 * nodes + 12.0 * Pq + 8.0 * nodes, timeit(lambda: k("fdd_gather_weighted_norm2", out, ws, tp, tc, b, wn, nodes)), results)
+        report("dssum[plan].fused (plain)", b_ds, timeit(lambda: k("fdd_csr_plan_dssum", planQtu, y_pts, None, tp, tc, b, None, None, 0, nodes, 0)), results)
+        report("dssum[plan].fused (weight+mask)", b_ds + 8.0 * Pq + 8.0 * nodes, timeit(lambda: k("fdd_csr_plan_dssum", planQtu, y_pts, None, tp, tc, b, wn, a, 0, nodes, 0)), results)
+        report("dssum[plan].fused in place (weight+mask)", b_ds + 8.0 * Pq + 8.0 * nodes, timeit(lambda: k("fdd_csr_plan_dssum", planQtu, b, None, tp, tc, b, wn, a, 0, nodes, 0)), results)
+        report("dssum[plan].gather (weight)", 4.0 * nodes + 12.0 * Pq + 16.0 * nodes, timeit(lambda: k("fdd_csr_plan_dssum", planQtu, None, x_nodes, tp, tc, b, wn, None, 0, nodes, 1)), results)
+        report("dssum[plan].gather_weighted_norm2", 4.0 * nodes + 12.0 * Pq + 8.0 * nodes, timeit(lambda: k("fdd_csr_plan_gather_weighted_norm2", planQtu, out, ws, tp, tc, b, wn)), results)
         del qp, qc, qv, tp, tc, tv
         m = 97 if args.quick else args.stencil
         sp, sc, sv = stencil27(m, dev)
