@@ -116,6 +116,13 @@ int fdd_dom_stiffness_matrix_2(double *Au, const double *const GDu[3], const dou
  * launches in Domain::stiffness_matrix (domain.tpp:602-607). */
 int fdd_dom_stiffness_matrix(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], int num_elements, int poly_degree, void *stream);
 
+/* The same fused operator on the fp64 matrix cores (v_mfma_f64_16x16x4_f64) for poly_degree 8..15:
+ * the six contractions of an element are 16x16x16 products on LDS-staged views, one persistent
+ * 1024-lane workgroup per CU, next element prefetched.  MFMA fuses multiply-add, so this entry is
+ * NOT bit-identical to the reference arithmetic (agrees to ~1e-15 * max|Au|).  elem_offset as in
+ * fdd_sub_stiffness_matrix (NULL => contiguous elements).  Au must not alias u. */
+int fdd_stiffness_matrix_mfma(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
+
 int fdd_dom_initialize_arrays(double *u_k, double *r_k, const double *f, int num_points, void *stream); /* domain.okl:100-107, domain.tpp:618,734 */
 
 /* Reductions.  The reference kernels write one partial per 128-thread block

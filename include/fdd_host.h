@@ -96,7 +96,9 @@ int fddh_problem_set_options(fddh_problem *p, int max_iterations, double toleran
  * launch sequences stay available for comparison):
  *   "fused_dssum"              1: one gather-scatter kernel per dssum (default), 0: the Qt / Q SpMV pair
  *   "restructured_inner_solve" 1: inner GMRES with cached assembled vectors, multi-dot / multi-axpy (default),
- *                              0: the reference's launch-by-launch sequence (subdomain.tpp:4309-4489) */
+ *                              0: the reference's launch-by-launch sequence (subdomain.tpp:4309-4489)
+ *   "mfma_stiffness"           1: degrees 11..15 apply the stiffness on the fp64 matrix cores (default;
+ *                              agrees with the bit-exact kernel to ~1e-15, not bit for bit), 0: scalar fused kernel */
 int fddh_problem_set_flag(fddh_problem *p, const char *name, int value);
 
 /* Domain operations on host vectors of num_local_points */

@@ -1,0 +1,261 @@
+// High-order (N = 8..15) SEM stiffness Au = D^T G D u on the fp64 matrix cores
+// of gfx950 (v_mfma_f64_16x16x4_f64).  Same operator as fdd_stiffness.hip's
+// fused kernel (domain.okl:5-98 / subdomain.okl:4-101, both passes, 64 B/point
+// of HBM traffic), for the degrees where the scalar kernel is LDS-bound
+// (n = N+1 = 16: 128 LDS reads per point, 2.5 TB/s).
+//
+// The six 1-D contractions of an element are 16x16x16 matrix products
+//     Y = Dm * X,   X = a 16x16 view of the element's 16^3 tensor in LDS whose
+//                       ROW index is the contracted direction,
+// i.e. 4 MFMAs each, 384 per element (6.1k cycles per CU, against ~32k cycles of
+// HBM time per element per CU: the kernel stays HBM-bound).  Degrees below 15
+// are zero-padded to 16 (the extra products are exact zeros).
+//
+// One persistent 1024-lane workgroup per CU (16 wavefronts, wave w owns xy-slab
+// k = w and xz-slab j = w), four padded 16^3 arrays in LDS (136 KiB):
+//   P0  u(element)            -> sU                       (registers prefetched one element ahead)
+//   P1  Du_x, Du_y (slab k=w), Du_z (slab j=w) = D * views(sU)      -> sA1, sA2, sA3
+//   P2  point-wise G mixing, in place on sA1..3            (G prefetched one element ahead)
+//   P3a Au_x + Au_y (slab k=w) = D^T * views(sA1, sA2)    -> sU
+//   P3b Au_z (slab j=w)       = D^T * view(sA3)           += sU
+//   P4  sU                     -> Au(element)
+// Global loads of element e+1 are issued while element e computes.
+//
+// Numerics: MFMA fuses multiply-add and sums each 16-term contraction in its
+// own order, so this kernel is NOT bit-identical to the reference arithmetic;
+// it agrees to ~1e-15 * max|Au| (tolerance 1e-12 in tests/).  The top-level
+// order (Au_x + Au_y) + Au_z and the G mixing expressions are the reference's.
+#include "fdd_common.h"
+
+namespace
+{
+
+constexpr int kThreads = 1024;
+constexpr int LD = 17;        // padded row of 16
+constexpr int PL = 16 * LD;   // plane stride
+constexpr int ARR = 16 * PL;  // doubles per padded 16^3 array
+constexpr int kPts = 4;       // padded points per lane (4096 / 1024)
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+struct GPtrs
+{
+    const double *g[FDD_NUM_GEOM_FACTS];
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+// the vector-memory counter, i.e. it would wait for the global loads prefetched
+// for the NEXT element and for the stores of the previous one at every phase
+// boundary; the phases here exchange data through LDS alone.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Y = Dm * X for the view X[row][col] = src[base + row*rs + col*cs];
+// a[s] = Dm[lane&15][4s + (lane>>4)] (A-operand fragments of the constant matrix).
+__device__ __forceinline__ v4f64 tile_product(const double *src, int base, int rs, int cs, const double (&a)[4], int lane)
+{
+    const int kk = lane >> 4, c = lane & 15;
+    double b[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) b[s] = src[base + (4 * s + kk) * rs + c * cs];
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// C/D layout of v_mfma_f64_16x16x4_f64: register r of lane l is Y[(l>>4) + 4r][l&15]
+__device__ __forceinline__ void tile_store(double *dst, int base, int rs, int cs, v4f64 y, int lane)
+{
+    const int kk = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++) dst[base + (kk + 4 * r) * rs + c * cs] = y[r];
+}
+
+__device__ __forceinline__ void tile_add(double *dst, int base, int rs, int cs, v4f64 y, int lane)
+{
+    const int kk = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int a = base + (kk + 4 * r) * rs + c * cs;
+        dst[a] = dst[a] + y[r];
+    }
+}
+
+template <int n>
+__global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *sU = smem;
+    double *sA1 = sU + ARR;
+    double *sA2 = sA1 + ARR;
+    double *sA3 = sA2 + ARR;
+
+    constexpr int n2 = n * n, n3 = n2 * n;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    // A-operand fragments of D (pass 1) and D^T (pass 2), zero-padded to 16x16
+    double a_D[4], a_Dt[4];
+    {
+        const int row = lane & 15, kk = lane >> 4;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+        {
+            const int p = 4 * s + kk;
+            const bool in = (row < n) && (p < n);
+            a_D[s] = in ? D_hat[p + row * n] : 0.0;   // D[row][p]   = D_hat[p + row*n_x] (domain.okl:42)
+            a_Dt[s] = in ? D_hat[row + p * n] : 0.0;  // D^T[row][p] = D_hat[row + p*n_x] (domain.okl:90)
+        }
+    }
+
+    // padded point q = tid + 1024 m  <->  (i, j, k = k0 + 4m): i, j are the
+    // lane's own, so every index below is a lane constant plus m times a literal
+    const int pi = tid & 15, pj = (tid >> 4) & 15, k0 = tid >> 8;
+    const int l0 = pi + pj * LD + k0 * PL;
+    const int g0 = pi + pj * n + k0 * n2;
+    const bool vij = (pi < n) && (pj < n);
+#define lidx(m) (l0 + 4 * (m)*PL)
+#define goff(m) (g0 + 4 * (m)*n2)
+#define valid(m) (vij && (k0 + 4 * (m) < n))
+
+    auto elem_base = [&](int e) -> size_t { return elem_offset ? (size_t)elem_offset[e] : (size_t)e * n3; };
+
+    double ru[kPts], rg[FDD_NUM_GEOM_FACTS][kPts];
+    int e = blockIdx.x;
+    if (e < num_elements)
+    {
+        const size_t base = elem_base(e);
+#pragma unroll
+        for (int m = 0; m < kPts; m++)
+        {
+            ru[m] = valid(m) ? u[base + goff(m)] : 0.0;
+#pragma unroll
+            for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? G.g[g][base + goff(m)] : 0.0;
+        }
+    }
+
+    for (; e < num_elements; e += gridDim.x)
+    {
+        const size_t base = elem_base(e);
+        const int en = e + gridDim.x;
+        const bool more = en < num_elements;
+        const size_t base_n = more ? elem_base(en) : 0;
+
+        // P0: element -> LDS (each lane rewrites the slots it read in P4: no barrier needed before)
+#pragma unroll
+        for (int m = 0; m < kPts; m++) sU[lidx(m)] = ru[m];
+        lds_barrier();
+        if (more)
+        {
+#pragma unroll
+            for (int m = 0; m < kPts; m++) ru[m] = valid(m) ? u[base_n + goff(m)] : 0.0;
+        }
+
+        // P1: first derivatives
+        {
+            v4f64 y = tile_product(sU, wave * PL, 1, LD, a_D, lane); // x: rows i, cols j, slab k = wave
+            tile_store(sA1, wave * PL, 1, LD, y, lane);
+            y = tile_product(sU, wave * PL, LD, 1, a_D, lane);       // y: rows j, cols i, slab k = wave
+            tile_store(sA2, wave * PL, LD, 1, y, lane);
+            y = tile_product(sU, wave * LD, PL, 1, a_D, lane);       // z: rows k, cols i, slab j = wave
+            tile_store(sA3, wave * LD, PL, 1, y, lane);
+        }
+        lds_barrier();
+
+        // P2: geometric factors, point-wise, in place (domain.okl:47-49)
+#pragma unroll
+        for (int m = 0; m < kPts; m++)
+        {
+            const double Du_1 = sA1[lidx(m)], Du_2 = sA2[lidx(m)], Du_3 = sA3[lidx(m)];
+            sA1[lidx(m)] = rg[0][m] * Du_1 + rg[3][m] * Du_2 + rg[4][m] * Du_3;
+            sA2[lidx(m)] = rg[3][m] * Du_1 + rg[1][m] * Du_2 + rg[5][m] * Du_3;
+            sA3[lidx(m)] = rg[4][m] * Du_1 + rg[5][m] * Du_2 + rg[2][m] * Du_3;
+        }
+        if (more)
+        {
+#pragma unroll
+            for (int m = 0; m < kPts; m++)
+#pragma unroll
+                for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? G.g[g][base_n + goff(m)] : 0.0;
+        }
+        lds_barrier();
+
+        // P3a: Au_x then + Au_y on this wave's xy-slab
+        {
+            v4f64 y = tile_product(sA1, wave * PL, 1, LD, a_Dt, lane);
+            tile_store(sU, wave * PL, 1, LD, y, lane);
+            y = tile_product(sA2, wave * PL, LD, 1, a_Dt, lane);
+            tile_add(sU, wave * PL, LD, 1, y, lane);
+        }
+        lds_barrier();
+
+        // P3b: + Au_z on this wave's xz-slab
+        {
+            v4f64 y = tile_product(sA3, wave * LD, PL, 1, a_Dt, lane);
+            tile_add(sU, wave * LD, PL, 1, y, lane);
+        }
+        lds_barrier();
+
+        // P4: LDS -> global
+#pragma unroll
+        for (int m = 0; m < kPts; m++)
+            if (valid(m)) Au[base + goff(m)] = sU[lidx(m)];
+    }
+#undef lidx
+#undef goff
+#undef valid
+}
+
+template <int n>
+int launch_mfma(double *Au, const double *u, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
+{
+    const size_t lds = 4 * (size_t)ARR * sizeof(double);
+    static bool configured = false;
+    if (!configured)
+    {
+        FDD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_stiffness_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    const int grid = num_elements < FDD_CU_COUNT ? num_elements : FDD_CU_COUNT;
+    hipLaunchKernelGGL(mfma_stiffness_kernel<n>, dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, D_hat, G, elem_offset, num_elements);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int fdd_stiffness_matrix_mfma(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    FDD_REQUIRE(num_elements >= 0);
+    if (num_elements == 0) return 0;
+    FDD_REQUIRE(Au != nullptr && u != nullptr && D_hat != nullptr && G != nullptr && Au != u);
+    GPtrs g;
+    for (int k = 0; k < FDD_NUM_GEOM_FACTS; k++)
+    {
+        FDD_REQUIRE(G[k] != nullptr);
+        g.g[k] = G[k];
+    }
+    switch (poly_degree + 1)
+    {
+    case 9: return launch_mfma<9>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 10: return launch_mfma<10>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 11: return launch_mfma<11>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 12: return launch_mfma<12>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 13: return launch_mfma<13>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 14: return launch_mfma<14>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 15: return launch_mfma<15>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 16: return launch_mfma<16>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    default:
+        fdd_set_error("fp64-MFMA stiffness kernel supports poly_degree 8..15, got %d", poly_degree);
+        return FDD_ERR_UNSUPPORTED;
+    }
+}
+
+} // extern "C"

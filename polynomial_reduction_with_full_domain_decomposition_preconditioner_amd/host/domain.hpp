@@ -207,6 +207,7 @@ class Domain
     int preconditioner_type = 1;
     bool use_preconditioner = true;
     bool fused_dssum = true; // gather-scatter kernel instead of the reference's Qt / Q SpMV pair
+    bool mfma_stiffness = true; // N >= 11: stiffness on the fp64 matrix cores (not bit-identical; 1e-12 tolerance)
     DType tolerance = 1.0e-07;
     std::vector<DType> residual_history; // what the reference prints per iteration
 
@@ -538,7 +539,13 @@ class Domain
     // domain.tpp:602-609
     void stiffness_matrix(fdd::memory &Au, fdd::memory &u, bool apply_dssum = false)
     {
-        if (mesh.dim == 3 and poly_degree <= 15)
+        if (mesh.dim == 3 and poly_degree >= 11 and poly_degree <= 15 and mfma_stiffness and Au.ptr() != u.ptr())
+        {
+            // high order: the six contractions on the fp64 matrix cores (tolerance-level parity, fdd_hip.h)
+            fdd::ProfileScope prof("mfma_stiffness_kernel", 64.0 * num_local_points);
+            FDD_CALL(fdd_stiffness_matrix_mfma(Au.as<double>(), u.as<double>(), D_hat.as<double>(), G_ptrs, nullptr, num_local_elements, poly_degree, fdd::dev().stream));
+        }
+        else if (mesh.dim == 3 and poly_degree <= 15)
         {
             fdd::ProfileScope prof("fused_stiffness_kernel", 64.0 * num_local_points);
             FDD_CALL(fdd_dom_stiffness_matrix(Au.as<double>(), u.as<double>(), D_hat.as<double>(), G_ptrs, num_local_elements, poly_degree, fdd::dev().stream));

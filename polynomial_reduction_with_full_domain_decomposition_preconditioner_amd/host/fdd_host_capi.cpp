@@ -425,6 +425,11 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
     {
         if (p->subdomain) p->subdomain->restructured = value != 0;
     }
+    else if (s == "mfma_stiffness")
+    {
+        for (auto &kv : p->domains) kv.second.mfma_stiffness = value != 0;
+        if (p->subdomain) p->subdomain->mfma_stiffness = value != 0;
+    }
     else
         return fail("unknown flag '%s'", name);
     return 0;

@@ -306,6 +306,7 @@ class Subdomain
     bool build_tree = true;               // run the degree-tree restrictions as the reference always does
     bool fused_dssum = true;              // gather-scatter kernel instead of the Qt / QQt_int / Q SpMV chain
     bool restructured = true;             // inner GMRES with cached assembled basis, multi-dot / multi-axpy
+    bool mfma_stiffness = true;           // N >= 11 element lists on the fp64 matrix cores
     std::vector<DType> residual_history;  // inner history of the last application
 
     int num_values = 0;
@@ -547,7 +548,22 @@ class Subdomain
 
         for (auto &ll : subdomain_operator.level_lists)
         {
-            if (dim == 3 and ll.poly_degree <= 15)
+            if (dim == 3 and ll.poly_degree >= 11 and ll.poly_degree <= 15 and mfma_stiffness and Au.ptr() != u.ptr())
+            {
+                const double n3 = (double)(ll.poly_degree + 1) * (ll.poly_degree + 1) * (ll.poly_degree + 1);
+                fdd::ProfileScope prof("mfma_stiffness_kernel", 64.0 * n3 * ll.num_elements);
+                if (ll.contiguous)
+                {
+                    const double *Gs[NUM_GEOM_FACTS];
+                    for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = subdomain_operator.G_ptrs[g] + ll.first_offset;
+                    FDD_CALL(fdd_stiffness_matrix_mfma(Au_sub_l.as<double>() + ll.first_offset, u_sub_l.as<double>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), Gs, nullptr, ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                }
+                else
+                {
+                    FDD_CALL(fdd_stiffness_matrix_mfma(Au_sub_l.as<double>(), u_sub_l.as<double>(), subdomain_operator.D_hat[ll.level].template as<double>(), subdomain_operator.G_ptrs, ll.elem_offset.template as<int>(), ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                }
+            }
+            else if (dim == 3 and ll.poly_degree <= 15)
             {
                 const double n3 = (double)(ll.poly_degree + 1) * (ll.poly_degree + 1) * (ll.poly_degree + 1);
                 fdd::ProfileScope prof("fused_stiffness_kernel", 64.0 * n3 * ll.num_elements);

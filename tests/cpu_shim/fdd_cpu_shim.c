@@ -110,6 +110,7 @@ static int fused(double *Au, const double *u, const double *D, const double *con
 }
 int fdd_dom_stiffness_matrix(double *Au, const double *u, const double *D, const double *const G[6], int ne, int N, void *s) { (void)s; return fused(Au, u, D, G, NULL, ne, N); }
 int fdd_sub_stiffness_matrix(double *Au, const double *u, const double *D, const double *const G[6], const int *eo, int ne, int N, void *s) { (void)s; return fused(Au, u, D, G, eo, ne, N); }
+int fdd_stiffness_matrix_mfma(double *Au, const double *u, const double *D, const double *const G[6], const int *eo, int ne, int N, void *s) { (void)s; return fused(Au, u, D, G, eo, ne, N); }
 int fdd_dom_initialize_arrays(double *u, double *r, const double *f, int n, void *s) { (void)s; orc_dom_initialize_arrays(u, r, f, n); return 0; }
 
 size_t fdd_reduce_workspace_doubles(void) { return 2 * (size_t)FDD_REDUCE_MAX_BLOCKS; }

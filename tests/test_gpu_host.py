@@ -218,6 +218,45 @@ def test_reference_shaped_and_restructured_paths_agree(setup):
     assert np.abs(ref[1][1] - res[1][1]).max() <= 1e-12 * ref[1][1][0]
 
 
+def test_high_order_mfma_path(setup):
+    """Config C3's degree (N = 15) at test size: Domain and Subdomain apply the
+    stiffness on the fp64 matrix cores.  Operator within 1e-12 of the bit-exact
+    scalar kernel and of the oracle; the preconditioned solve keeps the oracle's
+    iteration count and residual history."""
+    E, N, red = (2, 2, 2), 15, 6
+    p = make_problem(E, N, red, True)
+    m = S.ArrayMesh.from_problem(p)
+    W = S.OracleWorld([m], N)
+    sd = oracle_subdomain(p, N, red)
+    try:
+        assert [p.level_degree(lvl) for lvl in range(p.info["num_levels"])] == [15, 9, 3, 1]
+        u = S.seeded_uniform(p.n, 15)
+        ref = W.stiffness([u])[0]
+        got = p.stiffness(u)
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+        p.set_flag("mfma_stiffness", 0)
+        assert np.array_equal(p.stiffness(u), ref)  # scalar fused kernel: same bits
+        p.set_flag("mfma_stiffness", 1)
+        got = p.sub_op("stiffness", u)
+        assert np.abs(got - sd.stiffness(u)).max() <= 1e-12 * np.abs(ref).max()
+
+        u_star, f = p.make_rhs_from(S.seeded_uniform(p.n, 1234))
+        p.set_options(max_iterations=12, tolerance=0.0)
+        uu, its, hist = p.solve(f, "fcg")
+
+        def pre(z, r):
+            out, _, _ = sd.solve(r[0], "gmres")
+            z[0][:] = out
+
+        ou, oits, ohist = W.solve([f], "fcg", max_iterations=12, tolerance=0.0, precond=pre)
+        assert its == oits == 12
+        assert np.abs(hist - ohist).max() <= 1e-8 * ohist[0]
+    finally:
+        sd.close()
+        W.close()
+        p.close()
+
+
 def test_stepwise_pcg_equals_the_solver(setup):
     """fcg_begin + fcg_step (what bench.py times) walks the same iterates as
     flexible_conjugate_gradient."""

@@ -464,6 +464,36 @@ def test_stiffness_fused_bit_exact(gpu, N):
         assert np.array_equal(host(dAu), Au), (N, E)
 
 
+@pytest.mark.parametrize("N", [8, 9, 11, 12, 14, 15])
+def test_stiffness_mfma(gpu, N):
+    """fp64-MFMA path (config C3, N = 15; lower degrees zero-padded to 16): MFMA
+    fuses multiply-add and sums in its own order, so the bar is a tolerance,
+    1e-12 * max|Au| (observed ~1e-15), against the oracle AND against the
+    bit-exact fused kernel; element lists with offsets and counts that do not
+    divide the grid."""
+    for E in (1, 5, 300):
+        u, G, D = stiffness_inputs(E, N, 200 + N)
+        Au, _ = oracle_stiffness(u, G, D, N, 3)
+        du, dD, dG = dev(u, gpu), dev(D, gpu), [dev(g, gpu) for g in G]
+        out = torch.full((len(u),), 3.0, dtype=torch.float64, device=gpu)
+        k("fdd_stiffness_matrix_mfma", out, du, dD, dG, None, E, N)
+        got = host(out)
+        assert np.abs(got - Au).max() <= 1e-12 * np.abs(Au).max(), (N, E, np.abs(got - Au).max() / np.abs(Au).max())
+    # element offsets: every other element of a larger vector
+    n3 = (N + 1) ** 3
+    E = 40
+    u, G, D = stiffness_inputs(2 * E, N, 300 + N)
+    eo = (np.arange(E) * 2 * n3).astype(np.int32)
+    ref = torch.full((len(u),), 7.0, dtype=torch.float64, device=gpu)
+    out = torch.full((len(u),), 7.0, dtype=torch.float64, device=gpu)
+    du, dD, dG, deo = dev(u, gpu), dev(D, gpu), [dev(g, gpu) for g in G], dev(eo, gpu)
+    k("fdd_sub_stiffness_matrix", ref, du, dD, dG, deo, E, N)
+    k("fdd_stiffness_matrix_mfma", out, du, dD, dG, deo, E, N)
+    r, o = host(ref), host(out)
+    assert np.abs(o - r).max() <= 1e-12 * np.abs(r).max()
+    assert np.all(o.reshape(2 * E, n3)[1::2] == 7.0)  # untouched elements
+
+
 def test_stiffness_fused_unsupported_degree(gpu):
     z = torch.zeros(8, dtype=torch.float64, device=gpu)
     with pytest.raises(lib.FddError):

@@ -150,6 +150,8 @@ def main():
         u = a
         Au = b
         report(f"stiffness.fused N={N}", 64 * P, timeit(lambda: k("fdd_dom_stiffness_matrix", Au, u, Dh, G, E**3, N)), results)
+        if N >= 8:
+            report(f"stiffness.mfma_f64 N={N}", 64 * P, timeit(lambda: k("fdd_stiffness_matrix_mfma", Au, u, Dh, G, None, E**3, N)), results)
         GDu = [c, d, e_]
 
         def two():
