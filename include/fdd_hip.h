@@ -61,6 +61,12 @@ int fdd_stream_create(void **stream);           /* cudaStreamCreate, subdomain.t
 int fdd_stream_destroy(void *stream);
 int fdd_stream_sync(void *stream);
 int fdd_device_sync(void);                      /* occa::device::finish(), timer.tpp:50,59 */
+/* hipGraph capture / replay of a launch sequence (cudaGraph of the V-cycle legs,
+ * subdomain.tpp:3644-3704, 4021, 4113).  Capture needs a non-default stream. */
+int fdd_graph_begin_capture(void *stream);
+int fdd_graph_end_capture(void *stream, void **graph_exec);
+int fdd_graph_launch(void *graph_exec, void *stream);
+int fdd_graph_destroy(void *graph_exec);
 int fdd_event_create(void **event);
 int fdd_event_destroy(void *event);
 int fdd_event_record(void *event, void *stream);
@@ -185,6 +191,8 @@ int fdd_amg_main_update_field(double *u, const double *w, const double *D_val, i
 int fdd_amg_vector_multiplication(double *uv, const double *u, const double *v, int size, void *stream);                               /* AMG/kernels.cu:79-94 */
 /* y = alpha*A*x + beta*y (cusparseSpMV CSR_ALG1 at AMG/csr_matrix.cpp:129-131); y must not alias x */
 int fdd_amg_matvec(double *y, const int *ptr, const int *col, const double *val, const double *x, double alpha, double beta, int num_rows, void *stream);
+/* the same on a plan (LDS row staging for the ~27 non-zeros per row of the AMG levels) */
+int fdd_csr_plan_matvec(const fdd_csr_plan *plan, double *y, const int *A_ptr, const int *A_col, const double *A_val, const double *x, double alpha, double beta, void *stream);
 /* cublasDdot replacement (AMG/vector.cpp:100,129): out[0] = sum x*y */
 int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int size, void *stream);
 

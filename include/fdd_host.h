@@ -98,8 +98,23 @@ int fddh_problem_set_options(fddh_problem *p, int max_iterations, double toleran
  *   "restructured_inner_solve" 1: inner GMRES with cached assembled vectors, multi-dot / multi-axpy (default),
  *                              0: the reference's launch-by-launch sequence (subdomain.tpp:4309-4489)
  *   "mfma_stiffness"           1: degrees 11..15 apply the stiffness on the fp64 matrix cores (default;
- *                              agrees with the bit-exact kernel to ~1e-15, not bit for bit), 0: scalar fused kernel */
+ *                              agrees with the bit-exact kernel to ~1e-15, not bit for bit), 0: scalar fused kernel
+ *   "sub_use_preconditioner"   1: the inner solver preconditions with the low-order AMG V-cycle
+ *                              (Subdomain::use_preconditioner, subdomain.hpp:231; needs fddh_problem_amg_*), 0: dssum (default)
+ *   "amg_graph"                1: the V-cycle is replayed as one hipGraph when the stream allows capture (default) */
 int fddh_problem_set_flag(fddh_problem *p, const char *name, int value);
+
+/* Low-order AMG preconditioner of the inner solve (Subdomain::low_order_preconditioner,
+ * subdomain.tpp:3987-4159).  The reference builds the hierarchy with HYPRE BoomerAMG
+ * (subdomain.tpp:3383-3549); here the caller hands it in, finest level first:
+ * A (CSR), the Chebyshev diagonal scaling D_val and coefficients (hypre ds / coefs), and
+ * the prolongation P to the next level (null + n_coarse 0 on the coarsest level).  Level 0
+ * is numbered by the subdomain's dofs: fddh_problem_sub_point_dofs gives the dof of every
+ * level-0 point (-1 on Dirichlet points). */
+int fddh_problem_sub_point_dofs(const fddh_problem *p, int *dof, int n);
+int fddh_problem_amg_add_level(fddh_problem *p, int n, const int *A_ptr, const int *A_col, const double *A_val, const double *D_val, const double *coefs, int num_coefs, int n_coarse, const int *P_ptr, const int *P_col, const double *P_val);
+int fddh_problem_amg_finalize(fddh_problem *p);
+int fddh_problem_amg_apply(fddh_problem *p, const double *r, double *z);
 
 /* Domain operations on host vectors of num_local_points */
 int fddh_problem_dssum(fddh_problem *p, double *out, const double *in, int apply_mask, int apply_weight);          /* Domain::direct_stiffness_summation */

@@ -214,6 +214,21 @@ int orc_subdomain_gmres(orc_subdomain *s, double *u_l, const double *f_l, const 
 /* flexible_conjugate_gradient (subdomain.tpp:4161-4268) */
 int orc_subdomain_fcg(orc_subdomain *s, double *u_l, const double *f_l, const orc_subdomain_opts *opts, double *history, int history_cap, int *num_hist);
 
+/* ------------------------------------------------------------------ */
+/* Low-order AMG V-cycle given a hierarchy (subdomain.tpp:19-83,        */
+/* 3987-4159); the hierarchy itself comes from HYPRE in the reference   */
+/* and is an input here (fdd_oracle_amg.c)                              */
+/* ------------------------------------------------------------------ */
+typedef struct orc_amg orc_amg;
+orc_amg *orc_amg_create(int num_levels, int cheby_order, int num_vcycles);
+void orc_amg_set_level(orc_amg *a, int l, int n, const int *A_ptr, const int *A_col, const double *A_val, const double *D_val, const double *coefs, int n_coarse, const int *P_ptr, const int *P_col, const double *P_val);
+void orc_amg_destroy(orc_amg *a);
+int orc_amg_level_size(const orc_amg *a, int l);
+void orc_amg_vcycle(orc_amg *a, double *u0, const double *f0);
+void orc_subdomain_attach_amg(orc_subdomain *s, orc_amg *amg);
+void orc_subdomain_point_dofs(const orc_subdomain *s, int *dof);
+void orc_subdomain_low_order_preconditioner(orc_subdomain *s, double *z, const double *r);
+
 #ifdef __cplusplus
 }
 #endif

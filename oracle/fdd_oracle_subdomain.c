@@ -74,6 +74,8 @@ struct orc_subdomain
     double *f, *u_k, *r_k, *r_kp1, *q_k, *z_k, *p_k;
     double **V, **Z;
     int cap_vectors;
+
+    orc_amg *amg; /* low-order preconditioner hierarchy (not owned) */
 };
 
 static void *xcalloc(size_t n, size_t sz)
@@ -472,6 +474,37 @@ static double assembled_inner_product(orc_subdomain *s, const double *u, const d
     return orc_block_sum(s->p_k, num_blocks);
 }
 
+void orc_subdomain_attach_amg(orc_subdomain *s, orc_amg *amg) { s->amg = amg; }
+
+/* dof of every level-0 point, -1 where the point has none (the rows of the boolean Q, subdomain.tpp:1588-1601) */
+void orc_subdomain_point_dofs(const orc_subdomain *s, int *dof)
+{
+    for (int p = 0; p < s->num_points; p++) dof[p] = (s->Q.ptr[p + 1] > s->Q.ptr[p]) ? s->Q.col[s->Q.ptr[p]] : -1;
+}
+
+/* subdomain.tpp:3987-4159 on the conforming composite: Qt_int = Q_int = I, empty tail */
+void orc_subdomain_low_order_preconditioner(orc_subdomain *s, double *z, const double *r)
+{
+    if (!s->amg || orc_amg_level_size(s->amg, 0) != s->num_dofs)
+    {
+        fprintf(stderr, "fdd_oracle: low_order_preconditioner needs an attached AMG hierarchy over the %d dofs\n", s->num_dofs);
+        abort();
+    }
+    orc_csr_multiply(s->work[0], s->Qt.ptr, s->Qt.col, s->Qt.val, r, s->Qt.num_rows);                        /* :3996 */
+    orc_csr_multiply(s->work[1], s->Qt_int.ptr, s->Qt_int.col, s->Qt_int.val, s->work[0], s->Qt_int.num_rows); /* :4004 */
+    orc_amg_vcycle(s->amg, s->work[2], s->work[1]);                                                            /* :4008-4142 */
+    orc_csr_multiply(s->work[0], s->Q_int.ptr, s->Q_int.col, s->Q_int.val, s->work[2], s->Q_int.num_rows);     /* :4146 */
+    orc_csr_multiply(z, s->Q.ptr, s->Q.col, s->Q.val, s->work[0], s->Q.num_rows);                              /* :4153 */
+}
+
+static void apply_inner_preconditioner(orc_subdomain *s, const orc_subdomain_opts *opts, double *z, const double *r)
+{
+    if (opts->use_preconditioner)
+        orc_subdomain_low_order_preconditioner(s, z, r);
+    else
+        orc_subdomain_dssum(s, z, r);
+}
+
 static void push_hist(double *history, int cap, int *n, double v)
 {
     if (history && *n < cap) history[*n] = v;
@@ -544,8 +577,8 @@ int orc_subdomain_gmres(orc_subdomain *s, double *u_l, const double *f_l, const 
         {
             iter++;
 
-            /* use_preconditioner == false path (subdomain.tpp:4377-4382) */
-            orc_subdomain_dssum(s, s->Z[j], s->V[j]);
+            /* subdomain.tpp:4373-4382 */
+            apply_inner_preconditioner(s, opts, s->Z[j], s->V[j]);
 
             orc_subdomain_stiffness(s, s->q_k, s->Z[j]);
 
@@ -636,7 +669,7 @@ int orc_subdomain_fcg(orc_subdomain *s, double *u_l, const double *f_l, const or
 
     double alpha_k, beta_k, gamma_k, theta_k;
 
-    orc_subdomain_dssum(s, s->z_k, s->r_k);
+    apply_inner_preconditioner(s, opts, s->z_k, s->r_k); /* subdomain.tpp:4190-4193 */
     memcpy(s->p_k, s->z_k, (size_t)nv * sizeof(double));
 
     int iter = 0;
@@ -667,7 +700,7 @@ int orc_subdomain_fcg(orc_subdomain *s, double *u_l, const double *f_l, const or
         if (r_norm < opts->tolerance) break;
         if (iter == opts->max_iterations) break;
 
-        orc_subdomain_dssum(s, s->z_k, s->r_kp1);
+        apply_inner_preconditioner(s, opts, s->z_k, s->r_kp1); /* subdomain.tpp:4245-4248 */
 
         /* search_update_inner_product (subdomain.tpp:4544-4557) */
         orc_sub_search_update_inner_product(s->work[0], s->r_k, s->r_kp1, s->z_k, s->inner_weight, nv, nb);

@@ -572,4 +572,21 @@ int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr
     return 0;
 }
 
+// y = alpha*A*x + beta*y on a plan (the cusparseSpMV of AMG/csr_matrix.cpp:129-131); y must not alias x
+int fdd_csr_plan_matvec(const fdd_csr_plan *plan, double *y, const int *A_ptr, const int *A_col, const double *A_val, const double *x, double alpha, double beta, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr);
+    if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
+    FDD_REQUIRE(y != nullptr && A_ptr != nullptr && x != nullptr && y != x);
+    const EpiAxpby epi{alpha, beta};
+    if (plan->kind == 0) return launch_rows(y, A_ptr, A_col, A_val, x, epi, 0, plan->num_rows, stream, plan->unit_values != 0);
+    const dim3 grid(plan->num_blocks), block(kBlock);
+    if (plan->unit_values)
+        hipLaunchKernelGGL((csr_block_kernel<EpiAxpby, true>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev);
+    else
+        hipLaunchKernelGGL((csr_block_kernel<EpiAxpby, false>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
 } // extern "C"

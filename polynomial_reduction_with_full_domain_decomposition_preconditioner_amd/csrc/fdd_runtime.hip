@@ -131,6 +131,47 @@ int fdd_device_sync(void)
     return 0;
 }
 
+// hipGraph capture of a launch sequence on a stream: the reference captures the
+// down-leg and up-leg of the AMG V-cycle into CUDA graphs and replays them per
+// application (subdomain.tpp:3644-3704, 4021, 4113).
+int fdd_graph_begin_capture(void *stream)
+{
+    FDD_REQUIRE(stream != nullptr); // the default stream cannot be captured
+    FDD_HIP_CHECK(hipStreamBeginCapture(fdd_stream(stream), hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+
+int fdd_graph_end_capture(void *stream, void **graph_exec)
+{
+    FDD_REQUIRE(graph_exec != nullptr);
+    hipGraph_t graph = nullptr;
+    FDD_HIP_CHECK(hipStreamEndCapture(fdd_stream(stream), &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (err != hipSuccess)
+    {
+        fdd_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(err));
+        return (int)err;
+    }
+    *graph_exec = reinterpret_cast<void *>(exec);
+    return 0;
+}
+
+int fdd_graph_launch(void *graph_exec, void *stream)
+{
+    FDD_REQUIRE(graph_exec != nullptr);
+    FDD_HIP_CHECK(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), fdd_stream(stream)));
+    return 0;
+}
+
+int fdd_graph_destroy(void *graph_exec)
+{
+    if (graph_exec == nullptr) return 0;
+    FDD_HIP_CHECK(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec)));
+    return 0;
+}
+
 int fdd_event_create(void **event)
 {
     FDD_REQUIRE(event != nullptr);

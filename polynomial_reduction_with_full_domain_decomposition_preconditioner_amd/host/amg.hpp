@@ -1,0 +1,184 @@
+/*
+ * amg.hpp -- the low-order AMG V-cycle of the FDD preconditioner
+ * (Subdomain::low_order_preconditioner, subdomain.tpp:3987-4159; smoother
+ * pieces subdomain.tpp:19-83; containers AMG/csr_matrix.*, AMG/vector.*).
+ *
+ * The reference gets the hierarchy from HYPRE BoomerAMG (A_l, the Chebyshev
+ * diagonal scaling and coefficients, P_l; subdomain.tpp:3474-3549), keeps
+ * levels <= level_cutoff on the GPU and the rest on the host, solves the
+ * coarsest level with hypre_GaussElimSolve on the host, and replays the two
+ * device legs as CUDA graphs.  Here the hierarchy is handed in level by level
+ * (HYPRE is not available: documented deviation), EVERY level lives
+ * in HBM, the coarsest level is a dense inverse applied as one SpMV (computed
+ * once on the host by Gaussian elimination), and the whole V-cycle -- not two
+ * legs with host work in between -- is one hipGraph.
+ *
+ * Kernels: fdd_amg_* (AMG/kernels.cu), SpMV y = alpha*A*x + beta*y on the
+ * LDS-staged row-block plan (cusparseSpMV, AMG/csr_matrix.cpp:129-131).
+ */
+#ifndef FDD_AMG_HPP
+#define FDD_AMG_HPP
+
+#include <vector>
+
+#include "config.hpp"
+#include "csr_matrix.hpp"
+
+namespace amg
+{
+
+struct Level
+{
+    int n = 0;
+    CSR_Matrix<double> A;
+    CSR_Matrix<double> P; // n x n_coarse
+    CSR_Matrix<double> R; // P^T
+    fdd::memory D_val;
+    std::vector<double> coefs; // Chebyshev coefficients, coefs[p] multiplies (DAD)^p
+    fdd::memory f, u, r, v, w, work;
+};
+
+class Hierarchy
+{
+  private:
+    bool finalized = false;
+    void *graph = nullptr;
+    bool graph_failed = false;
+    CSR_Matrix<double> coarse_inverse;
+
+    static void copy(fdd::memory &dst, const fdd::memory &src, int n) { dst.copyFrom(src, (size_t)n * sizeof(double)); }
+
+    // Chebyshev smoother, device branches of subdomain.tpp:19-83
+    void smooth(int l)
+    {
+        Level &L = levels[l];
+        void *s = fdd::dev().stream;
+        // scaled_residual (:34-39)
+        copy(L.work, L.f, L.n);
+        L.A.matvec(L.work, L.u, -1.0, 1.0);
+        FDD_CALL(fdd_amg_main_scaled_residual(L.r.as<double>(), L.w.as<double>(), L.work.as<double>(), L.D_val.as<double>(), L.coefs[cheby_order - 1], L.n, s));
+        // polynomial_evaluation (:62-67)
+        for (int p = cheby_order - 2; p >= 0; p--)
+        {
+            FDD_CALL(fdd_amg_vector_multiplication(L.work.as<double>(), L.D_val.as<double>(), L.w.as<double>(), L.n, s));
+            L.A.matvec(L.v, L.work, 1.0, 0.0);
+            FDD_CALL(fdd_amg_main_polynomial_evaluation(L.w.as<double>(), L.v.as<double>(), L.r.as<double>(), L.D_val.as<double>(), L.coefs[p], L.n, s));
+        }
+        // update_field (:79-82)
+        FDD_CALL(fdd_amg_main_update_field(L.u.as<double>(), L.w.as<double>(), L.D_val.as<double>(), L.n, s));
+    }
+
+    // subdomain.tpp:4015-4139, every level on the device
+    void vcycle_launches()
+    {
+        const int nl = (int)levels.size();
+        void *s = fdd::dev().stream;
+        FDD_CALL(fdd_amg_vector_set_to_value(levels[0].u.as<double>(), 0.0, levels[0].n, s)); // :4012
+        for (int iter = 0; iter < num_vcycles; iter++)
+        {
+            for (int l = 0; l < nl - 1; l++)
+            {
+                Level &L = levels[l];
+                if (l > 0) FDD_CALL(fdd_amg_vector_set_to_value(L.u.as<double>(), 0.0, L.n, s));
+                smooth(l);
+                copy(L.v, L.f, L.n);             // v = f
+                L.A.matvec(L.v, L.u, -1.0, 1.0); // v = f - A u
+                L.R.matvec(levels[l + 1].f, L.v, 1.0, 0.0);
+            }
+            Level &C = levels[nl - 1];
+            coarse_inverse.matvec(C.u, C.f, 1.0, 0.0); // hypre_GaussElimSolve's role (:4084)
+            for (int l = nl - 1; l > 0; l--)
+            {
+                levels[l - 1].P.matvec(levels[l - 1].u, levels[l].u, 1.0, 1.0); // u_{l-1} += P u_l
+                smooth(l - 1);
+            }
+        }
+    }
+
+  public:
+    int cheby_order = 2; // subdomain.hpp:237
+    int num_vcycles = 1; // subdomain.hpp:236
+    bool use_graph = true; // AMG/config.hpp:6 USE_CUDA_GRAPH
+    std::vector<Level> levels;
+
+    bool ready() const { return finalized; }
+    int fine_size() const { return levels.empty() ? 0 : levels[0].n; }
+
+    // CSR arrays on the host; P_* null on the coarsest level
+    void add_level(int n, const int *A_ptr, const int *A_col, const double *A_val, const double *D_val, const double *coefs_, int n_coarse, const int *P_ptr, const int *P_col, const double *P_val)
+    {
+        levels.emplace_back();
+        Level &L = levels.back();
+        L.n = n;
+        L.A.assemble_from_csr(n, n, A_ptr, A_col, A_val);
+        if (P_ptr)
+        {
+            L.P.assemble_from_csr(n, n_coarse, P_ptr, P_col, P_val);
+            L.P.transpose(L.R); // R_fem[l] = P^T (subdomain.tpp:3526-3545)
+        }
+        L.D_val = fdd::dev().malloc<double>(n);
+        L.D_val.copyFrom(D_val, (size_t)n * sizeof(double));
+        L.coefs.assign(coefs_, coefs_ + cheby_order);
+        for (fdd::memory *m : {&L.f, &L.u, &L.r, &L.v, &L.w, &L.work}) *m = fdd::dev().malloc<double>(n);
+    }
+
+    void finalize()
+    {
+        // dense inverse of the coarsest operator by Gaussian elimination (no pivoting), once, on the host
+        Level &C = levels.back();
+        const int n = C.n;
+        std::vector<double> M((size_t)n * n, 0.0), Inv((size_t)n * n, 0.0);
+        for (int i = 0; i < n; i++)
+            for (int j = C.A.ptr_hst[i]; j < C.A.ptr_hst[i + 1]; j++) M[(size_t)i * n + C.A.col_hst[j]] += C.A.val_hst[j];
+        for (int i = 0; i < n; i++) Inv[(size_t)i * n + i] = 1.0;
+        for (int k = 0; k < n; k++)
+            for (int i = k + 1; i < n; i++)
+            {
+                const double m = M[(size_t)i * n + k] / M[(size_t)k * n + k];
+                if (m == 0.0) continue;
+                for (int j = k + 1; j < n; j++) M[(size_t)i * n + j] -= m * M[(size_t)k * n + j];
+                for (int j = 0; j < n; j++) Inv[(size_t)i * n + j] -= m * Inv[(size_t)k * n + j];
+            }
+        for (int i = n - 1; i >= 0; i--)
+            for (int c = 0; c < n; c++)
+            {
+                double s = Inv[(size_t)i * n + c];
+                for (int j = i + 1; j < n; j++) s -= M[(size_t)i * n + j] * Inv[(size_t)j * n + c];
+                Inv[(size_t)i * n + c] = s / M[(size_t)i * n + i];
+            }
+        std::vector<int> ptr(n + 1), col((size_t)n * n);
+        for (int i = 0; i <= n; i++) ptr[i] = i * n;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) col[(size_t)i * n + j] = j;
+        coarse_inverse.assemble_from_csr(n, n, ptr.data(), col.data(), Inv.data());
+        finalized = true;
+    }
+
+    // u_fem[0] = V-cycle applied to f_fem[0] from u = 0; both live in levels[0]
+    void vcycle()
+    {
+        void *s = fdd::dev().stream;
+        if (use_graph and s != nullptr and not graph_failed and not fdd::profiler().enabled)
+        {
+            if (graph == nullptr)
+            {
+                if (fdd_graph_begin_capture(s) == 0)
+                {
+                    vcycle_launches();
+                    if (fdd_graph_end_capture(s, &graph) != 0) graph = nullptr;
+                }
+                if (graph == nullptr) graph_failed = true;
+            }
+            if (graph != nullptr)
+            {
+                FDD_CALL(fdd_graph_launch(graph, s));
+                return;
+            }
+        }
+        vcycle_launches();
+    }
+};
+
+} // namespace amg
+
+#endif

@@ -123,6 +123,36 @@ class CSR_Matrix
         }
 
         for (int i = 1; i <= num_rows; i++) ptr_hst[i] += ptr_hst[i - 1];
+
+        entries.clear();
+        entries.shrink_to_fit();
+        upload();
+    }
+
+    // take finished CSR arrays as they are (AMG::CSR_Matrix::initialize copies HYPRE's i/j/data, AMG/csr_matrix.cpp:24-66)
+    void assemble_from_csr(int num_rows_, int num_cols_, const int *ptr_, const int *col_, const DType *val_)
+    {
+        initialize(num_rows_, num_cols_);
+        if ((num_rows == 0) or (num_cols == 0) or (ptr_[num_rows] == 0)) return;
+        ptr_hst.assign(ptr_, ptr_ + num_rows + 1);
+        col_hst.assign(col_, col_ + ptr_[num_rows]);
+        val_hst.assign(val_, val_ + ptr_[num_rows]);
+        upload();
+    }
+
+    // y = alpha*A*x + beta*y (AMG::CSR_Matrix::matvec, AMG/csr_matrix.cpp:129-131); beta == 0 never reads y
+    void matvec(fdd::memory &y, fdd::memory &x, double alpha, double beta)
+    {
+        if ((num_rows == 0) or (num_cols == 0)) return;
+        initialization_check();
+        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiAxpby>" : "csr_block_kernel<EpiAxpby>", algorithmic_bytes(beta != 0.0));
+        FDD_CALL(fdd_csr_plan_matvec(plan, y.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), x.as<double>(), alpha, beta, fdd::dev().stream));
+    }
+
+  private:
+    // host mirrors -> HBM + the SpMV plan
+    void upload()
+    {
         num_nnz = (int)col_hst.size();
 
         unit_values = true;
@@ -148,10 +178,9 @@ class CSR_Matrix
         FDD_CALL(fdd_csr_plan_create(&plan, ptr_hst.data(), num_rows, num_cols, num_nnz));
         FDD_CALL(fdd_csr_plan_kind(plan, &plan_kind));
         FDD_CALL(fdd_csr_plan_set_unit_values(plan, unit_values ? 1 : 0));
-
-        entries.clear();
-        entries.shrink_to_fit();
     }
+
+  public:
 
     // drop the host mirrors of a large matrix once setup no longer needs them
     void release_host()

@@ -430,8 +430,68 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
         for (auto &kv : p->domains) kv.second.mfma_stiffness = value != 0;
         if (p->subdomain) p->subdomain->mfma_stiffness = value != 0;
     }
+    else if (s == "sub_use_preconditioner")
+    {
+        if (!p->subdomain) return fail("problem was created without a Subdomain");
+        p->subdomain->use_preconditioner = value != 0;
+    }
+    else if (s == "amg_graph")
+    {
+        if (p->subdomain) p->subdomain->amg_hierarchy.use_graph = value != 0;
+    }
     else
         return fail("unknown flag '%s'", name);
+    return 0;
+}
+
+int fddh_problem_sub_point_dofs(const fddh_problem *p, int *dof, int n)
+{
+    if (!p || !dof) return fail("null argument");
+    if (!p->subdomain) return fail("problem was created without a Subdomain");
+    if (n != (int)p->subdomain->point_dof.size()) return fail("the subdomain has %d level-0 points", (int)p->subdomain->point_dof.size());
+    memcpy(dof, p->subdomain->point_dof.data(), (size_t)n * sizeof(int));
+    return 0;
+}
+
+int fddh_problem_amg_add_level(fddh_problem *p, int n, const int *A_ptr, const int *A_col, const double *A_val, const double *D_val, const double *coefs, int num_coefs, int n_coarse, const int *P_ptr, const int *P_col, const double *P_val)
+{
+    if (!p || !A_ptr || !A_col || !A_val || !D_val || !coefs) return fail("null argument");
+    if (!p->subdomain) return fail("problem was created without a Subdomain");
+    Subdomain<SType> &s = *p->subdomain;
+    if (s.amg_hierarchy.ready()) return fail("the AMG hierarchy is already finalized");
+    if (num_coefs != s.cheby_order) return fail("cheby_order is %d, got %d coefficients", s.cheby_order, num_coefs);
+    if (s.amg_hierarchy.levels.empty() && n != s.dofs()) return fail("the finest AMG level must have the subdomain's %d dofs, got %d", s.dofs(), n);
+    if (!s.amg_hierarchy.levels.empty())
+    {
+        const amg::Level &prev = s.amg_hierarchy.levels.back();
+        if (prev.P.num_rows == 0) return fail("the previous level was given without a prolongation, so it is the coarsest");
+        if (prev.P.num_cols != n) return fail("level size %d does not match the previous prolongation's %d columns", n, prev.P.num_cols);
+    }
+    if ((P_ptr != nullptr) != (n_coarse > 0)) return fail("n_coarse > 0 exactly when a prolongation is given");
+    s.amg_add_level(n, A_ptr, A_col, A_val, D_val, coefs, n_coarse, P_ptr, P_col, P_val);
+    return 0;
+}
+
+int fddh_problem_amg_finalize(fddh_problem *p)
+{
+    if (!p) return fail("null argument");
+    if (!p->subdomain) return fail("problem was created without a Subdomain");
+    if (p->subdomain->amg_hierarchy.levels.empty()) return fail("no AMG level was added");
+    if (p->subdomain->amg_hierarchy.levels.back().P.num_rows != 0) return fail("the last AMG level still has a prolongation: add its coarse level first");
+    p->subdomain->amg_finalize();
+    return 0;
+}
+
+// z = low_order_preconditioner(r) on level-0 subdomain points (subdomain.tpp:3987-4159)
+int fddh_problem_amg_apply(fddh_problem *p, const double *r, double *z)
+{
+    if (!p || !r || !z) return fail("null argument");
+    if (!p->subdomain) return fail("problem was created without a Subdomain");
+    if (!p->subdomain->amg_hierarchy.ready()) return fail("no finalized AMG hierarchy is attached");
+    const size_t bytes = (size_t)p->fine().num_local_points * sizeof(double);
+    p->a.copyFrom(r, bytes);
+    p->subdomain->apply_low_order_preconditioner(p->b, p->a);
+    p->b.copyTo(z, bytes);
     return 0;
 }
 

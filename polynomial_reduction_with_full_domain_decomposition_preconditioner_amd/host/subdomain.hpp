@@ -39,6 +39,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "amg.hpp"
 #include "config.hpp"
 #include "csr_matrix.hpp"
 #include "domain.hpp"
@@ -278,14 +279,36 @@ class Subdomain
         FDD_CALL(fdd_sub_residual_and_search_update(p.as<double>(), r.as<double>(), z.as<double>(), r1.as<double>(), beta_k, num_values, fdd::dev().stream));
     }
 
-    // subdomain.tpp:3987-4159.  The low-order FEM matrix and its AMG hierarchy
-    // come from HYPRE in the reference (subdomain.tpp:2749-3705); no hierarchy
-    // is attached in this build, so asking for it is an error, not a silent
-    // identity.
-    void low_order_preconditioner(fdd::memory &, fdd::memory &)
+    // subdomain.tpp:3987-4159: z = Q Q_int V(Qt_int Qt r), V = the AMG V-cycle on
+    // the low-order FEM matrix.  The hierarchy comes from HYPRE in the reference
+    // (subdomain.tpp:2749-3705) and is attached from outside here (amg.hpp);
+    // asking for the preconditioner without one is an error, not a silent identity.
+    void low_order_preconditioner(fdd::memory &z, fdd::memory &r)
     {
-        fprintf(stderr, "ERROR: Subdomain::use_preconditioner = true needs the low-order AMG hierarchy, which this build does not construct\n");
-        exit(EXIT_FAILURE);
+        if (not amg_hierarchy.ready() or amg_hierarchy.fine_size() != num_dofs)
+        {
+            fprintf(stderr, "ERROR: Subdomain::use_preconditioner = true needs an attached AMG hierarchy over the %d dofs (amg_add_level / amg_finalize)\n", num_dofs);
+            exit(EXIT_FAILURE);
+        }
+        amg::Level &fine = amg_hierarchy.levels[0];
+        fdd::memory r_sub_l = r.slice(0, subdomain_operator.num_points);
+        fdd::memory z_sub_l = z.slice(0, subdomain_operator.num_points);
+        subdomain_operator.Qt.multiply(work_dev[0], r_sub_l); // :3996
+        if (Qt_int.is_identity)
+            fine.f.copyFrom(work_dev[0], (size_t)num_dofs * sizeof(DType)); // :4004-4008 with Qt_int = I
+        else
+        {
+            Qt_int.multiply(work_dev[1], work_dev[0]);
+            fine.f.copyFrom(work_dev[1], (size_t)num_dofs * sizeof(DType));
+        }
+        amg_hierarchy.vcycle(); // :4012-4142
+        if (Q_int.is_identity)
+            subdomain_operator.Q.multiply(z_sub_l, fine.u); // :4146-4153 with Q_int = I
+        else
+        {
+            Q_int.multiply(work_dev[0], fine.u);
+            subdomain_operator.Q.multiply(z_sub_l, work_dev[0]);
+        }
     }
 
   public:
@@ -301,7 +324,18 @@ class Subdomain
 
     int num_vcycles = 1;
     int cheby_order = 2;
-    int level_cutoff = 5;
+    int level_cutoff = 5; // kept for the interface; every level lives in HBM here (amg.hpp)
+    amg::Hierarchy amg_hierarchy;
+
+    // hand the hierarchy in, finest level first (stands in for subdomain.tpp:3474-3549)
+    void amg_add_level(int n, const int *A_ptr, const int *A_col, const double *A_val, const double *D_val, const double *coefs, int n_coarse, const int *P_ptr, const int *P_col, const double *P_val)
+    {
+        amg_hierarchy.cheby_order = cheby_order;
+        amg_hierarchy.num_vcycles = num_vcycles;
+        amg_hierarchy.add_level(n, A_ptr, A_col, A_val, D_val, coefs, n_coarse, P_ptr, P_col, P_val);
+    }
+    void amg_finalize() { amg_hierarchy.finalize(); }
+    void apply_low_order_preconditioner(fdd::memory &z, fdd::memory &r) { low_order_preconditioner(z, r); }
 
     bool build_tree = true;               // run the degree-tree restrictions as the reference always does
     bool fused_dssum = true;              // gather-scatter kernel instead of the Qt / QQt_int / Q SpMV chain
@@ -310,6 +344,7 @@ class Subdomain
     std::vector<DType> residual_history;  // inner history of the last application
 
     int num_values = 0;
+    std::vector<int> point_dof; // dof of every level-0 subdomain point, -1 on Dirichlet points (the rows of Q)
 
     Subdomain() {}
 
@@ -410,6 +445,9 @@ class Subdomain
             if (tmp[p] > 0.0) subdomain_operator.Q.add_entry(p, (int)tmp[p] - 1, 1.0);
         subdomain_operator.Q.assemble();
         subdomain_operator.Q.transpose(subdomain_operator.Qt);
+        point_dof.assign(P, -1);
+        for (int p = 0; p < P; p++)
+            if (tmp[p] > 0.0) point_dof[p] = (int)tmp[p] - 1;
         {
             std::vector<int> no_dof;
             for (int p = 0; p < P; p++)

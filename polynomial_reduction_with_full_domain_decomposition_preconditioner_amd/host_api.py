@@ -281,6 +281,37 @@ class Problem:
         _H().call("fddh_problem_sub_op", self.h, code, _dp(np.ascontiguousarray(u)), _dp(out))
         return out
 
+    # --- low-order AMG preconditioner of the inner solve (hierarchy handed in) ---
+    def sub_point_dofs(self):
+        dof = np.zeros(self.n, dtype=np.int32)
+        _H().call("fddh_problem_sub_point_dofs", self.h, dof.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), self.n)
+        return dof
+
+    def amg_attach(self, levels):
+        """levels: finest first, dicts with A (scipy CSR), D (diagonal scaling),
+        coefs (Chebyshev coefficients) and P (scipy CSR, None on the coarsest)."""
+        ip = ctypes.POINTER(ctypes.c_int)
+        for lv in levels:
+            A = lv["A"].tocsr()
+            A.sort_indices()
+            a = (np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32), np.ascontiguousarray(A.data, dtype=np.float64))
+            D = np.ascontiguousarray(lv["D"], dtype=np.float64)
+            coefs = np.ascontiguousarray(lv["coefs"], dtype=np.float64)
+            if lv.get("P") is not None:
+                P = lv["P"].tocsr()
+                P.sort_indices()
+                pp = (np.ascontiguousarray(P.indptr, dtype=np.int32), np.ascontiguousarray(P.indices, dtype=np.int32), np.ascontiguousarray(P.data, dtype=np.float64))
+                pargs = (P.shape[1], pp[0].ctypes.data_as(ip), pp[1].ctypes.data_as(ip), _dp(pp[2]))
+            else:
+                pargs = (0, None, None, None)
+            _H().call("fddh_problem_amg_add_level", self.h, A.shape[0], a[0].ctypes.data_as(ip), a[1].ctypes.data_as(ip), _dp(a[2]), _dp(D), _dp(coefs), len(coefs), *pargs)
+        _H().call("fddh_problem_amg_finalize", self.h)
+
+    def amg_apply(self, r):
+        z = np.zeros(self.n)
+        _H().call("fddh_problem_amg_apply", self.h, _dp(np.ascontiguousarray(r)), _dp(z))
+        return z
+
     def sub_residual_norm(self, r):
         v = ctypes.c_double()
         _H().call("fddh_problem_sub_residual_norm", self.h, _dp(np.ascontiguousarray(r)), ctypes.byref(v))

@@ -1,0 +1,76 @@
+"""Parity of the low-order AMG V-cycle preconditioner (Subdomain::
+low_order_preconditioner, subdomain.tpp:3987-4159) between the product's host
+layer and the oracle, shared by the CPU-shim test and the GPU test.
+
+The hierarchy is the scipy-built stand-in for HYPRE's (support.low_order_
+hierarchy); product and oracle get the same arrays.  Parity of results the
+reference would produce with ITS hierarchy is unpinned: HYPRE is not available.
+
+Tolerances: the V-cycle is SpMV + element-wise kernels; the product applies the
+polynomial as A*(D*w) (device branch, subdomain.tpp:62-67) and a precomputed
+inverse on the coarsest level where the oracle follows the host branch
+(val*D*w; Gaussian elimination per application), so agreement is to rounding:
+1e-11 of the result's max norm.
+"""
+import numpy as np
+
+import support as S
+
+
+def check_amg(p, N, red, outer_solve=True):
+    meshes = [S.ArrayMesh.from_problem(p, lvl) for lvl in range(p.info["num_levels"])]
+    sd = S.OracleSubdomain(None, N, red, meshes=meshes)
+    W = S.OracleWorld([meshes[0]], N)
+    try:
+        dof = p.sub_point_dofs()
+        assert np.array_equal(dof, sd.point_dofs())
+        nd = p.info["sub_num_dofs"]
+        assert nd == sd.num_dofs() == dof.max() + 1
+
+        levels = S.low_order_hierarchy(meshes[0], dof, nd)
+        assert len(levels) >= 2 and levels[0]["A"].shape[0] == nd and levels[-1]["P"] is None
+        p.amg_attach(levels)
+        sd.attach_amg(levels)
+
+        # one application of the V-cycle preconditioner
+        r = S.seeded_uniform(p.n, 5) - 0.5
+        z = p.amg_apply(r)
+        oz = sd.low_order_preconditioner(r)
+        assert np.abs(oz).max() > 0
+        assert np.abs(z - oz).max() <= 1e-11 * np.abs(oz).max()
+        # points without a dof get nothing; the operator is positive on assembled data
+        assert np.all(z[dof < 0] == 0.0)
+        assert float(np.dot(sd.dssum(r), z)) > 0.0
+        # replay (hipGraph on the GPU): same bits as the first application
+        assert np.array_equal(p.amg_apply(r), z)
+
+        # inner solves preconditioned by it
+        p.set_flag("sub_use_preconditioner", 1)
+        for method in ("gmres", "fcg"):
+            zz, hist = p.precond_apply(r, method)
+            ozz, oits, ohist = sd.solve(r, method, use_preconditioner=True)
+            assert len(hist) == len(ohist) == 5, (method, len(hist), len(ohist))
+            assert np.abs(hist - ohist).max() <= 1e-9 * ohist[0], method
+            assert np.abs(zz - ozz).max() <= 1e-9 * np.abs(ozz).max(), method
+            # and it helps: 4 iterations get further than with the plain dssum
+            _, _, plain = sd.solve(r, method, use_preconditioner=False)
+            assert ohist[-1] < plain[-1], (method, ohist[-1], plain[-1])
+
+        if outer_solve:
+            _, f = p.make_rhs_from(S.seeded_uniform(p.n, 1234))
+
+            def pre(zv, rv):
+                out, _, _ = sd.solve(rv[0], "gmres", use_preconditioner=True)
+                zv[0][:] = out
+
+            p.set_options(preconditioner_type=1)
+            u, its, hist = p.solve(f, "fcg")
+            ou, oits, ohist = W.solve([f], "fcg", precond=pre)
+            assert its == oits and len(hist) == len(ohist), (its, oits)
+            assert np.abs(hist - ohist).max() <= 1e-8 * ohist[0]
+            assert np.abs(u - ou[0]).max() <= 1e-8 * np.abs(ou[0]).max()
+            return its
+    finally:
+        sd.close()
+        W.close()
+    return None

@@ -46,6 +46,11 @@ int fdd_stream_destroy(void *s) { (void)s; return 0; }
 int fdd_stream_sync(void *s) { (void)s; return 0; }
 int fdd_device_sync(void) { return 0; }
 
+/* no graphs on the CPU: capture is refused, callers fall back to eager launches */
+int fdd_graph_begin_capture(void *s) { (void)s; snprintf(g_err, sizeof(g_err), "no graph capture in the CPU shim"); return FDD_ERR_UNSUPPORTED; }
+int fdd_graph_end_capture(void *s, void **g) { (void)s; *g = NULL; return FDD_ERR_UNSUPPORTED; }
+int fdd_graph_launch(void *g, void *s) { (void)g; (void)s; return FDD_ERR_UNSUPPORTED; }
+int fdd_graph_destroy(void *g) { (void)g; return 0; }
 int fdd_event_create(void **e) { *e = calloc(1, sizeof(struct timespec)); return 0; }
 int fdd_event_destroy(void *e) { free(e); return 0; }
 int fdd_event_record(void *e, void *s) { (void)s; clock_gettime(CLOCK_MONOTONIC, (struct timespec *)e); return 0; }
@@ -204,6 +209,7 @@ int fdd_amg_main_update_field(double *u, const double *w, const double *D, int n
 int fdd_amg_vector_multiplication(double *uv, const double *u, const double *v, int n, void *s) { (void)s; orc_amg_vector_multiplication(uv, u, v, n); return 0; }
 int fdd_amg_matvec(double *y, const int *p, const int *c, const double *v, const double *x, double a, double b, int n, void *s) { (void)s; orc_amg_matvec(y, p, c, v, x, a, b, n); return 0; }
 int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int n, void *s) { return fdd_sub_inner_product(out, ws, x, y, n, s); }
+int fdd_csr_plan_matvec(const fdd_csr_plan *plan, double *y, const int *p, const int *c, const double *v, const double *x, double a, double b, void *s) { (void)s; orc_amg_matvec(y, p, c, v, x, a, b, plan->num_rows); return 0; }
 
 /* ---- multi-vector forms: the reference's launch-per-vector sequences ---- */
 int fdd_multi_weighted_inner_product(double *out, double *ws, const double *a, const double *const *b, int m, const double *w, int n, void *s)

@@ -114,6 +114,7 @@ def oracle():
         L.orc_world_assembled_inner_product.restype = ctypes.c_double
         L.orc_subdomain_create.restype = vp
         L.orc_subdomain_residual_norm.restype = ctypes.c_double
+        L.orc_amg_create.restype = vp
         _oracle = L
     return _oracle
 
@@ -395,9 +396,44 @@ class OracleSubdomain:
     def residual_norm(self, r):
         return self.L.orc_subdomain_residual_norm(self.s, _p(r))
 
-    def solve(self, f, method="gmres", num_vectors=4, max_iterations=4, tolerance=1e-12):
+    def point_dofs(self):
+        dof = np.zeros(self.num_points, dtype=np.int32)
+        self.L.orc_subdomain_point_dofs(self.s, dof.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        return dof
+
+    def num_dofs(self):
+        return self.L.orc_subdomain_num_dofs(self.s)
+
+    def attach_amg(self, levels, cheby_order=2, num_vcycles=1):
+        """levels as Problem.amg_attach takes them (finest first)."""
+        ip = ctypes.POINTER(ctypes.c_int)
+        self.amg = vp(self.L.orc_amg_create(len(levels), cheby_order, num_vcycles))
+        self._amg_keep = []
+        for l, lv in enumerate(levels):
+            A = lv["A"].tocsr()
+            A.sort_indices()
+            arrs = [np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32), np.ascontiguousarray(A.data, dtype=np.float64),
+                    np.ascontiguousarray(lv["D"], dtype=np.float64), np.ascontiguousarray(lv["coefs"], dtype=np.float64)]
+            if lv.get("P") is not None:
+                P = lv["P"].tocsr()
+                P.sort_indices()
+                parr = [np.ascontiguousarray(P.indptr, dtype=np.int32), np.ascontiguousarray(P.indices, dtype=np.int32), np.ascontiguousarray(P.data, dtype=np.float64)]
+                pargs = (P.shape[1], parr[0].ctypes.data_as(ip), parr[1].ctypes.data_as(ip), _p(parr[2]))
+                arrs += parr
+            else:
+                pargs = (0, None, None, None)
+            self._amg_keep.append(arrs)
+            self.L.orc_amg_set_level(self.amg, l, A.shape[0], arrs[0].ctypes.data_as(ip), arrs[1].ctypes.data_as(ip), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), *pargs)
+        self.L.orc_subdomain_attach_amg(self.s, self.amg)
+
+    def low_order_preconditioner(self, r):
+        z = np.zeros(self.num_values)
+        self.L.orc_subdomain_low_order_preconditioner(self.s, _p(z), _p(np.ascontiguousarray(r)))
+        return z
+
+    def solve(self, f, method="gmres", num_vectors=4, max_iterations=4, tolerance=1e-12, use_preconditioner=False):
         u = np.zeros(self.num_points)
-        opts = OrcSubdomainOpts(num_vectors, max_iterations, tolerance, 0)
+        opts = OrcSubdomainOpts(num_vectors, max_iterations, tolerance, int(use_preconditioner))
         hist = np.zeros(max_iterations + 2)
         nh = ctypes.c_int(0)
         fn = self.L.orc_subdomain_gmres if method == "gmres" else self.L.orc_subdomain_fcg
@@ -409,3 +445,119 @@ def seeded_uniform(n, seed=1234):
     """Seeded stand-in for the reference's unseeded rand()/RAND_MAX RHS
     (domain.tpp:572-573)."""
     return np.random.Generator(np.random.MT19937(seed)).random(n)
+
+
+# --------------------------------------------------------------------------
+# A low-order AMG hierarchy for the inner preconditioner.  The reference gets
+# it from HYPRE BoomerAMG on its low-order FEM matrix (subdomain.tpp:2749-3549);
+# HYPRE is not in this image, so the tests build a geometric-multigrid
+# hierarchy of the same shape with scipy: trilinear FEM on the GLL grid of the
+# subdomain, coarsened by 2 per direction with Galerkin coarse operators,
+# Chebyshev(2) data per level as hypre's ds / coefs arrays hold them.
+# --------------------------------------------------------------------------
+def _fem_1d(xs):
+    import scipy.sparse as sp
+
+    h = np.diff(xs)
+    n = len(xs)
+    K = sp.lil_matrix((n, n))
+    M = sp.lil_matrix((n, n))
+    for e in range(n - 1):
+        K[e, e] += 1 / h[e]; K[e + 1, e + 1] += 1 / h[e]; K[e, e + 1] -= 1 / h[e]; K[e + 1, e] -= 1 / h[e]
+        M[e, e] += h[e] / 2; M[e + 1, e + 1] += h[e] / 2  # lumped: the closest low-order match of the GLL quadrature mass
+    return K.tocsr(), M.tocsr()
+
+
+def _interp_1d(xf, keep):
+    """linear interpolation from the coarse grid xf[keep] to xf"""
+    import scipy.sparse as sp
+
+    xc = xf[keep]
+    P = sp.lil_matrix((len(xf), len(xc)))
+    for i, x in enumerate(xf):
+        j = min(np.searchsorted(xc, x, side="right") - 1, len(xc) - 2) if len(xc) > 1 else 0
+        if len(xc) == 1:
+            P[i, 0] = 1.0
+            continue
+        t = (x - xc[j]) / (xc[j + 1] - xc[j])
+        if abs(t) < 1e-14:
+            P[i, j] = 1.0
+        elif abs(t - 1) < 1e-14:
+            P[i, j + 1] = 1.0
+        else:
+            P[i, j] = 1 - t
+            P[i, j + 1] = t
+    return P.tocsr()
+
+
+def chebyshev_coefs(lmax, lo=0.3, hi=1.1):
+    """degree-1 Chebyshev polynomial p(x) = c0 + c1 x ~ 1/x on [lo, hi]*lmax: two Chebyshev steps"""
+    a, b = lo * lmax, hi * lmax
+    theta, delta = (a + b) / 2, (b - a) / 2
+    den = 2 * theta * theta - delta * delta
+    return np.array([4 * theta / den, -2 / den])
+
+
+def low_order_hierarchy(mesh, point_dof, num_dofs, min_size=30, max_levels=8):
+    """mesh: BoxMesh/ArrayMesh with x, y, z per level-0 point; point_dof: dof per point (-1: none)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    coords = [np.asarray(getattr(mesh, c), dtype=np.float64) for c in ("x", "y", "z")]
+    axes, idx = [], []
+    for c in coords:
+        u, inv = np.unique(np.round(c, 10), return_inverse=True)
+        axes.append(u)
+        idx.append(inv)
+    nx, ny, nz = (len(a) for a in axes)
+    grid_of_point = idx[0] + nx * (idx[1] + ny * idx[2])
+    has = point_dof >= 0
+    grid_of_dof = np.full(num_dofs, -1, dtype=np.int64)
+    grid_of_dof[point_dof[has]] = grid_of_point[has]
+    assert (grid_of_dof >= 0).all()
+    # all points of one dof sit on the same grid node
+    assert (grid_of_dof[point_dof[has]] == grid_of_point[has]).all()
+
+    K, M = zip(*[_fem_1d(a) for a in axes])
+    A_full = (sp.kron(M[2], sp.kron(M[1], K[0])) + sp.kron(M[2], sp.kron(K[1], M[0])) + sp.kron(K[2], sp.kron(M[1], M[0]))).tocsr()
+    active = np.zeros(nx * ny * nz, dtype=bool)
+    active[grid_of_dof] = True
+    A = A_full[grid_of_dof][:, grid_of_dof].tocsr()
+
+    levels = []
+    order = grid_of_dof  # grid node of every dof of the current level, in dof order
+    cur_axes = axes
+    for _ in range(max_levels):
+        n = A.shape[0]
+        D = 1.0 / np.sqrt(A.diagonal())
+        DAD = sp.diags(D) @ A @ sp.diags(D)
+        lmax = float(spla.eigsh(DAD, k=1, which="LA", return_eigenvectors=False, tol=1e-4, v0=np.ones(n))[0]) if n > 2 else float(np.linalg.eigvalsh(DAD.toarray()).max())
+        lv = {"A": A, "D": D, "coefs": chebyshev_coefs(lmax), "P": None}
+        levels.append(lv)
+        if n <= min_size:
+            break
+        keeps = [np.unique(np.r_[np.arange(0, len(a), 2), len(a) - 1]) for a in cur_axes]
+        if all(len(k) == len(a) for k, a in zip(keeps, cur_axes)):
+            break
+        P1 = [_interp_1d(a, k) for a, k in zip(cur_axes, keeps)]
+        P_full = sp.kron(P1[2], sp.kron(P1[1], P1[0])).tocsr()
+        fnx, fny = len(cur_axes[0]), len(cur_axes[1])
+        cnx, cny, cnz = (len(k) for k in keeps)
+        # a coarse node is a dof iff the fine node under it is
+        act_f = np.zeros(P_full.shape[0], dtype=bool)
+        act_f[order] = True
+        ci, cj, ck = np.meshgrid(np.arange(cnx), np.arange(cny), np.arange(cnz), indexing="ij")
+        fine_under = keeps[0][ci] + fnx * (keeps[1][cj] + fny * keeps[2][ck])
+        cgrid = ci + cnx * (cj + cny * ck)
+        sel = act_f[fine_under.ravel()]
+        c_order = np.sort(cgrid.ravel()[sel])
+        if len(c_order) == 0 or len(c_order) == n:
+            break
+        P = P_full[order][:, c_order].tocsr()
+        P.eliminate_zeros()
+        lv["P"] = P
+        A = (P.T @ A @ P).tocsr()
+        A.sort_indices()
+        order = c_order
+        cur_axes = [a[k] for a, k in zip(cur_axes, keeps)]
+    return levels

@@ -1,0 +1,74 @@
+"""GPU parity of the low-order AMG V-cycle preconditioner (SURVEY.md 8 row a14,
+config C5's inner preconditioner) against the oracle, through include/fdd_host.h.
+The checks themselves live in amg_checks.py (shared with the CPU-shim test).
+
+The host layer runs on its own HIP stream here so that the V-cycle goes through
+hipGraph capture + replay (the default stream cannot be captured); a second
+pass with "amg_graph" off runs the same launches eagerly and must give the
+same bits."""
+import numpy as np
+import pytest
+
+import amg_checks
+import support as S
+from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def own_stream(gpu):
+    H.init(0, use_torch_stream=False)
+    H.comm_single()
+    H.set_print(False)
+    yield True
+    H.init(0)  # back to torch's current stream for the other modules
+
+
+def make_problem(E, N, red):
+    p = H.Problem.box(E, (1, 1, 1), N, red, True)
+    for lvl in range(p.info["num_levels"]):
+        p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
+    return p
+
+
+@pytest.mark.parametrize("E,N,red", [((4, 4, 4), 3, 2), ((3, 2, 2), 5, 2)])
+def test_amg_preconditioner_matches_oracle(own_stream, E, N, red):
+    p = make_problem(E, N, red)
+    try:
+        its = amg_checks.check_amg(p, N, red)
+        assert its is not None and its <= 6
+    finally:
+        p.close()
+
+
+def test_graph_replay_equals_eager_launches(own_stream):
+    E, N, red = (4, 4, 4), 3, 2
+    out = []
+    for graph in (1, 0):
+        p = make_problem(E, N, red)
+        try:
+            p.set_flag("amg_graph", graph)
+            m = S.ArrayMesh.from_problem(p)
+            dof = p.sub_point_dofs()
+            p.amg_attach(S.low_order_hierarchy(m, dof, p.info["sub_num_dofs"]))
+            r = S.seeded_uniform(p.n, 9) - 0.5
+            out.append([p.amg_apply(r) for _ in range(3)])
+        finally:
+            p.close()
+    for z in out[0][1:] + out[1]:
+        assert np.array_equal(z, out[0][0])
+
+
+def test_errors(own_stream):
+    p = make_problem((2, 2, 2), 3, 2)
+    try:
+        with pytest.raises(Exception):
+            p.amg_apply(np.zeros(p.n))  # nothing attached
+        m = S.ArrayMesh.from_problem(p)
+        levels = S.low_order_hierarchy(m, p.sub_point_dofs(), p.info["sub_num_dofs"])
+        bad = [dict(levels[1])]
+        with pytest.raises(Exception):
+            p.amg_attach(bad)  # finest level must have the subdomain's dofs
+    finally:
+        p.close()
