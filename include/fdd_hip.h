@@ -162,6 +162,9 @@ int fdd_sub_stiffness_matrix_2(double *Au, const double *const GDu[3], const dou
  * that level's elements; elem_offset[e] (device) is the first point of element
  * e in u / Au / G (NULL => e * (N+1)^3). */
 int fdd_sub_stiffness_matrix(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
+/* The same with the boolean scatter Q of the subdomain fused into the load: u[p] = v[point_dof[p]]
+ * (0 where point_dof[p] < 0), v a vector over the subdomain's dofs (Q v then A, subdomain.tpp:3977-3981 + 3942-3967). */
+int fdd_sub_stiffness_matrix_gather(double *Au, const double *v, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
 
 int fdd_sub_inner_product(double *out, double *ws, const double *u, const double *v, int num_values, void *stream);                                                                                  /* subdomain.okl:103-132 */
 int fdd_sub_weighted_inner_product(double *out, double *ws, const double *u, const double *v, const double *w, int num_values, void *stream);                                                       /* subdomain.okl:134-163, subdomain.tpp:4302,4508 */
@@ -209,6 +212,12 @@ int fdd_multi_weighted_inner_product(double *out, double *ws, const double *a, c
  * vector_vector_addition launches of domain.tpp:817-822,902-907 / subdomain.tpp:4396-4401,4473-4478.
  * coeffs is a HOST array, v a HOST array of device pointers (none may alias q). */
 int fdd_multi_axpy(double *q, const double *coeffs, const double *const *v, int m, int n, void *stream);
+/* y += sign * sum_k coeffs_dev[k] * x_k and out[0] = sum y*y*w of the result, one pass, coefficients read
+ * from device memory (the output of fdd_multi_weighted_inner_product): Gram-Schmidt update + norm with no
+ * host round trip in between (subdomain.tpp:4396-4416). */
+int fdd_multi_axpy_norm2_dev(double *out, double *ws, double *y, const double *coeffs_dev, double sign, const double *const *x, int m, const double *w, int n, void *stream);
+/* au = (1 / sqrt(*norm2_dev)) * u (subdomain.tpp:4457 with the norm still on the device) */
+int fdd_vector_scaling_rsqrt_dev(double *au, const double *norm2_dev, const double *u, int n, void *stream);
 /* out[0] = sum_nodes s*s*w with s = (Qt u)[node]*w[node]: Subdomain::residual_norm
  * (subdomain.tpp:4491-4515: multiply_weight + weighted_inner_product) without the dof vector */
 int fdd_gather_weighted_norm2(double *out, double *ws, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, int num_nodes, void *stream);

@@ -97,6 +97,8 @@ int fddh_problem_set_options(fddh_problem *p, int max_iterations, double toleran
  *   "fused_dssum"              1: one gather-scatter kernel per dssum (default), 0: the Qt / Q SpMV pair
  *   "restructured_inner_solve" 1: inner GMRES with cached assembled vectors, multi-dot / multi-axpy (default),
  *                              0: the reference's launch-by-launch sequence (subdomain.tpp:4309-4489)
+ *   "assembled_inner_solve"    1: inner GMRES on vectors over the dofs, Q fused into the stiffness load, one host
+ *                              synchronisation per step (default); 0: the point-space forms above
  *   "mfma_stiffness"           1: degrees 11..15 apply the stiffness on the fp64 matrix cores (default;
  *                              agrees with the bit-exact kernel to ~1e-15, not bit for bit), 0: scalar fused kernel
  *   "sub_use_preconditioner"   1: the inner solver preconditions with the low-order AMG V-cycle

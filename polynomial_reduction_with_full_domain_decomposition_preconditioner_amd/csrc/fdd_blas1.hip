@@ -88,6 +88,22 @@ struct AxpbyOp // math.okl:21-27
     __device__ void one(long long i) const { uv[i] = alpha * u[i] + beta * v[i]; }
 };
 
+// x = (1 / sqrt(*s2)) * u with the squared norm still on the device
+// (host sequence: alpha = sqrt(s2); vector_scaling(x, 1.0 / alpha, u), subdomain.tpp:4457)
+struct ScaleRsqrtDevOp
+{
+    double *au;
+    const double *u;
+    const double *s2;
+    __device__ void vec2(long long i) const
+    {
+        const double alpha = 1.0 / sqrt(*s2);
+        double2 a = ld2(u, i);
+        st2(au, i, make_double2(alpha * a.x, alpha * a.y));
+    }
+    __device__ void one(long long i) const { au[i] = (1.0 / sqrt(*s2)) * u[i]; }
+};
+
 struct ScaleOp // math.okl:29-35
 {
     double *au;
@@ -396,6 +412,14 @@ int fdd_vector_scaling(double *au, double alpha, const double *u, int n, void *s
     if (n == 0) return 0;
     FDD_REQUIRE(au != nullptr && u != nullptr);
     return launch_ew(ScaleOp{au, u, alpha}, n, fdd_aligned16(au) && fdd_aligned16(u), stream);
+}
+
+int fdd_vector_scaling_rsqrt_dev(double *au, const double *norm2_dev, const double *u, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(au != nullptr && u != nullptr && norm2_dev != nullptr);
+    return launch_ew(ScaleRsqrtDevOp{au, u, norm2_dev}, n, fdd_aligned16(au) && fdd_aligned16(u), stream);
 }
 
 int fdd_dom_initialize_arrays(double *u_k, double *r_k, const double *f, int num_points, void *stream)

@@ -280,6 +280,60 @@ int launch_multi_dot(double *out, double *ws, const double *a, const double *con
     return launch_reduce(op, out, ws, n, al, stream);
 }
 
+// Gram-Schmidt update and the norm of its result in one pass:
+// y += sign * sum_k c[k] * x_k (the arithmetic of fdd_multi_axpy), out = sum y*y*w.
+// The coefficients stay on the device (the output of fdd_multi_weighted_inner_product).
+template <int M>
+struct MultiAxpyNormOp
+{
+    static constexpr int NV = 1;
+    double *y;
+    const double *w, *c;
+    const double *x[M];
+    double sign;
+    __device__ void vec2(long long i, Acc<1> &acc) const
+    {
+        double2 yy = ld2(y, i);
+        const double2 ww = ld2(w, i);
+#pragma unroll
+        for (int k = 0; k < M; k++)
+        {
+            const double ck = sign * c[k];
+            const double2 b = ld2(x[k], i);
+            yy.x = 1.0 * yy.x + ck * b.x;
+            yy.y = 1.0 * yy.y + ck * b.y;
+        }
+        reinterpret_cast<double2 *>(y)[i] = yy;
+        acc.v[0] += yy.x * yy.x * ww.x;
+        acc.v[0] += yy.y * yy.y * ww.y;
+    }
+    __device__ void one(long long i, Acc<1> &acc) const
+    {
+        double v = y[i];
+#pragma unroll
+        for (int k = 0; k < M; k++) v = 1.0 * v + (sign * c[k]) * x[k][i];
+        y[i] = v;
+        acc.v[0] += v * v * w[i];
+    }
+};
+
+template <int M>
+int launch_multi_axpy_norm(double *out, double *ws, double *y, const double *c, double sign, const double *const *x, const double *w, int n, void *stream)
+{
+    MultiAxpyNormOp<M> op;
+    op.y = y;
+    op.w = w;
+    op.c = c;
+    op.sign = sign;
+    bool al = al2(y, w);
+    for (int k = 0; k < M; k++)
+    {
+        op.x[k] = x[k];
+        al = al && fdd_aligned16(x[k]);
+    }
+    return launch_reduce(op, out, ws, n, al, stream);
+}
+
 // ||Qt_w u||^2 in one pass: per assembled node s = (sum_j 1.0*u[col_j]) * w,
 // accumulate s*s*w -- the gather of multiply_weight (csr_matrix.okl:35-48) and
 // the weighted_inner_product (subdomain.okl:134-163) of Subdomain::residual_norm
@@ -398,6 +452,24 @@ int fdd_multi_weighted_inner_product(double *out, double *ws, const double *a, c
     case 6: return launch_multi_dot<6>(out, ws, a, b, w, n, stream);
     case 7: return launch_multi_dot<7>(out, ws, a, b, w, n, stream);
     default: return launch_multi_dot<8>(out, ws, a, b, w, n, stream);
+    }
+}
+
+int fdd_multi_axpy_norm2_dev(double *out, double *ws, double *y, const double *coeffs_dev, double sign, const double *const *x, int m, const double *w, int n, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && ws != nullptr && n >= 0 && m >= 1 && m <= FDD_MULTI_MAX && x != nullptr && coeffs_dev != nullptr);
+    FDD_REQUIRE(n == 0 || (y != nullptr && w != nullptr));
+    for (int k = 0; k < m; k++) FDD_REQUIRE(n == 0 || x[k] != nullptr);
+    switch (m)
+    {
+    case 1: return launch_multi_axpy_norm<1>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
+    case 2: return launch_multi_axpy_norm<2>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
+    case 3: return launch_multi_axpy_norm<3>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
+    case 4: return launch_multi_axpy_norm<4>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
+    case 5: return launch_multi_axpy_norm<5>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
+    case 6: return launch_multi_axpy_norm<6>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
+    case 7: return launch_multi_axpy_norm<7>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
+    default: return launch_multi_axpy_norm<8>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
     }
 }
 

@@ -228,22 +228,42 @@ struct FusedCfg
     static constexpr int slab = n * ld;
 };
 
-template <int n>
-__global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
+// Synchronisation between the LDS phases of one element.  When n*n divides 64
+// an element never straddles a wavefront (n = 2, 4, 8: the headline N = 7), the
+// LDS executes a wave's instructions in order, and no barrier is needed at all:
+// every wave streams its elements independently.  Otherwise a barrier that
+// waits on the LDS counter only -- __syncthreads() would also drain the vector
+// memory counter, i.e. the geometric factors prefetched for the next slab.
+template <bool kWaveLocal>
+__device__ __forceinline__ void element_sync()
+{
+    if (kWaveLocal)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// kGather: u is read through point_dof (u[e,i,j,k] = v[point_dof[...]], 0 where
+// the point has no dof): the boolean scatter Q of Subdomain fused into the load.
+template <int n, bool kGather>
+__global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
 {
     using C = FusedCfg<n>;
     constexpr int nn = C::nn;
     constexpr int n3 = nn * n;
+    constexpr bool kWaveLocal = (64 % nn == 0);
     // D_hat rows/columns a lane needs in every slab live in registers up to
     // n = 8 (4 x 8 doubles); above that they are re-read from LDS per slab.
     constexpr bool kDReg = (n <= 8);
     constexpr int nd = kDReg ? n : 1;
 
     __shared__ double s_D[n * n];
-    __shared__ double s_u[C::epb][C::slab];
-    __shared__ double s_g1[C::epb][C::slab];
-    __shared__ double s_g2[C::epb][C::slab];
-    __shared__ double s_12[C::epb][n3]; // Au_1 + Au_2 per point, until Au_3 is complete
+    __shared__ double s_u[C::epb][n * C::slab];   // the element, rows padded; slab k is reused for Au_1 + Au_2 once consumed
+    __shared__ double s_g[2][2][C::epb][C::slab]; // GDu_1 / GDu_2 of the slab, double buffered: one sync per slab
 
     const int tid = threadIdx.x;
     const int e_loc = tid / nn;
@@ -258,16 +278,39 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
     size_t base = 0;
     if (active) base = elem_offset ? (size_t)elem_offset[elem] : (size_t)elem * n3;
 
-    // this lane's k-column of u (z contraction stays in registers)
+    const int el = active ? e_loc : 0;
+    double *su = s_u[el];
+    const int lpos = i + j * C::ld;
+
+    // this lane's k-column of u: registers for the z contraction, LDS for x and y
     double r_u[n], r_3[n];
+    if (kGather)
+    {
+        int d[n];
+#pragma unroll
+        for (int k = 0; k < n; k++) d[k] = active ? point_dof[base + ij + k * nn] : -1;
+#pragma unroll
+        for (int k = 0; k < n; k++) r_u[k] = (d[k] >= 0) ? u[d[k]] : 0.0;
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0; k < n; k++) r_u[k] = active ? u[base + ij + k * nn] : 0.0;
+    }
+
+    // geometric factors of slab 0; inside the loop slab k+1 is requested before slab k is used
+    double gn[FDD_NUM_GEOM_FACTS];
+#pragma unroll
+    for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) gn[f] = active ? G.g[f][base + ij] : 0.0;
+
 #pragma unroll
     for (int k = 0; k < n; k++)
     {
-        r_u[k] = active ? u[base + ij + k * nn] : 0.0;
         r_3[k] = 0.0;
+        if (active) su[lpos + k * C::slab] = r_u[k];
     }
 
-    __syncthreads();
+    __syncthreads(); // s_D (written across elements) and s_u
 
     double D_i[nd], D_j[nd], Dt_i[nd], Dt_j[nd];
     if (kDReg)
@@ -282,31 +325,19 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
         }
     }
 
-    const int el = active ? e_loc : 0;
-    double *su = s_u[el];
-    double *sg1 = s_g1[el];
-    double *sg2 = s_g2[el];
-    double *s12 = s_12[el];
-
     // The slab loop is deliberately NOT unrolled: unrolled, every D_hat entry
     // becomes loop-invariant register state (> 256 VGPRs and scratch spills).
 #pragma unroll 1
     for (int k = 0; k < n; k++)
     {
-        // geometric factors of this slab: issued first, consumed after the
-        // x/y/z contractions
-        double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0, g4 = 0.0, g5 = 0.0, uk = 0.0;
-        if (active)
+        double g[FDD_NUM_GEOM_FACTS];
+#pragma unroll
+        for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) g[f] = gn[f];
+        if (active && k + 1 < n)
         {
-            const size_t idx = base + ij + k * nn;
-            uk = u[idx]; // L1/L2 hit: the column was just read into r_u
-            g0 = G.g[0][idx];
-            g1 = G.g[1][idx];
-            g2 = G.g[2][idx];
-            g3 = G.g[3][idx];
-            g4 = G.g[4][idx];
-            g5 = G.g[5][idx];
-            su[i + j * C::ld] = uk;
+            const size_t idx = base + ij + (size_t)(k + 1) * nn;
+#pragma unroll
+            for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) gn[f] = G.g[f][idx];
         }
 
         // row k of D_hat: wave-uniform address -> scalar loads, lives in SGPRs
@@ -319,29 +350,30 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
         int io = i, jo = j;
         if (!kDReg) asm volatile("" : "+v"(io), "+v"(jo));
 
-        __syncthreads();
-
+        const double *suk = su + k * C::slab;
         double Du_1 = 0.0, Du_2 = 0.0, Du_3 = 0.0;
 #pragma unroll
         for (int p = 0; p < n; p++)
         {
             const double di = kDReg ? D_i[kDReg ? p : 0] : s_D[p + io * n];
             const double dj = kDReg ? D_j[kDReg ? p : 0] : s_D[p + jo * n];
-            Du_1 += di * su[p + j * C::ld];
-            Du_2 += dj * su[i + p * C::ld];
+            Du_1 += di * suk[p + j * C::ld];
+            Du_2 += dj * suk[i + p * C::ld];
             Du_3 += Dk[p] * r_u[p];
         }
 
-        const double GDu_1 = g0 * Du_1 + g3 * Du_2 + g4 * Du_3;
-        const double GDu_2 = g3 * Du_1 + g1 * Du_2 + g5 * Du_3;
-        const double GDu_3 = g4 * Du_1 + g5 * Du_2 + g2 * Du_3;
+        const double GDu_1 = g[0] * Du_1 + g[3] * Du_2 + g[4] * Du_3;
+        const double GDu_2 = g[3] * Du_1 + g[1] * Du_2 + g[5] * Du_3;
+        const double GDu_3 = g[4] * Du_1 + g[5] * Du_2 + g[2] * Du_3;
 
+        double *sg1 = s_g[k & 1][0][el];
+        double *sg2 = s_g[k & 1][1][el];
         if (active)
         {
-            sg1[i + j * C::ld] = GDu_1;
-            sg2[i + j * C::ld] = GDu_2;
+            sg1[lpos] = GDu_1;
+            sg2[lpos] = GDu_2;
         }
-        __syncthreads();
+        element_sync<kWaveLocal>();
 
         double Au_1 = 0.0, Au_2 = 0.0;
 #pragma unroll
@@ -352,7 +384,9 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
             Au_1 += dti * sg1[p + j * C::ld];
             Au_2 += dtj * sg2[i + p * C::ld];
         }
-        if (active) s12[ij + k * nn] = Au_1 + Au_2;
+        // every lane of the element is past its reads of slab k of s_u (they
+        // precede the sync above): the slot now holds Au_1 + Au_2 of this point
+        if (active) su[lpos + k * C::slab] = Au_1 + Au_2;
 
         // Au_3(i,j,m) += D_hat[m + k*n_x] * GDu_3(i,j,k): the reference's p = k term
 #pragma unroll
@@ -361,23 +395,26 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
 
     if (active)
     {
-        // s12 entries are read back by the lane that wrote them
+        // the s_u slots are read back by the lane that wrote them
 #pragma unroll
-        for (int k = 0; k < n; k++) Au[base + ij + k * nn] = s12[ij + k * nn] + r_3[k];
+        for (int k = 0; k < n; k++) Au[base + ij + k * nn] = su[lpos + k * C::slab] + r_3[k];
     }
 }
 
 template <int n>
-int launch_fused(double *Au, const double *u, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
+int launch_fused(double *Au, const double *u, const int *point_dof, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
 {
     using C = FusedCfg<n>;
     const int grid = (num_elements + C::epb - 1) / C::epb;
-    hipLaunchKernelGGL(fused_stiffness_kernel<n>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, D_hat, G, elem_offset, num_elements);
+    if (point_dof)
+        hipLaunchKernelGGL((fused_stiffness_kernel<n, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, D_hat, G, elem_offset, num_elements);
+    else
+        hipLaunchKernelGGL((fused_stiffness_kernel<n, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, D_hat, G, elem_offset, num_elements);
     FDD_LAUNCH_CHECK();
     return 0;
 }
 
-int fused_dispatch(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+int fused_dispatch(double *Au, const double *u, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
 {
     FDD_REQUIRE(num_elements >= 0);
     if (num_elements == 0) return 0;
@@ -391,21 +428,21 @@ int fused_dispatch(double *Au, const double *u, const double *D_hat, const doubl
 
     switch (poly_degree + 1)
     {
-    case 2: return launch_fused<2>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 3: return launch_fused<3>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 4: return launch_fused<4>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 5: return launch_fused<5>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 6: return launch_fused<6>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 7: return launch_fused<7>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 8: return launch_fused<8>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 9: return launch_fused<9>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 10: return launch_fused<10>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 11: return launch_fused<11>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 12: return launch_fused<12>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 13: return launch_fused<13>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 14: return launch_fused<14>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 15: return launch_fused<15>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 16: return launch_fused<16>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 2: return launch_fused<2>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 3: return launch_fused<3>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 4: return launch_fused<4>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 5: return launch_fused<5>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 6: return launch_fused<6>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 7: return launch_fused<7>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 8: return launch_fused<8>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 9: return launch_fused<9>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 10: return launch_fused<10>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 11: return launch_fused<11>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 12: return launch_fused<12>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 13: return launch_fused<13>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 14: return launch_fused<14>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 15: return launch_fused<15>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 16: return launch_fused<16>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
     default:
         fdd_set_error("fused stiffness kernel supports poly_degree 1..15, got %d (use the two-launch form)", poly_degree);
         return FDD_ERR_UNSUPPORTED;
@@ -463,12 +500,18 @@ int fdd_dom_stiffness_matrix_2(double *Au, const double *const GDu[3], const dou
 
 int fdd_dom_stiffness_matrix(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], int num_elements, int poly_degree, void *stream)
 {
-    return fused_dispatch(Au, u, D_hat, G, nullptr, num_elements, poly_degree, stream);
+    return fused_dispatch(Au, u, nullptr, D_hat, G, nullptr, num_elements, poly_degree, stream);
 }
 
 int fdd_sub_stiffness_matrix(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
 {
-    return fused_dispatch(Au, u, D_hat, G, elem_offset, num_elements, poly_degree, stream);
+    return fused_dispatch(Au, u, nullptr, D_hat, G, elem_offset, num_elements, poly_degree, stream);
+}
+
+int fdd_sub_stiffness_matrix_gather(double *Au, const double *v, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    FDD_REQUIRE(point_dof != nullptr);
+    return fused_dispatch(Au, v, point_dof, D_hat, G, elem_offset, num_elements, poly_degree, stream);
 }
 
 int fdd_sub_stiffness_matrix_1(double *const GDu[3], const double *u, const double *const *D_hat_ptr, const int *offset, const int *vert, const int *level, const int *poly_degree, int num_levels, const double *const G[FDD_NUM_GEOM_FACTS], int num_points, int dim, void *stream)

@@ -425,6 +425,10 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
     {
         if (p->subdomain) p->subdomain->restructured = value != 0;
     }
+    else if (s == "assembled_inner_solve")
+    {
+        if (p->subdomain) p->subdomain->assembled_inner = value != 0;
+    }
     else if (s == "mfma_stiffness")
     {
         for (auto &kv : p->domains) kv.second.mfma_stiffness = value != 0;

@@ -128,6 +128,9 @@ class Subdomain
 
     std::vector<fdd::memory> VA; // assembled (dof-space) copies Qt_w V[i] of the Krylov basis
     fdd::memory qa;              // Qt_w q
+    std::vector<fdd::memory> ZA;  // assembled-space inner solve: preconditioned basis (only with the AMG preconditioner)
+    fdd::memory ua, fa;          // assembled-space inner solve: solution and right-hand side over the dofs
+    fdd::memory point_dof_dev;   // dof of every level-0 point (-1: none): Q as an index array
 
     fdd::memory points_without_dof; // Dirichlet points: empty rows of Q
     int num_points_without_dof = 0;
@@ -279,18 +282,23 @@ class Subdomain
         FDD_CALL(fdd_sub_residual_and_search_update(p.as<double>(), r.as<double>(), z.as<double>(), r1.as<double>(), beta_k, num_values, fdd::dev().stream));
     }
 
-    // subdomain.tpp:3987-4159: z = Q Q_int V(Qt_int Qt r), V = the AMG V-cycle on
-    // the low-order FEM matrix.  The hierarchy comes from HYPRE in the reference
-    // (subdomain.tpp:2749-3705) and is attached from outside here (amg.hpp);
-    // asking for the preconditioner without one is an error, not a silent identity.
-    void low_order_preconditioner(fdd::memory &z, fdd::memory &r)
+    amg::Level &amg_checked()
     {
         if (not amg_hierarchy.ready() or amg_hierarchy.fine_size() != num_dofs)
         {
             fprintf(stderr, "ERROR: Subdomain::use_preconditioner = true needs an attached AMG hierarchy over the %d dofs (amg_add_level / amg_finalize)\n", num_dofs);
             exit(EXIT_FAILURE);
         }
-        amg::Level &fine = amg_hierarchy.levels[0];
+        return amg_hierarchy.levels[0];
+    }
+
+    // subdomain.tpp:3987-4159: z = Q Q_int V(Qt_int Qt r), V = the AMG V-cycle on
+    // the low-order FEM matrix.  The hierarchy comes from HYPRE in the reference
+    // (subdomain.tpp:2749-3705) and is attached from outside here (amg.hpp);
+    // asking for the preconditioner without one is an error, not a silent identity.
+    void low_order_preconditioner(fdd::memory &z, fdd::memory &r)
+    {
+        amg::Level &fine = amg_checked();
         fdd::memory r_sub_l = r.slice(0, subdomain_operator.num_points);
         fdd::memory z_sub_l = z.slice(0, subdomain_operator.num_points);
         subdomain_operator.Qt.multiply(work_dev[0], r_sub_l); // :3996
@@ -340,6 +348,7 @@ class Subdomain
     bool build_tree = true;               // run the degree-tree restrictions as the reference always does
     bool fused_dssum = true;              // gather-scatter kernel instead of the Qt / QQt_int / Q SpMV chain
     bool restructured = true;             // inner GMRES with cached assembled basis, multi-dot / multi-axpy
+    bool assembled_inner = true;          // inner GMRES on vectors over the dofs: Q fused into the stiffness load, no point-space Krylov basis
     bool mfma_stiffness = true;           // N >= 11 element lists on the fp64 matrix cores
     std::vector<DType> residual_history;  // inner history of the last application
 
@@ -448,6 +457,8 @@ class Subdomain
         point_dof.assign(P, -1);
         for (int p = 0; p < P; p++)
             if (tmp[p] > 0.0) point_dof[p] = (int)tmp[p] - 1;
+        point_dof_dev = fdd::dev().malloc<int>(std::max(P, 1));
+        point_dof_dev.copyFrom(point_dof.data(), (size_t)P * sizeof(int));
         {
             std::vector<int> no_dof;
             for (int p = 0; p < P; p++)
@@ -530,10 +541,10 @@ class Subdomain
         q_k = fdd::dev().malloc<DType>(num_values);
         z_k = fdd::dev().malloc<DType>(num_values);
         p_k = fdd::dev().malloc<DType>(num_values);
-        allocate_krylov();
+        allocate_krylov_scalars(); // the point-space Krylov basis is allocated by the solvers that use it
 
         reduce_ws = fdd::dev().malloc<double>(fdd_reduce_workspace_doubles());
-        scalars = fdd::dev().malloc<double>(8);
+        scalars = fdd::dev().malloc<double>(2 * FDD_MULTI_MAX);
 
         // the big boolean matrices' host mirrors are not needed after setup
         subdomain_operator.Q.release_host();
@@ -548,6 +559,11 @@ class Subdomain
         for (int i = 0; i < num_vectors + 1; i++) V[i] = fdd::dev().malloc<DType>(num_values);
         Z.resize(num_vectors);
         for (int i = 0; i < num_vectors; i++) Z[i] = fdd::dev().malloc<DType>(num_values);
+        allocate_krylov_scalars();
+    }
+
+    void allocate_krylov_scalars()
+    {
         H.assign(num_vectors, std::vector<DType>(num_vectors, 0.0));
         c_gmres.assign(num_vectors, 0.0);
         s_gmres.assign(num_vectors, 0.0);
@@ -893,9 +909,245 @@ class Subdomain
         num_iterations += iter;
     }
 
+    // ------------------------------------------------------------------
+    // The same flexible GMRES(m) once more, with every Krylov vector held
+    // ASSEMBLED (one value per dof instead of one per element-local point).
+    // The reference's point-space iteration only ever looks at its vectors
+    // through Qt: the inner products are <Qt u, Qt v> (subdomain.tpp:4277-4307),
+    // the operator is A Q Qt (dssum, then the element stiffness), so with
+    // v~ = Qt v it IS GMRES on Qt A Q in the dof space, and its result is
+    // u = Q u~.  Per step: the element stiffness reads Q z~ through the
+    // point -> dof index array (no dssum pass, no point-space copy), one gather
+    // Qt back to the dofs, then dots / update / norm / scaling on dof vectors
+    // (0.68x the points at N = 7) with the Gram-Schmidt coefficients and the
+    // norm staying on the device: one host synchronisation per step.
+    // Same recurrences and Givens rotations as subdomain.tpp:4309-4489; the
+    // iterates agree with the point-space form to rounding (Qt is applied
+    // before instead of after the linear combinations).
+    // ------------------------------------------------------------------
+    bool can_assemble() const
+    {
+        if (not(subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0 and num_vectors + 1 <= FDD_MULTI_MAX and dim == 3)) return false;
+        for (auto &ll : subdomain_operator.level_lists)
+            if (ll.poly_degree > 15) return false;
+        return true;
+    }
+
+    // q (points) = A_local (Q z~)
+    void stiffness_from_dofs(fdd::memory &q, fdd::memory &za)
+    {
+        for (auto &ll : subdomain_operator.level_lists)
+        {
+            const double n3 = (double)(ll.poly_degree + 1) * (ll.poly_degree + 1) * (ll.poly_degree + 1);
+            if (ll.poly_degree >= 11 and mfma_stiffness)
+            {
+                // the matrix-core kernel streams contiguous elements: scatter first (unit-value SpMV), then apply
+                subdomain_operator.Q.multiply(work_dev[0], za);
+                stiffness_matrix(q, work_dev[0]);
+                return;
+            }
+            fdd::ProfileScope prof("fused_stiffness_kernel<gather>", (60.0 * n3) * ll.num_elements + 8.0 * subdomain_operator.num_extended_dofs);
+            if (ll.contiguous)
+            {
+                const double *Gs[NUM_GEOM_FACTS];
+                for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = subdomain_operator.G_ptrs[g] + ll.first_offset;
+                FDD_CALL(fdd_sub_stiffness_matrix_gather(q.as<double>() + ll.first_offset, za.as<double>(), point_dof_dev.template as<int>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), Gs, nullptr, ll.num_elements, ll.poly_degree, fdd::dev().stream));
+            }
+            else
+                FDD_CALL(fdd_sub_stiffness_matrix_gather(q.as<double>(), za.as<double>(), point_dof_dev.template as<int>(), subdomain_operator.D_hat[ll.level].template as<double>(), subdomain_operator.G_ptrs, ll.elem_offset.template as<int>(), ll.num_elements, ll.poly_degree, fdd::dev().stream));
+        }
+    }
+
+    void gmres_assembled(fdd::memory &u_l, fdd::memory &f_l, bool print_history, bool use_relative)
+    {
+        const int nd = subdomain_operator.num_extended_dofs;
+        const int m = num_vectors;
+        void *stream = fdd::dev().stream;
+        if ((int)VA.size() != m + 1 or not ua.ptr())
+        {
+            for (auto &v : VA) v.free();
+            VA.resize(m + 1);
+            for (auto &v : VA) v = fdd::dev().malloc<DType>(std::max(nd, 1));
+            qa.free();
+            qa = fdd::dev().malloc<DType>(std::max(nd, 1));
+            ua.free();
+            ua = fdd::dev().malloc<DType>(std::max(nd, 1));
+            fa.free();
+            fa = fdd::dev().malloc<DType>(std::max(nd, 1));
+        }
+        if (use_preconditioner and (int)ZA.size() != m)
+        {
+            for (auto &v : ZA) v.free();
+            ZA.resize(m);
+            for (auto &v : ZA) v = fdd::dev().malloc<DType>(std::max(nd, 1));
+        }
+        if ((int)H.size() != m) allocate_krylov_scalars();
+        residual_history.clear();
+        double *sc = scalars.as<double>();
+        double *ws = reduce_ws.as<double>();
+        const double *nw = norm_weight.as<double>();
+
+        auto dot_dofs = [&](double *out_dev, fdd::memory &a, const double *const *b, int count) {
+            fdd::ProfileScope prof("reduce_vec2_kernel<MultiDotW>", 8.0 * nd * (count + 2));
+            FDD_CALL(fdd_multi_weighted_inner_product(out_dev, ws, a.as<double>(), b, count, nw, nd, stream));
+        };
+
+        // f~ = Qt T f (the degree tree runs as in the reference; its level-0 part is the right-hand side)
+        if (build_tree)
+        {
+            tree_operator(f, f_l);
+            gather_weighted(fa, f);
+        }
+        else
+            gather_weighted(fa, f_l);
+        FDD_CALL(fdd_set_to_value(ua.as<double>(), 0.0, nd, 0, stream));
+
+        DType r_norm, r_0_norm;
+        {
+            const double *self[1] = {fa.as<double>()};
+            dot_dofs(sc, fa, self, 1);
+            fetch_scalars(&r_0_norm, 1);
+            r_0_norm = std::sqrt(r_0_norm);
+        }
+        residual_history.push_back(r_0_norm);
+        if (print_history) pstdout("- Iter %3d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", 0, r_0_norm, 1.0);
+
+        bool converged = false;
+        int iter = 0;
+        int j;
+        DType alpha_j, beta_j, gamma_j, gamma_k;
+        std::vector<double> coeffs(m + 2);
+        std::vector<const double *> ptrs(m + 1);
+        fdd::memory *ra = &fa; // assembled residual of the current cycle
+
+        while (iter < max_iterations)
+        {
+            if (iter > 0)
+            {
+                // r~ = f~ - Qt A Q u~
+                stiffness_from_dofs(q_k, ua);
+                gather_weighted(qa, q_k);
+                FDD_CALL(fdd_vector_vector_addition(qa.as<double>(), 1.0, fa.as<double>(), -1.0, qa.as<double>(), nd, stream));
+                const double *self[1] = {qa.as<double>()};
+                dot_dofs(sc, qa, self, 1);
+                fetch_scalars(&r_norm, 1);
+                r_norm = std::sqrt(r_norm);
+                gamma[0] = r_norm;
+                ra = &qa;
+            }
+            else
+            {
+                gamma[0] = r_0_norm;
+            }
+
+            FDD_CALL(fdd_vector_scaling(VA[0].template as<double>(), 1.0 / gamma[0], ra->template as<double>(), nd, stream));
+
+            for (j = 0; j < m; j++)
+            {
+                iter++;
+
+                // z~_j = M^-1 v~_j: the identity on assembled data (dssum), or the AMG V-cycle over the dofs
+                fdd::memory *za = &VA[j];
+                if (use_preconditioner)
+                {
+                    amg::Level &fine = amg_checked();
+                    fine.f.copyFrom(VA[j], (size_t)nd * sizeof(DType));
+                    amg_hierarchy.vcycle();
+                    ZA[j].copyFrom(fine.u, (size_t)nd * sizeof(DType));
+                    za = &ZA[j];
+                }
+
+                stiffness_from_dofs(q_k, *za);
+                gather_weighted(qa, q_k);
+
+                // H[0..j][j] = <q~, v~_i>, q~ -= sum H v~_i, ||q~||^2: coefficients never leave the device in between
+                for (int i = 0; i < j + 1; i++) ptrs[i] = VA[i].template as<double>();
+                dot_dofs(sc, qa, ptrs.data(), j + 1);
+                {
+                    fdd::ProfileScope prof("reduce_vec2_kernel<MultiAxpyNorm>", 8.0 * nd * (j + 4));
+                    FDD_CALL(fdd_multi_axpy_norm2_dev(sc + (j + 1), ws, qa.as<double>(), sc, -1.0, ptrs.data(), j + 1, nw, nd, stream));
+                }
+                // v~_{j+1} = q~ / ||q~||, launched before the host looks at the numbers (unused if this was the last step)
+                if (j + 1 <= m) FDD_CALL(fdd_vector_scaling_rsqrt_dev(VA[j + 1].template as<double>(), sc + (j + 1), qa.as<double>(), nd, stream));
+
+                fetch_scalars(coeffs.data(), j + 2);
+                for (int i = 0; i < j + 1; i++) H[i][j] = coeffs[i];
+                alpha_j = std::sqrt(coeffs[j + 1]);
+
+                for (int i = 0; i < j; i++)
+                {
+                    DType h_ij = H[i][j];
+                    H[i][j] = c_gmres[i] * h_ij + s_gmres[i] * H[i + 1][j];
+                    H[i + 1][j] = -s_gmres[i] * h_ij + c_gmres[i] * H[i + 1][j];
+                }
+
+                if (std::abs(alpha_j) == 0.0)
+                {
+                    converged = true;
+                    break;
+                }
+
+                beta_j = std::sqrt(H[j][j] * H[j][j] + alpha_j * alpha_j);
+                gamma_j = 1.0 / beta_j;
+                c_gmres[j] = H[j][j] * gamma_j;
+                s_gmres[j] = alpha_j * gamma_j;
+                H[j][j] = beta_j;
+                gamma[j + 1] = -s_gmres[j] * gamma[j];
+                gamma[j] = c_gmres[j] * gamma[j];
+
+                r_norm = std::abs(gamma[j + 1]);
+                residual_history.push_back(r_norm);
+                if (print_history) pstdout("- Iter %3d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", iter, r_norm, r_norm / r_0_norm);
+
+                if (use_relative ? (r_norm / r_0_norm < tolerance) : (r_norm < tolerance))
+                {
+                    converged = true;
+                    break;
+                }
+
+                if (iter >= max_iterations)
+                {
+                    converged = true;
+                    break;
+                }
+            }
+
+            if (j == m) j--;
+
+            for (int k = j; k >= 0; k--)
+            {
+                gamma_k = gamma[k];
+                for (int i = j; i > k; i--) gamma_k -= H[k][i] * c_gmres[i];
+                c_gmres[k] = gamma_k / H[k][k];
+            }
+
+            for (int i = 0; i < j + 1; i++)
+            {
+                coeffs[i] = c_gmres[i];
+                ptrs[i] = use_preconditioner ? ZA[i].template as<double>() : VA[i].template as<double>();
+            }
+            {
+                fdd::ProfileScope prof("ew_vec2_kernel<MultiAxpy>", 8.0 * nd * (j + 3));
+                FDD_CALL(fdd_multi_axpy(ua.as<double>(), coeffs.data(), ptrs.data(), j + 1, nd, stream));
+            }
+
+            if (converged) break;
+        }
+
+        // u = Q u~ on the level-0 points (points without a dof get the 0.0 the SpMV writes)
+        fdd::memory u_sub_l = u_l.slice(0, subdomain_operator.num_points);
+        subdomain_operator.Q.multiply(u_sub_l, ua);
+        num_iterations += iter;
+    }
+
     // subdomain.tpp:4309-4489
     void generalized_minimum_residual(fdd::memory &u_l, fdd::memory &f_l, bool print_history = true, bool use_relative = false)
     {
+        if (assembled_inner and can_assemble())
+        {
+            gmres_assembled(u_l, f_l, print_history, use_relative);
+            return;
+        }
         if (restructured and fused_dssum and can_restructure())
         {
             gmres_restructured(u_l, f_l, print_history, use_relative);

@@ -10,6 +10,7 @@
  * (polynomial_..._amd/lib.py) only ever opens libfdd_hip.so and fails loudly
  * without it.  In effect this is the reference's OCCA "Serial" mode.
  */
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -115,6 +116,26 @@ static int fused(double *Au, const double *u, const double *D, const double *con
 }
 int fdd_dom_stiffness_matrix(double *Au, const double *u, const double *D, const double *const G[6], int ne, int N, void *s) { (void)s; return fused(Au, u, D, G, NULL, ne, N); }
 int fdd_sub_stiffness_matrix(double *Au, const double *u, const double *D, const double *const G[6], const int *eo, int ne, int N, void *s) { (void)s; return fused(Au, u, D, G, eo, ne, N); }
+int fdd_sub_stiffness_matrix_gather(double *Au, const double *v, const int *pd, const double *D, const double *const G[6], const int *eo, int ne, int N, void *s)
+{
+    (void)s;
+    int n3 = (N + 1) * (N + 1) * (N + 1);
+    double *u = (double *)malloc(sizeof(double) * (size_t)n3);
+    double *w[3];
+    for (int k = 0; k < 3; k++) w[k] = (double *)malloc(sizeof(double) * (size_t)n3);
+    for (int e = 0; e < ne; e++)
+    {
+        size_t o = eo ? (size_t)eo[e] : (size_t)e * n3;
+        const double *Ge[6];
+        for (int g = 0; g < 6; g++) Ge[g] = G[g] + o;
+        for (int q = 0; q < n3; q++) u[q] = (pd[o + q] >= 0) ? v[pd[o + q]] : 0.0;
+        orc_dom_stiffness_matrix_1(w, u, D, Ge, n3, N, 3);
+        orc_dom_stiffness_matrix_2(Au + o, (const double *const *)w, D, n3, N, 3);
+    }
+    for (int k = 0; k < 3; k++) free(w[k]);
+    free(u);
+    return 0;
+}
 int fdd_stiffness_matrix_mfma(double *Au, const double *u, const double *D, const double *const G[6], const int *eo, int ne, int N, void *s) { (void)s; return fused(Au, u, D, G, eo, ne, N); }
 int fdd_dom_initialize_arrays(double *u, double *r, const double *f, int n, void *s) { (void)s; orc_dom_initialize_arrays(u, r, f, n); return 0; }
 
@@ -215,6 +236,22 @@ int fdd_csr_plan_matvec(const fdd_csr_plan *plan, double *y, const int *p, const
 int fdd_multi_weighted_inner_product(double *out, double *ws, const double *a, const double *const *b, int m, const double *w, int n, void *s)
 {
     for (int k = 0; k < m; k++) fdd_sub_weighted_inner_product(out + k, ws, a, b[k], w, n, s);
+    return 0;
+}
+int fdd_multi_axpy_norm2_dev(double *out, double *ws, double *y, const double *c, double sign, const double *const *x, int m, const double *w, int n, void *s)
+{
+    for (int i = 0; i < n; i++)
+    {
+        double v = y[i];
+        for (int k = 0; k < m; k++) v = 1.0 * v + (sign * c[k]) * x[k][i];
+        y[i] = v;
+    }
+    return fdd_sub_weighted_inner_product(out, ws, y, y, w, n, s);
+}
+int fdd_vector_scaling_rsqrt_dev(double *au, const double *s2, const double *u, int n, void *s)
+{
+    (void)s;
+    orc_vector_scaling(au, 1.0 / sqrt(*s2), u, n);
     return 0;
 }
 int fdd_multi_axpy(double *q, const double *c, const double *const *v, int m, int n, void *s)

@@ -150,6 +150,10 @@ def main():
         u = a
         Au = b
         report(f"stiffness.fused N={N}", 64 * P, timeit(lambda: k("fdd_dom_stiffness_matrix", Au, u, Dh, G, E**3, N)), results)
+        (_, qc0, _), _, _, nodes0 = box_Q(E, N, dev)
+        v_nodes = torch.rand(nodes0, dtype=torch.float64, device=dev)
+        report(f"stiffness.fused+gather N={N}", 60 * P + 8 * nodes0, timeit(lambda: k("fdd_sub_stiffness_matrix_gather", Au, v_nodes, qc0, Dh, G, None, E**3, N)), results)
+        del qc0
         if N >= 8:
             report(f"stiffness.mfma_f64 N={N}", 64 * P, timeit(lambda: k("fdd_stiffness_matrix_mfma", Au, u, Dh, G, None, E**3, N)), results)
         GDu = [c, d, e_]
