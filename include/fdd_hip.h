@@ -56,6 +56,7 @@ int fdd_free(void *ptr);                        /* occa::memory::free() */
 int fdd_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream); /* occa::memory::copyFrom(host): blocking */
 int fdd_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream); /* occa::memory::copyTo(host): blocking */
 int fdd_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream); /* occa::memory::copyFrom/To(mem): async */
+int fdd_fetch_scalars(void *dst, const void *src, size_t bytes, void *stream); /* blocking D2H of <= 4 KiB of reduction results via a pinned staging buffer */
 int fdd_memset(void *dst, int value, size_t bytes, void *stream);
 int fdd_stream_create(void **stream);           /* cudaStreamCreate, subdomain.tpp:3475 */
 int fdd_stream_destroy(void *stream);
@@ -235,6 +236,7 @@ int fdd_dssum_fused(double *QQtu, double *t, const int *Qt_ptr, const int *Qt_co
 int fdd_dssum_gather(double *t, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, int node_start, int node_end, void *stream);      /* t = (Qt u) .* w on a node range */
 int fdd_dssum_scatter(double *QQtu, const double *t, const int *Qt_ptr, const int *Qt_col, const double *point_mask, int node_start, int node_end, void *stream);  /* out = (Q t) .* mask on a node range */
 int fdd_fill_indexed(double *out, const int *idx, double value, int n, void *stream); /* out[idx[i]] = value (points without a dof) */
+int fdd_gather_indexed(double *out, const double *in, const int *index, const double *scale, int n, void *stream); /* out[i] = in[index[i]] * scale[i] (0 where index[i] < 0; scale may be NULL) */
 /* The same three operations on the row blocks of Qt's SpMV plan (unit-value plans only): entries are
  * staged through LDS so that no global access depends on a row length.  mode 0 = gather + scatter,
  * 1 = gather only (t out), 2 = scatter only (t in); nodes [row_lo, row_hi).  Same bits as above. */

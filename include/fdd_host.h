@@ -97,6 +97,9 @@ int fddh_problem_set_options(fddh_problem *p, int max_iterations, double toleran
  *   "fused_dssum"              1: one gather-scatter kernel per dssum (default), 0: the Qt / Q SpMV pair
  *   "restructured_inner_solve" 1: inner GMRES with cached assembled vectors, multi-dot / multi-axpy (default),
  *                              0: the reference's launch-by-launch sequence (subdomain.tpp:4309-4489)
+ *   "assembled_outer_solve"    1: flexible CG on node vectors (one value per assembled node): Q fused into the stiffness
+ *                              load, no dssum pass, the inner solve entered and left in dof numbering (default when the
+ *                              inner solve is the assembled GMRES or there is no preconditioner); 0: point vectors
  *   "assembled_inner_solve"    1: inner GMRES on vectors over the dofs, Q fused into the stiffness load, one host
  *                              synchronisation per step (default); 0: the point-space forms above
  *   "mfma_stiffness"           1: degrees 11..15 apply the stiffness on the fp64 matrix cores (default;

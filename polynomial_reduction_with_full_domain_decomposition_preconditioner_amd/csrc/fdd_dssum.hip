@@ -159,6 +159,19 @@ __global__ __launch_bounds__(kBlock) void fill_indexed_kernel(double *__restrict
     const int stride = gridDim.x * kBlock;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[idx[i]] = value;
 }
+// out[i] = in[index[i]] * scale[i], 0 where index[i] < 0: renumbering between two
+// assembled numberings (domain nodes <-> subdomain dofs) with the stitching weight folded in
+__global__ __launch_bounds__(kBlock) void gather_indexed_kernel(double *__restrict__ out, const double *__restrict__ in, const int *__restrict__ index, const double *__restrict__ scale, int n)
+{
+    const int stride = gridDim.x * kBlock;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const int s = index[i];
+        double v = (s >= 0) ? in[s] : 0.0;
+        if (scale) v *= scale[i];
+        out[i] = v;
+    }
+}
 } // namespace
 
 extern "C" {
@@ -185,6 +198,16 @@ int fdd_dssum_scatter(double *QQtu, const double *t, const int *Qt_ptr, const in
     if (node_end == node_start) return 0;
     FDD_REQUIRE(QQtu != nullptr && t != nullptr && Qt_ptr != nullptr && Qt_col != nullptr);
     return launch<2>(QQtu, const_cast<double *>(t), Qt_ptr, Qt_col, nullptr, nullptr, point_mask, node_start, node_end, stream);
+}
+
+int fdd_gather_indexed(double *out, const double *in, const int *index, const double *scale, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(out != nullptr && in != nullptr && index != nullptr && out != in);
+    hipLaunchKernelGGL(gather_indexed_kernel, dim3(fdd_stream_grid(n, kBlock)), dim3(kBlock), 0, fdd_stream(stream), out, in, index, scale, n);
+    FDD_LAUNCH_CHECK();
+    return 0;
 }
 
 int fdd_fill_indexed(double *out, const int *idx, double value, int n, void *stream)

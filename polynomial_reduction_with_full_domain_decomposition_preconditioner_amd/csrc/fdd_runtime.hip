@@ -87,6 +87,22 @@ int fdd_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
     return 0;
 }
 
+// Device -> host copy of a handful of reduction results (at most 4 KiB) through a
+// pinned staging buffer owned by the library: a pageable destination costs an
+// extra runtime-internal staging hop per call, and the solvers fetch scalars
+// several times per iteration.
+int fdd_fetch_scalars(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (bytes == 0) return 0;
+    FDD_REQUIRE(dst != nullptr && src != nullptr && bytes <= 4096);
+    static thread_local void *staging = nullptr;
+    if (staging == nullptr) FDD_HIP_CHECK(hipHostMalloc(&staging, 4096, hipHostMallocDefault));
+    FDD_HIP_CHECK(hipMemcpyAsync(staging, src, bytes, hipMemcpyDeviceToHost, fdd_stream(stream)));
+    FDD_HIP_CHECK(hipStreamSynchronize(fdd_stream(stream)));
+    memcpy(dst, staging, bytes);
+    return 0;
+}
+
 int fdd_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
 {
     if (bytes == 0) return 0;

@@ -76,7 +76,13 @@ class memory
     // device -> device
     void copyFrom(const memory &src, size_t bytes) { FDD_CALL(fdd_memcpy_d2d(base_, src.base_, bytes, dev().stream)); }
     // device -> host (blocking)
-    void copyTo(void *dst, size_t bytes) const { FDD_CALL(fdd_memcpy_d2h(dst, base_, bytes, dev().stream)); }
+    void copyTo(void *dst, size_t bytes) const
+    {
+        if (bytes <= 256) // reduction results: pinned staging inside the library
+            FDD_CALL(fdd_fetch_scalars(dst, base_, bytes, dev().stream));
+        else
+            FDD_CALL(fdd_memcpy_d2h(dst, base_, bytes, dev().stream));
+    }
     // device -> device
     void copyTo(memory dst, size_t bytes) const { FDD_CALL(fdd_memcpy_d2d(dst.base_, base_, bytes, dev().stream)); }
 

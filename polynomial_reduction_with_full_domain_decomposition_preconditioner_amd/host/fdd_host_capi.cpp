@@ -425,6 +425,10 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
     {
         if (p->subdomain) p->subdomain->restructured = value != 0;
     }
+    else if (s == "assembled_outer_solve")
+    {
+        for (auto &kv : p->domains) kv.second.assembled_outer = value != 0;
+    }
     else if (s == "assembled_inner_solve")
     {
         if (p->subdomain) p->subdomain->assembled_inner = value != 0;
@@ -682,6 +686,7 @@ int fddh_problem_pcg_steps(fddh_problem *p, int steps, double *last_residual)
 int fddh_problem_pcg_solution(fddh_problem *p, double *u)
 {
     if (!p || !u) return fail("null argument");
+    p->fine().fcg_finish();
     p->b.copyTo(u, (size_t)p->fine().num_local_points * sizeof(double));
     return 0;
 }

@@ -129,7 +129,7 @@ class Subdomain
     std::vector<fdd::memory> VA; // assembled (dof-space) copies Qt_w V[i] of the Krylov basis
     fdd::memory qa;              // Qt_w q
     std::vector<fdd::memory> ZA;  // assembled-space inner solve: preconditioned basis (only with the AMG preconditioner)
-    fdd::memory ua, fa;          // assembled-space inner solve: solution and right-hand side over the dofs
+    fdd::memory ua, fa;          // assembled-space inner solve from point vectors: solution and right-hand side over the dofs
     fdd::memory point_dof_dev;   // dof of every level-0 point (-1: none): Q as an index array
 
     fdd::memory points_without_dof; // Dirichlet points: empty rows of Q
@@ -961,19 +961,40 @@ class Subdomain
     void gmres_assembled(fdd::memory &u_l, fdd::memory &f_l, bool print_history, bool use_relative)
     {
         const int nd = subdomain_operator.num_extended_dofs;
+        if (not ua.ptr())
+        {
+            ua = fdd::dev().malloc<DType>(std::max(nd, 1));
+            fa = fdd::dev().malloc<DType>(std::max(nd, 1));
+        }
+        // f~ = Qt T f (the degree tree runs as in the reference; its level-0 part is the right-hand side)
+        if (build_tree)
+        {
+            tree_operator(f, f_l);
+            gather_weighted(fa, f);
+        }
+        else
+            gather_weighted(fa, f_l);
+
+        gmres_dofs(ua, fa, print_history, use_relative);
+
+        // u = Q u~ on the level-0 points (points without a dof get the 0.0 the SpMV writes)
+        fdd::memory u_sub_l = u_l.slice(0, subdomain_operator.num_points);
+        subdomain_operator.Q.multiply(u_sub_l, ua);
+    }
+
+    // the solve itself, dof vectors in and out (callers that already hold assembled data skip Qt / Q)
+    void gmres_dofs(fdd::memory &ua, fdd::memory &fa, bool print_history = true, bool use_relative = false)
+    {
+        const int nd = subdomain_operator.num_extended_dofs;
         const int m = num_vectors;
         void *stream = fdd::dev().stream;
-        if ((int)VA.size() != m + 1 or not ua.ptr())
+        if ((int)VA.size() != m + 1)
         {
             for (auto &v : VA) v.free();
             VA.resize(m + 1);
             for (auto &v : VA) v = fdd::dev().malloc<DType>(std::max(nd, 1));
             qa.free();
             qa = fdd::dev().malloc<DType>(std::max(nd, 1));
-            ua.free();
-            ua = fdd::dev().malloc<DType>(std::max(nd, 1));
-            fa.free();
-            fa = fdd::dev().malloc<DType>(std::max(nd, 1));
         }
         if (use_preconditioner and (int)ZA.size() != m)
         {
@@ -992,14 +1013,6 @@ class Subdomain
             FDD_CALL(fdd_multi_weighted_inner_product(out_dev, ws, a.as<double>(), b, count, nw, nd, stream));
         };
 
-        // f~ = Qt T f (the degree tree runs as in the reference; its level-0 part is the right-hand side)
-        if (build_tree)
-        {
-            tree_operator(f, f_l);
-            gather_weighted(fa, f);
-        }
-        else
-            gather_weighted(fa, f_l);
         FDD_CALL(fdd_set_to_value(ua.as<double>(), 0.0, nd, 0, stream));
 
         DType r_norm, r_0_norm;
@@ -1134,9 +1147,6 @@ class Subdomain
             if (converged) break;
         }
 
-        // u = Q u~ on the level-0 points (points without a dof get the 0.0 the SpMV writes)
-        fdd::memory u_sub_l = u_l.slice(0, subdomain_operator.num_points);
-        subdomain_operator.Q.multiply(u_sub_l, ua);
         num_iterations += iter;
     }
 

@@ -40,6 +40,7 @@ int fdd_malloc(void **ptr, size_t bytes) { *ptr = bytes ? calloc(1, bytes) : NUL
 int fdd_free(void *ptr) { free(ptr); return 0; }
 int fdd_memcpy_h2d(void *d, const void *s, size_t b, void *st) { (void)st; if (b) memmove(d, s, b); return 0; }
 int fdd_memcpy_d2h(void *d, const void *s, size_t b, void *st) { (void)st; if (b) memmove(d, s, b); return 0; }
+int fdd_fetch_scalars(void *d, const void *s, size_t b, void *st) { (void)st; if (b) memmove(d, s, b); return 0; }
 int fdd_memcpy_d2d(void *d, const void *s, size_t b, void *st) { (void)st; if (b) memmove(d, s, b); return 0; }
 int fdd_memset(void *d, int v, size_t b, void *st) { (void)st; if (b) memset(d, v, b); return 0; }
 int fdd_stream_create(void **s) { *s = NULL; return 0; }
@@ -306,6 +307,7 @@ int fdd_dssum_fused(double *out, double *t, const int *p, const int *c, const do
 int fdd_dssum_gather(double *t, const int *p, const int *c, const double *u, const double *w, int n0, int n1, void *s) { (void)s; gather_range(t, p, c, u, w, n0, n1); return 0; }
 int fdd_dssum_scatter(double *out, const double *t, const int *p, const int *c, const double *m, int n0, int n1, void *s) { (void)s; scatter_range(out, t, p, c, m, n0, n1); return 0; }
 int fdd_fill_indexed(double *out, const int *idx, double v, int n, void *s) { (void)s; for (int i = 0; i < n; i++) out[idx[i]] = v; return 0; }
+int fdd_gather_indexed(double *out, const double *in, const int *index, const double *scale, int n, void *s) { (void)s; for (int i = 0; i < n; i++) { double v = index[i] >= 0 ? in[index[i]] : 0.0; if (scale) v *= scale[i]; out[i] = v; } return 0; }
 
 int fdd_csr_plan_dssum(const fdd_csr_plan *plan, double *out, double *t, const int *p, const int *c, const double *u, const double *w, const double *m, int r0, int r1, int mode, void *s)
 {
