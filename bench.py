@@ -91,6 +91,25 @@ def cpu_baseline(args):
     }
 
 
+def pmc_traffic(kernel_key, elements, degree):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
+    (tools/profile_bench.sh: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this
+    same command; FETCH_SIZE doubled on gfx950 per MI355X_MICROARCH.md).  None when the
+    committed counters are for another workload or kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_c2.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        pmc = json.load(fh)
+    if pmc.get("workload") != {"elements_per_gpu": elements, "degree": degree}:
+        return None
+    family, variant = kernel_key.split("<")[0], "true" if "<gather>" in kernel_key else "false"
+    for name, st in pmc["kernels"].items():
+        if name.startswith(family + "<") and (family != "fused_stiffness_kernel" or name.endswith(", %s>" % variant)):
+            return st["hbm_bytes_per_launch"]
+    return None
+
+
 def main():
     args = parse()
     import numpy as np
@@ -168,6 +187,14 @@ def main():
         avg_ms = st["ms"] / st["count"]
         gbps = st["bytes"] / (st["ms"] * 1e-3) / 1e9
         table[name] = {"launches": st["count"], "avg_us": avg_ms * 1e3, "total_ms": st["ms"], "bytes_per_launch": st["bytes"] / st["count"], "GBps": gbps}
+    # the SpMV half of the metric: Q x and Qt x on this problem's matrices (outside the timed region)
+    spmv = {}
+    for which, label in ((0, "Q (scatter, 1 nnz/row)"), (1, "Qt (gather, 1-8 nnz/row)")):
+        us, nbytes = ctypes.c_double(), ctypes.c_double()
+        lib.host().call("fddh_problem_spmv_time", prob.h, which, 20, ctypes.byref(us), ctypes.byref(nbytes))
+        gbps = nbytes.value / (us.value * 1e-6) / 1e9
+        spmv[label] = {"avg_us": us.value, "algorithmic_bytes": nbytes.value, "GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+
     if table:
         dom = max(table, key=lambda k: table[k]["total_ms"])
         roofline = {
@@ -177,7 +204,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": table[dom]["GBps"] / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": pmc_traffic(dom, e, N),
             "launches": table[dom]["launches"],
             "avg_launch_us": table[dom]["avg_us"],
             "algorithmic_bytes_per_launch": table[dom]["bytes_per_launch"],
@@ -210,6 +237,7 @@ def main():
         "last_residual_norm": last_res,
         "setup_s": t_setup,
         "roofline": roofline,
+        "spmv": spmv,
         "kernels": table,
     }
 

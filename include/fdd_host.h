@@ -141,6 +141,11 @@ int fddh_problem_precond_apply(fddh_problem *p, int type, const double *r, doubl
 int fddh_problem_sub_op(fddh_problem *p, int op, const double *in, double *out);
 int fddh_problem_sub_residual_norm(fddh_problem *p, const double *r, double *norm);
 
+/* Average launch time (HIP events on the stream) and algorithmic bytes (12 B per non-zero,
+ * 12 B per row, 8 B per column) of the assembly SpMVs of csr_matrix.okl on the problem's matrices:
+ * which = 0: Q x (scatter), 1: Qt x (gather). */
+int fddh_problem_spmv_time(fddh_problem *p, int which, int iterations, double *avg_us, double *algorithmic_bytes);
+
 /* Stepwise PCG with vectors resident in HBM (what bench.py times): begin sets
  * u = 0, r = f, z = M^-1 r, p = z; each step is one full outer iteration with
  * no stopping test.  last_residual receives ||r|| of the last step. */

