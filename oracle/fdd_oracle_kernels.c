@@ -726,7 +726,8 @@ void orc_amg_matvec(double *y, const int *ptr, const int *col, const double *val
         for (int idx = ptr[row]; idx < ptr[row + 1]; idx++)
             Ax += val[idx] * x[col[idx]];
 
-        y[row] = alpha * Ax + beta * y[row];
+        /* cusparseSpMV does not read y when beta == 0 (AMG/csr_matrix.cpp:129-131) */
+        y[row] = (beta == 0.0) ? alpha * Ax : alpha * Ax + beta * y[row];
     }
 }
 

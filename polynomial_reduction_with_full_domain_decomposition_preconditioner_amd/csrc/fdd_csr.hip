@@ -44,7 +44,8 @@ struct EpiWeight
 struct EpiAxpby // AMG/csr_matrix.cpp:112-134
 {
     double alpha, beta;
-    __device__ double apply(double s, int row, const double *y_old) const { return alpha * s + beta * y_old[row]; }
+    // beta == 0: y is output only (cusparseSpMV semantics), whatever it held is not read
+    __device__ double apply(double s, int row, const double *y_old) const { return (beta == 0.0) ? alpha * s : alpha * s + beta * y_old[row]; }
 };
 
 // Lane-per-row SpMV.  Each lane owns NPT rows (strided by the workgroup size,

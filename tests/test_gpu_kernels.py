@@ -464,6 +464,31 @@ def test_stiffness_fused_bit_exact(gpu, N):
         assert np.array_equal(host(dAu), Au), (N, E)
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 6, 7, 9, 15])
+def test_stiffness_fused_gather_on_load(gpu, N):
+    """fdd_sub_stiffness_matrix_gather: u[p] = v[point_dof[p]] (0 where the point
+    has no dof) fused into the load == scatter on the host, then the oracle's
+    two-kernel arithmetic, bit for bit; contiguous and offset-list element order."""
+    n3 = (N + 1) ** 3
+    for E in (1, 6, 41):
+        _, G, D = stiffness_inputs(E, N, 190 + N)
+        rng = np.random.default_rng(300 + N + E)
+        ndof = max(1, (E * n3) // 3)
+        pd = rng.integers(-1, ndof, E * n3).astype(np.int32)
+        v = rng.uniform(-1, 1, ndof)
+        u = np.where(pd >= 0, v[np.maximum(pd, 0)], 0.0)
+        Au, _ = oracle_stiffness(u, G, D, N, 3)
+        dG = [dev(g, gpu) for g in G]
+        dAu = torch.full((E * n3,), 3.0, dtype=torch.float64, device=gpu)
+        k("fdd_sub_stiffness_matrix_gather", dAu, dev(v, gpu), dev(pd, gpu), dev(D, gpu), dG, None, E, N)
+        assert np.array_equal(host(dAu), Au), (N, E)
+        # the same elements visited through an offset list in reverse order
+        eo = (np.arange(E)[::-1] * n3).astype(np.int32)
+        dAu2 = torch.full((E * n3,), 5.0, dtype=torch.float64, device=gpu)
+        k("fdd_sub_stiffness_matrix_gather", dAu2, dev(v, gpu), dev(pd, gpu), dev(D, gpu), dG, dev(eo, gpu), E, N)
+        assert np.array_equal(host(dAu2), Au), (N, E)
+
+
 @pytest.mark.parametrize("N", [8, 9, 11, 12, 14, 15])
 def test_stiffness_mfma(gpu, N):
     """fp64-MFMA path (config C3, N = 15; lower degrees zero-padded to 16): MFMA
@@ -804,6 +829,130 @@ def test_gather_weighted_norm2(gpu):
     out = torch.zeros(1, dtype=torch.float64, device=gpu)
     k("fdd_gather_weighted_norm2", out, ws, dev(tptr, gpu), dev(tcol, gpu), dev(u, gpu), dev(w, gpu), nodes)
     assert abs(host(out)[0] - ref) <= 1e-13 * ref
+
+
+@pytest.mark.parametrize("m", [1, 2, 4, 8])
+def test_multi_axpy_norm2_with_device_coefficients(gpu, m):
+    """Gram-Schmidt update + norm in one pass: the update is the arithmetic of
+    fdd_multi_axpy with coefficients sign*c[k] read from device memory (bit-exact),
+    the norm is the weighted dot of the result (reduction tolerance)."""
+    L = S.oracle()
+    ws = reduce_workspace(gpu)
+    for n in (1, 1001, 400003):
+        y, w = rnd(n, 50), np.abs(rnd(n, 51))
+        X = [rnd(n, 60 + i) for i in range(m)]
+        c = rnd(m, 52)
+        ref = y.copy()
+        for i in range(m):
+            L.orc_vector_vector_addition(P(ref), ctypes.c_double(1.0), P(ref), ctypes.c_double(-c[i]), P(X[i]), n)
+        nb = (n + 127) // 128
+        block = np.zeros(nb)
+        L.orc_sub_weighted_inner_product(P(block), P(ref), P(ref), P(w), n, nb)
+        norm2 = L.orc_block_sum(P(block), nb)
+        dy = dev(y, gpu)
+        out = torch.zeros(1, dtype=torch.float64, device=gpu)
+        k("fdd_multi_axpy_norm2_dev", out, ws, dy, dev(c, gpu), -1.0, [dev(x, gpu) for x in X], m, dev(w, gpu), n)
+        assert np.array_equal(host(dy), ref)
+        assert abs(host(out)[0] - norm2) <= 1e-13 * norm2
+        # x = (1 / sqrt(norm2_dev)) * y: the host sequence alpha = sqrt(s); scaling by 1.0 / alpha
+        dx = torch.zeros(n, dtype=torch.float64, device=gpu)
+        k("fdd_vector_scaling_rsqrt_dev", dx, out, dy, n)
+        s = host(out)[0]
+        sref = np.zeros(n)
+        L.orc_vector_scaling(P(sref), ctypes.c_double(1.0 / np.sqrt(s)), P(ref), n)
+        assert np.array_equal(host(dx), sref)
+
+
+def test_gather_indexed(gpu):
+    n_in, n_out = 5000, 7001
+    x, sc = rnd(n_in, 70), rnd(n_out, 71)
+    idx = np.random.default_rng(72).integers(-1, n_in, n_out).astype(np.int32)
+    base = np.where(idx >= 0, x[np.maximum(idx, 0)], 0.0)
+    out = torch.full((n_out,), 9.0, dtype=torch.float64, device=gpu)
+    k("fdd_gather_indexed", out, dev(x, gpu), dev(idx, gpu), None, n_out)
+    assert np.array_equal(host(out), base)
+    k("fdd_gather_indexed", out, dev(x, gpu), dev(idx, gpu), dev(sc, gpu), n_out)
+    assert np.array_equal(host(out), base * sc)
+
+
+@pytest.mark.parametrize("shape", ["boolean", "stencil", "dense"])
+def test_csr_plan_matvec_axpby(gpu, shape):
+    """y = alpha*A*x + beta*y on the plan (cusparseSpMV's role in the AMG V-cycle);
+    beta = 0 must not read y (NaN in, numbers out)."""
+    L = S.oracle()
+    rng = np.random.default_rng(80)
+    if shape == "boolean":
+        ptr, col, _ = boolean_gather(3000, 9000, 81)
+        val = np.ones(len(col))
+        rows, cols = 3000, 9000
+    elif shape == "stencil":
+        import scipy.sparse as sp
+
+        m = 17
+        T = sp.diags([1.0, -2.0, 1.0], [-1, 0, 1], shape=(m, m))
+        A = (sp.kron(sp.kron(T, sp.eye(m)), sp.eye(m)) + sp.kron(sp.kron(sp.eye(m), T), sp.eye(m)) + sp.kron(sp.eye(m), sp.kron(sp.eye(m), T))).tocsr()
+        A.sort_indices()
+        ptr, col, val = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+        rows = cols = m**3
+    else:
+        rows = cols = 37
+        ptr = (np.arange(rows + 1) * cols).astype(np.int32)
+        col = np.tile(np.arange(cols), rows).astype(np.int32)
+        val = rng.uniform(-1, 1, rows * cols)
+    x, y0 = rnd(cols, 82), rnd(rows, 83)
+    plan = vp()
+    lib.hip().call("fdd_csr_plan_create", ctypes.byref(plan), vp(ptr.ctypes.data), rows, cols, len(col))
+    try:
+        for alpha, beta in ((1.0, 0.0), (-1.0, 1.0), (1.0, 1.0), (0.5, -2.0)):
+            ref = y0.copy()
+            L.orc_amg_matvec(P(ref), P(ptr), P(col), P(val), P(x), ctypes.c_double(alpha), ctypes.c_double(beta), rows)
+            y_in = np.full(rows, np.nan) if beta == 0.0 else y0
+            dy = dev(y_in, gpu)
+            k("fdd_csr_plan_matvec", plan, dy, dev(ptr, gpu), dev(col, gpu), dev(val, gpu), dev(x, gpu), alpha, beta)
+            assert np.array_equal(host(dy), ref), (shape, alpha, beta)
+    finally:
+        lib.hip().call("fdd_csr_plan_destroy", plan)
+
+
+def test_graph_capture_and_replay(gpu):
+    """fdd_graph_*: a captured launch sequence replays with the same result;
+    the default stream is refused (it cannot be captured)."""
+    L = lib.hip()
+    n = 100003
+    a, b = rnd(n, 90), rnd(n, 91)
+    st = vp()
+    L.call("fdd_stream_create", ctypes.byref(st))
+    da, db, dc = dev(a, gpu), dev(b, gpu), torch.zeros(n, dtype=torch.float64, device=gpu)
+    torch.cuda.synchronize()
+    with pytest.raises(lib.FddError):
+        L.call("fdd_graph_begin_capture", None)
+    L.call("fdd_graph_begin_capture", st)
+    L.call("fdd_vector_vector_addition", vp(dc.data_ptr()), 1.0, vp(da.data_ptr()), 2.0, vp(db.data_ptr()), n, st)
+    L.call("fdd_vector_scaling", vp(dc.data_ptr()), 0.5, vp(dc.data_ptr()), n, st)
+    g = vp()
+    L.call("fdd_graph_end_capture", st, ctypes.byref(g))
+    L.call("fdd_stream_sync", st)
+    assert not host(dc).any()  # capture records, it does not run
+    for _ in range(2):
+        L.call("fdd_graph_launch", g, st)
+        L.call("fdd_stream_sync", st)
+        assert np.array_equal(host(dc), 0.5 * (1.0 * a + 2.0 * b))
+        dc.zero_()
+        torch.cuda.synchronize()
+    L.call("fdd_graph_destroy", g)
+    L.call("fdd_stream_destroy", st)
+
+
+def test_fetch_scalars(gpu):
+    L = lib.hip()
+    a = rnd(32, 95)
+    da = dev(a, gpu)
+    torch.cuda.synchronize()
+    out = np.zeros(32)
+    L.call("fdd_fetch_scalars", P(out), vp(da.data_ptr()), 256, None)
+    assert np.array_equal(out, a)
+    with pytest.raises(lib.FddError):
+        L.call("fdd_fetch_scalars", P(out), vp(da.data_ptr()), 8192, None)
 
 
 # -------------------------------------------------------------- runtime
