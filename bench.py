@@ -104,10 +104,16 @@ def pmc_traffic(kernel_key, elements, degree):
     if pmc.get("workload") != {"elements_per_gpu": elements, "degree": degree}:
         return None
     family, variant = kernel_key.split("<")[0], "true" if "<gather>" in kernel_key else "false"
+    best = None
     for name, st in pmc["kernels"].items():
-        if name.startswith(family + "<") and (family != "fused_stiffness_kernel" or name.endswith(", %s>" % variant)):
-            return st["hbm_bytes_per_launch"]
-    return None
+        if not name.startswith(family + "<"):
+            continue
+        targs = [a.strip() for a in name[len(family) + 1:].rstrip(">").split(",")]
+        if family == "fused_stiffness_kernel" and (len(targs) < 2 or targs[1] != variant):  # <n, kGather, kNTStore>
+            continue
+        if best is None or st["launches"] > best["launches"]:
+            best = st
+    return None if best is None else best["hbm_bytes_per_launch"]
 
 
 def main():

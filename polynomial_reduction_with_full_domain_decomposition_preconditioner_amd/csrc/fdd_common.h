@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <cstdint>
 #include <cstdio>
 
@@ -144,6 +146,13 @@ __device__ __forceinline__ int fdd_xcd_chunked_block(int bid, int nblocks)
     const int xcd = bid % FDD_NUM_XCD;
     const int idx = bid / FDD_NUM_XCD;
     return xcd * per + (xcd < rem ? xcd : rem) + idx;
+}
+
+// integer tuning knob from the environment (read once by the caller: `static const`)
+static inline int fdd_env_int(const char *name, int fallback)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : fallback;
 }
 
 #endif

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double
     for (int it = 0; it < kIts; it++)
     {
         const int k = threadIdx.x + it * kBlock;
-        c[it] = (k < nnz) ? Qt_col[base + k] : 0;
+        c[it] = (k < nnz) ? __builtin_nontemporal_load(Qt_col + base + k) : 0; // the index stream is read once
     }
     if (MODE != 2)
     {

@@ -145,7 +145,12 @@ int launch_reduce(const Op &op, double *out, double *ws, long long n, bool align
     return 0;
 }
 
-__device__ __forceinline__ double2 ld2(const double *p, long long i) { return reinterpret_cast<const double2 *>(p)[i]; }
+typedef double fdd_v2f64 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld2(const double *p, long long i) // non-temporal: read once per launch
+{
+    const fdd_v2f64 v = __builtin_nontemporal_load(reinterpret_cast<const fdd_v2f64 *>(p) + i);
+    return make_double2(v.x, v.y);
+}
 
 struct Dot2Op // subdomain.okl:103-132 / cublasDdot
 {

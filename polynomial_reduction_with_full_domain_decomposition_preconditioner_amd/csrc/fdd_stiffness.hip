@@ -249,7 +249,7 @@ __device__ __forceinline__ void element_sync()
 
 // kGather: u is read through point_dof (u[e,i,j,k] = v[point_dof[...]], 0 where
 // the point has no dof): the boolean scatter Q of Subdomain fused into the load.
-template <int n, bool kGather>
+template <int n, bool kGather, bool kNTStore>
 __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
 {
     using C = FusedCfg<n>;
@@ -265,15 +265,17 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
     __shared__ double s_u[C::epb][n * C::slab];   // the element, rows padded; slab k is reused for Au_1 + Au_2 once consumed
     __shared__ double s_g[2][2][C::epb][C::slab]; // GDu_1 / GDu_2 of the slab, double buffered: one sync per slab
 
+    // n = 8: the element index is the wavefront index.  Telling the compiler so
+    // (readfirstlane) keeps the element base, the `active` test and all array
+    // bases in scalar registers: loads take the SGPR-base + 32-bit lane offset form.
+    constexpr bool kWaveIsElement = (nn == 64);
     const int tid = threadIdx.x;
-    const int e_loc = tid / nn;
+    const int e_loc = kWaveIsElement ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid / nn;
     const int ij = tid - e_loc * nn;
     const int j = ij / n;
     const int i = ij - j * n;
     const int elem = blockIdx.x * C::epb + e_loc;
     const bool active = (e_loc < C::epb) && (elem < num_elements);
-
-    for (int t = tid; t < n * n; t += kBlock) s_D[t] = D_hat[t];
 
     size_t base = 0;
     if (active) base = elem_offset ? (size_t)elem_offset[elem] : (size_t)elem * n3;
@@ -282,32 +284,50 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
     double *su = s_u[el];
     const int lpos = i + j * C::ld;
 
-    // this lane's k-column of u: registers for the z contraction, LDS for x and y
-    double r_u[n], r_3[n];
-    if (kGather)
+    // this lane's k-column of u: registers for the z contraction, LDS for x and y;
+    // geometric factors of the first kPF slabs right behind it (inside the loop slab
+    // k + kPF is requested as soon as slab k's are consumed).  All of it is in
+    // flight before D_hat is staged.
+    constexpr int kPF = 1; // slabs of geometric factors in flight (2 measured no faster at n = 8: the kernel is not latency-bound)
+    double r_u[n], r_3[n], gq[kPF][FDD_NUM_GEOM_FACTS];
+#pragma unroll
+    for (int k = 0; k < n; k++) r_u[k] = 0.0;
+#pragma unroll
+    for (int s = 0; s < kPF; s++)
+#pragma unroll
+        for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) gq[s][f] = 0.0;
+    if (active)
     {
-        int d[n];
+        if (kGather)
+        {
+            const int *pd = point_dof + base;
+            int d[n];
 #pragma unroll
-        for (int k = 0; k < n; k++) d[k] = active ? point_dof[base + ij + k * nn] : -1;
+            for (int k = 0; k < n; k++) d[k] = __builtin_nontemporal_load(pd + (ij + k * nn));
 #pragma unroll
-        for (int k = 0; k < n; k++) r_u[k] = (d[k] >= 0) ? u[d[k]] : 0.0;
-    }
-    else
-    {
+            for (int k = 0; k < n; k++)
+                if (d[k] >= 0) r_u[k] = u[d[k]];
+        }
+        else
+        {
+            const double *up = u + base;
 #pragma unroll
-        for (int k = 0; k < n; k++) r_u[k] = active ? u[base + ij + k * nn] : 0.0;
+            for (int k = 0; k < n; k++) r_u[k] = __builtin_nontemporal_load(up + (ij + k * nn));
+        }
+#pragma unroll
+        for (int s = 0; s < kPF; s++)
+#pragma unroll
+            for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) gq[s][f] = __builtin_nontemporal_load(G.g[f] + base + (ij + s * nn));
     }
 
-    // geometric factors of slab 0; inside the loop slab k+1 is requested before slab k is used
-    double gn[FDD_NUM_GEOM_FACTS];
-#pragma unroll
-    for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) gn[f] = active ? G.g[f][base + ij] : 0.0;
+    for (int t = tid; t < n * n; t += kBlock) s_D[t] = D_hat[t];
 
 #pragma unroll
-    for (int k = 0; k < n; k++)
+    for (int k = 0; k < n; k++) r_3[k] = 0.0;
+    if (active)
     {
-        r_3[k] = 0.0;
-        if (active) su[lpos + k * C::slab] = r_u[k];
+#pragma unroll
+        for (int k = 0; k < n; k++) su[lpos + k * C::slab] = r_u[k];
     }
 
     __syncthreads(); // s_D (written across elements) and s_u
@@ -325,79 +345,97 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
         }
     }
 
-    // The slab loop is deliberately NOT unrolled: unrolled, every D_hat entry
-    // becomes loop-invariant register state (> 256 VGPRs and scratch spills).
+    // The slab loop is deliberately NOT unrolled beyond the prefetch depth:
+    // unrolled, every D_hat entry becomes loop-invariant register state
+    // (> 256 VGPRs and scratch spills).  A wave waits one full HBM latency per
+    // slab unless enough slabs of geometric factors are already requested:
+    // kPF slabs are in flight per lane (12 VGPRs each).
 #pragma unroll 1
-    for (int k = 0; k < n; k++)
+    for (int k0 = 0; k0 < n; k0 += kPF)
     {
-        double g[FDD_NUM_GEOM_FACTS];
 #pragma unroll
-        for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) g[f] = gn[f];
-        if (active && k + 1 < n)
+        for (int s = 0; s < kPF; s++)
         {
-            const size_t idx = base + ij + (size_t)(k + 1) * nn;
+            const int k = k0 + s;
+            if ((n % kPF != 0) && k >= n) continue;
+            // this slot's factors move to g; slab k + kPF is requested into the slot
+            double g[FDD_NUM_GEOM_FACTS];
 #pragma unroll
-            for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) gn[f] = G.g[f][idx];
+            for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) g[f] = gq[s][f];
+            if (active && k + kPF < n)
+            {
+                const int off = ij + (k + kPF) * nn;
+#pragma unroll
+                for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) gq[s][f] = __builtin_nontemporal_load(G.g[f] + base + off);
+            }
+
+            // row k of D_hat: wave-uniform address -> scalar loads, lives in SGPRs
+            double Dk[n];
+#pragma unroll
+            for (int p = 0; p < n; p++) Dk[p] = D_hat[p + k * n];
+
+            // opaque copies of i, j stop the compiler from hoisting the D_hat LDS
+            // reads out of the slab loop when they are not meant to be registers
+            int io = i, jo = j;
+            if (!kDReg) asm volatile("" : "+v"(io), "+v"(jo));
+
+            const double *suk = su + k * C::slab;
+            double Du_1 = 0.0, Du_2 = 0.0, Du_3 = 0.0;
+#pragma unroll
+            for (int p = 0; p < n; p++)
+            {
+                const double di = kDReg ? D_i[kDReg ? p : 0] : s_D[p + io * n];
+                const double dj = kDReg ? D_j[kDReg ? p : 0] : s_D[p + jo * n];
+                Du_1 += di * suk[p + j * C::ld];
+                Du_2 += dj * suk[i + p * C::ld];
+                Du_3 += Dk[p] * r_u[p];
+            }
+
+            const double GDu_1 = g[0] * Du_1 + g[3] * Du_2 + g[4] * Du_3;
+            const double GDu_2 = g[3] * Du_1 + g[1] * Du_2 + g[5] * Du_3;
+            const double GDu_3 = g[4] * Du_1 + g[5] * Du_2 + g[2] * Du_3;
+
+            double *sg1 = s_g[k & 1][0][el];
+            double *sg2 = s_g[k & 1][1][el];
+            if (active)
+            {
+                sg1[lpos] = GDu_1;
+                sg2[lpos] = GDu_2;
+            }
+            element_sync<kWaveLocal>();
+
+            double Au_1 = 0.0, Au_2 = 0.0;
+#pragma unroll
+            for (int p = 0; p < n; p++)
+            {
+                const double dti = kDReg ? Dt_i[kDReg ? p : 0] : s_D[io + p * n];
+                const double dtj = kDReg ? Dt_j[kDReg ? p : 0] : s_D[jo + p * n];
+                Au_1 += dti * sg1[p + j * C::ld];
+                Au_2 += dtj * sg2[i + p * C::ld];
+            }
+            // every lane of the element is past its reads of slab k of s_u (they
+            // precede the sync above): the slot now holds Au_1 + Au_2 of this point
+            if (active) su[lpos + k * C::slab] = Au_1 + Au_2;
+
+            // Au_3(i,j,m) += D_hat[m + k*n_x] * GDu_3(i,j,k): the reference's p = k term
+#pragma unroll
+            for (int m = 0; m < n; m++) r_3[m] += Dk[m] * GDu_3;
         }
-
-        // row k of D_hat: wave-uniform address -> scalar loads, lives in SGPRs
-        double Dk[n];
-#pragma unroll
-        for (int p = 0; p < n; p++) Dk[p] = D_hat[p + k * n];
-
-        // opaque copies of i, j stop the compiler from hoisting the D_hat LDS
-        // reads out of the slab loop when they are not meant to be registers
-        int io = i, jo = j;
-        if (!kDReg) asm volatile("" : "+v"(io), "+v"(jo));
-
-        const double *suk = su + k * C::slab;
-        double Du_1 = 0.0, Du_2 = 0.0, Du_3 = 0.0;
-#pragma unroll
-        for (int p = 0; p < n; p++)
-        {
-            const double di = kDReg ? D_i[kDReg ? p : 0] : s_D[p + io * n];
-            const double dj = kDReg ? D_j[kDReg ? p : 0] : s_D[p + jo * n];
-            Du_1 += di * suk[p + j * C::ld];
-            Du_2 += dj * suk[i + p * C::ld];
-            Du_3 += Dk[p] * r_u[p];
-        }
-
-        const double GDu_1 = g[0] * Du_1 + g[3] * Du_2 + g[4] * Du_3;
-        const double GDu_2 = g[3] * Du_1 + g[1] * Du_2 + g[5] * Du_3;
-        const double GDu_3 = g[4] * Du_1 + g[5] * Du_2 + g[2] * Du_3;
-
-        double *sg1 = s_g[k & 1][0][el];
-        double *sg2 = s_g[k & 1][1][el];
-        if (active)
-        {
-            sg1[lpos] = GDu_1;
-            sg2[lpos] = GDu_2;
-        }
-        element_sync<kWaveLocal>();
-
-        double Au_1 = 0.0, Au_2 = 0.0;
-#pragma unroll
-        for (int p = 0; p < n; p++)
-        {
-            const double dti = kDReg ? Dt_i[kDReg ? p : 0] : s_D[io + p * n];
-            const double dtj = kDReg ? Dt_j[kDReg ? p : 0] : s_D[jo + p * n];
-            Au_1 += dti * sg1[p + j * C::ld];
-            Au_2 += dtj * sg2[i + p * C::ld];
-        }
-        // every lane of the element is past its reads of slab k of s_u (they
-        // precede the sync above): the slot now holds Au_1 + Au_2 of this point
-        if (active) su[lpos + k * C::slab] = Au_1 + Au_2;
-
-        // Au_3(i,j,m) += D_hat[m + k*n_x] * GDu_3(i,j,k): the reference's p = k term
-#pragma unroll
-        for (int m = 0; m < n; m++) r_3[m] += Dk[m] * GDu_3;
     }
 
     if (active)
     {
         // the s_u slots are read back by the lane that wrote them
+        double *Aup = Au + base;
 #pragma unroll
-        for (int k = 0; k < n; k++) Au[base + ij + k * nn] = su[lpos + k * C::slab] + r_3[k];
+        for (int k = 0; k < n; k++)
+        {
+            const double v = su[lpos + k * C::slab] + r_3[k];
+            if (kNTStore)
+                __builtin_nontemporal_store(v, Aup + (ij + k * nn));
+            else
+                Aup[ij + k * nn] = v;
+        }
     }
 }
 
@@ -406,10 +444,15 @@ int launch_fused(double *Au, const double *u, const int *point_dof, const double
 {
     using C = FusedCfg<n>;
     const int grid = (num_elements + C::epb - 1) / C::epb;
-    if (point_dof)
-        hipLaunchKernelGGL((fused_stiffness_kernel<n, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, D_hat, G, elem_offset, num_elements);
+    static const bool nt_store = fdd_env_int("FDD_TUNE_STIFFNESS_NT_STORE", 1) != 0;
+    if (point_dof and nt_store)
+        hipLaunchKernelGGL((fused_stiffness_kernel<n, true, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, D_hat, G, elem_offset, num_elements);
+    else if (point_dof)
+        hipLaunchKernelGGL((fused_stiffness_kernel<n, true, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, D_hat, G, elem_offset, num_elements);
+    else if (nt_store)
+        hipLaunchKernelGGL((fused_stiffness_kernel<n, false, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, D_hat, G, elem_offset, num_elements);
     else
-        hipLaunchKernelGGL((fused_stiffness_kernel<n, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((fused_stiffness_kernel<n, false, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, D_hat, G, elem_offset, num_elements);
     FDD_LAUNCH_CHECK();
     return 0;
 }

@@ -130,6 +130,7 @@ def main():
     a, b, c, d, e_, f = vecs
     ws = reduce_workspace(dev)
     out = torch.zeros(2, dtype=torch.float64, device=dev)
+    out8 = torch.zeros(16, dtype=torch.float64, device=dev)
 
     if want("blas1"):
         report("blas1.set_to_value", 8 * P, timeit(lambda: k("fdd_set_to_value", a, 1.0, P, 0)), results)
@@ -142,6 +143,17 @@ def main():
         report("dot.sub_inner_product", 16 * P, timeit(lambda: k("fdd_sub_inner_product", out, ws, a, b, P)), results)
         report("dot.dom_residual_norm", 24 * P, timeit(lambda: k("fdd_dom_residual_norm", out, ws, a, b, c, P)), results)
         report("dot.dom_projection_inner_products", 32 * P, timeit(lambda: k("fdd_dom_projection_inner_products", out, ws, a, b, c, d, P)), results)
+
+    if want("streams"):
+        # what plain streaming reaches with as many concurrent streams as the stiffness kernel has (7 reads + 1 write)
+        extra = [torch.rand(P, dtype=torch.float64, device=dev) for _ in range(3)]
+        vs = [b, c, d, e_, f] + extra
+        for m in (1, 2, 4, 6, 8):
+            report(f"streams.multi_dot {m + 2}R", 8 * P * (m + 2), timeit(lambda: k("fdd_multi_weighted_inner_product", out8, ws, a, vs[:m], m, vs[-1], P)), results)
+        for m in (1, 2, 4, 6):
+            coef = (ctypes.c_double * m)(*([1e-3] * m))
+            report(f"streams.multi_axpy {m + 1}R+1W", 8 * P * (m + 2), timeit(lambda: k("fdd_multi_axpy", a, coef, vs[:m], m, P)), results)
+        del extra, vs
 
     if want("stiffness"):
         _, w, _ = gll(N)
