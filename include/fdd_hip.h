@@ -219,6 +219,22 @@ int fdd_multi_axpy(double *q, const double *coeffs, const double *const *v, int 
 int fdd_multi_axpy_norm2_dev(double *out, double *ws, double *y, const double *coeffs_dev, double sign, const double *const *x, int m, const double *w, int n, void *stream);
 /* au = (1 / sqrt(*norm2_dev)) * u (subdomain.tpp:4457 with the norm still on the device) */
 int fdd_vector_scaling_rsqrt_dev(double *au, const double *norm2_dev, const double *u, int n, void *stream);
+int fdd_multi_axpy_dev(double *q, const double *coeffs_dev, const double *const *v, int m, int n, void *stream); /* fdd_multi_axpy, coefficients in device memory */
+
+/* Scalar bookkeeping of one restart cycle of the inner flexible GMRES(m) (subdomain.tpp:4396-4477) on the device:
+ * Hessenberg column + Givens rotations + residual recurrence + stopping tests per step, back-substitution at the
+ * end, so that a cycle is enqueued without a host round trip per step.  `state` = fdd_gmres_state_bytes() bytes of
+ * device memory.  A stop is recorded, not acted on: later steps of the cycle run on vectors nobody uses, and
+ * fdd_gmres_fetch reports the columns 0..j_last the reference would have used.
+ *   begin : gamma[0] = sqrt(*norm2_dev) (also the relative-test norm when first_cycle)
+ *   step j: dots_dev[0..j] = <q, v_i>, dots_dev[j+1] = ||q - sum_i h_i v_i||^2
+ *   finish: y = H^-1 gamma on columns 0..j_last; fdd_gmres_coefficients gives the device pointer to y[FDD_MULTI_MAX] */
+size_t fdd_gmres_state_bytes(void);
+int fdd_gmres_begin_dev(void *state, const double *norm2_dev, int first_cycle, void *stream);
+int fdd_gmres_step_dev(void *state, const double *dots_dev, int j, int iterations_before, int max_iterations, double tolerance, int use_relative, void *stream);
+int fdd_gmres_finish_dev(void *state, int m, void *stream);
+int fdd_gmres_fetch(void *state, double *y, double *hist, int *num_hist, int *j_last, int *steps, int *converged, void *stream);
+int fdd_gmres_coefficients(void *state, const double **y_dev);
 /* out[0] = sum_nodes s*s*w with s = (Qt u)[node]*w[node]: Subdomain::residual_norm
  * (subdomain.tpp:4491-4515: multiply_weight + weighted_inner_product) without the dof vector */
 int fdd_gather_weighted_norm2(double *out, double *ws, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, int num_nodes, void *stream);

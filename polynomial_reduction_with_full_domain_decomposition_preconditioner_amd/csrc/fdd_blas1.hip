@@ -284,6 +284,50 @@ int launch_multi_axpy(double *q, const double *coeffs, const double *const *v, i
     return launch_ew(op, n, al, stream);
 }
 
+// the same with the coefficients read from device memory (the output of fdd_gmres_finish_dev)
+template <int M>
+struct MultiAxpyDevOp
+{
+    double *q;
+    const double *v[M];
+    const double *c;
+    __device__ void vec2(long long i) const
+    {
+        double2 x = ld2(q, i);
+#pragma unroll
+        for (int k = 0; k < M; k++)
+        {
+            const double ck = c[k];
+            const double2 b = ld2(v[k], i);
+            x.x = 1.0 * x.x + ck * b.x;
+            x.y = 1.0 * x.y + ck * b.y;
+        }
+        st2(q, i, x);
+    }
+    __device__ void one(long long i) const
+    {
+        double x = q[i];
+#pragma unroll
+        for (int k = 0; k < M; k++) x = 1.0 * x + c[k] * v[k][i];
+        q[i] = x;
+    }
+};
+
+template <int M>
+int launch_multi_axpy_dev(double *q, const double *coeffs_dev, const double *const *v, int n, void *stream)
+{
+    MultiAxpyDevOp<M> op;
+    op.q = q;
+    op.c = coeffs_dev;
+    bool al = fdd_aligned16(q);
+    for (int k = 0; k < M; k++)
+    {
+        op.v[k] = v[k];
+        al = al && fdd_aligned16(v[k]);
+    }
+    return launch_ew(op, n, al, stream);
+}
+
 // ------------------------------------------------------------ AMG/kernels.cu
 struct ScaledResidualOp // AMG/kernels.cu:25-41
 {
@@ -513,6 +557,25 @@ int fdd_multi_axpy(double *q, const double *coeffs, const double *const *v, int 
     case 6: return launch_multi_axpy<6>(q, coeffs, v, n, stream);
     case 7: return launch_multi_axpy<7>(q, coeffs, v, n, stream);
     default: return launch_multi_axpy<8>(q, coeffs, v, n, stream);
+    }
+}
+
+int fdd_multi_axpy_dev(double *q, const double *coeffs_dev, const double *const *v, int m, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0 && m >= 1 && m <= FDD_MULTI_MAX);
+    if (n == 0) return 0;
+    FDD_REQUIRE(q != nullptr && coeffs_dev != nullptr && v != nullptr);
+    for (int k = 0; k < m; k++) FDD_REQUIRE(v[k] != nullptr && v[k] != q);
+    switch (m)
+    {
+    case 1: return launch_multi_axpy_dev<1>(q, coeffs_dev, v, n, stream);
+    case 2: return launch_multi_axpy_dev<2>(q, coeffs_dev, v, n, stream);
+    case 3: return launch_multi_axpy_dev<3>(q, coeffs_dev, v, n, stream);
+    case 4: return launch_multi_axpy_dev<4>(q, coeffs_dev, v, n, stream);
+    case 5: return launch_multi_axpy_dev<5>(q, coeffs_dev, v, n, stream);
+    case 6: return launch_multi_axpy_dev<6>(q, coeffs_dev, v, n, stream);
+    case 7: return launch_multi_axpy_dev<7>(q, coeffs_dev, v, n, stream);
+    default: return launch_multi_axpy_dev<8>(q, coeffs_dev, v, n, stream);
     }
 }
 

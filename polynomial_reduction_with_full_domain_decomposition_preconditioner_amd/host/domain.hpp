@@ -94,6 +94,7 @@ class Domain
     // (see fcg_nodes_* below; built on first use)
     bool nodes_ready = false;
     bool fcg_nodes_active = false;
+    bool fcg_norm_pending = false;
     fdd::memory point_node_dev;           // int[num_local_points]: Q as an index array
     fdd::memory node_mask;                // Dirichlet mask per node
     fdd::memory node_stitch;              // local multiplicity * assembled weight * mask
@@ -226,6 +227,7 @@ class Domain
     bool use_preconditioner = true;
     bool fused_dssum = true; // gather-scatter kernel instead of the reference's Qt / Q SpMV pair
     bool assembled_outer = true; // flexible CG on node vectors (one value per assembled node) when the configuration allows it
+    bool device_scalars = true;  // node-space flexible CG: alpha / beta read by the update kernels from device memory, residual norm fetched late
     bool mfma_stiffness = true; // N >= 11: stiffness on the fp64 matrix cores (not bit-identical; 1e-12 tolerance)
     DType tolerance = 1.0e-07;
     std::vector<DType> residual_history; // what the reference prints per iteration
@@ -668,26 +670,41 @@ class Domain
         FDD_CALL(fdd_sub_stiffness_matrix_gather(q.as<double>(), pn.as<double>(), point_node_dev.as<int>(), D_hat.as<double>(), G_ptrs, nullptr, num_local_elements, poly_degree, fdd::dev().stream));
     }
 
-    // sqrt(<r, QQt r>) (domain.tpp:916-931) from r^ = Qt r: sum_n r^_n * gs(r^)_n * mask_n
-    void node_norm(DType &r_norm, fdd::memory &rn)
+    // sqrt(<r, QQt r>) (domain.tpp:916-931) from r^ = Qt r: sum_n r^_n * gs(r^)_n * mask_n.
+    // Two halves: the reductions (+ all-reduce) are enqueued into scalars[4..5]; the value is
+    // fetched when the host wants it, which may be after more work has been enqueued.
+    void node_norm_enqueue(fdd::memory &rn)
     {
         const int nn = num_local_nodes;
         const int nb = (fdd::comm().size > 1 and num_interface_slots > 0) ? num_bdary_nodes : 0;
-        DType v[2] = {0.0, 0.0};
+        double *out = scalars.as<double>() + 4;
         if (nb > 0)
         {
             nt.copyFrom(rn, (size_t)nb * sizeof(DType));
             gs_add_boundary(nt);
-            FDD_CALL(fdd_dom_residual_norm(scalars.as<double>(), reduce_ws.as<double>(), rn.as<double>(), nt.as<double>(), node_mask.as<double>(), nb, fdd::dev().stream));
-            FDD_CALL(fdd_dom_residual_norm(scalars.as<double>() + 1, reduce_ws.as<double>(), rn.as<double>() + nb, rn.as<double>() + nb, node_mask.as<double>() + nb, nn - nb, fdd::dev().stream));
-            fetch_scalars(v, 2);
+            FDD_CALL(fdd_dom_residual_norm(out, reduce_ws.as<double>(), rn.as<double>(), nt.as<double>(), node_mask.as<double>(), nb, fdd::dev().stream));
+            FDD_CALL(fdd_dom_residual_norm(out + 1, reduce_ws.as<double>(), rn.as<double>() + nb, rn.as<double>() + nb, node_mask.as<double>() + nb, nn - nb, fdd::dev().stream));
         }
         else
         {
-            FDD_CALL(fdd_dom_residual_norm(scalars.as<double>(), reduce_ws.as<double>(), rn.as<double>(), rn.as<double>(), node_mask.as<double>(), nn, fdd::dev().stream));
-            fetch_scalars(v, 1);
+            FDD_CALL(fdd_dom_residual_norm(out, reduce_ws.as<double>(), rn.as<double>(), rn.as<double>(), node_mask.as<double>(), nn, fdd::dev().stream));
+            FDD_CALL(fdd_set_to_value(out + 1, 0.0, 1, 0, fdd::dev().stream));
         }
-        r_norm = std::sqrt(v[0] + v[1]);
+        if (fdd::comm().size > 1) fdd::comm().allreduce_sum(out, 2);
+    }
+
+    DType node_norm_fetch()
+    {
+        DType v[2];
+        fdd::memory tail = scalars.slice(4, 2);
+        tail.copyTo(v, 2 * sizeof(DType));
+        return std::sqrt(v[0] + v[1]);
+    }
+
+    void node_norm(DType &r_norm, fdd::memory &rn)
+    {
+        node_norm_enqueue(rn);
+        r_norm = node_norm_fetch();
     }
 
     // z~ = M^-1 r^ and the stitching (domain.tpp:639-645, 697-706)
@@ -746,6 +763,15 @@ class Domain
         timer.stop("domain.operator_application");
 
         FDD_CALL(fdd_dom_projection_inner_products(scalars.as<double>(), reduce_ws.as<double>(), nz.as<double>(), nr.as<double>(), np.as<double>(), nq.as<double>(), nn, stream));
+        if (device_scalars)
+        {
+            // gamma = scalars[0] (kept for beta), theta = scalars[1]: alpha never visits the host
+            if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>(), 2);
+            FDD_CALL(fdd_dom_solution_and_residual_update_dev(nu.as<double>(), nr1.as<double>(), nr.as<double>(), np.as<double>(), nq.as<double>(), scalars.as<double>(), scalars.as<double>() + 1, nn, stream));
+            node_norm_enqueue(nr1);
+            fcg_norm_pending = true;
+            return std::numeric_limits<DType>::quiet_NaN(); // fcg_nodes_norm() has the value
+        }
         fetch_scalars(values, 2);
         fcg_gamma_k = values[0];
         const DType alpha_k = fcg_gamma_k / values[1];
@@ -758,16 +784,36 @@ class Domain
         return r_norm;
     }
 
+    // the residual norm enqueued by the last fcg_nodes_step_residual (device_scalars mode)
+    DType fcg_nodes_norm()
+    {
+        const DType r_norm = node_norm_fetch();
+        fcg_norm_pending = false;
+        residual_history.push_back(r_norm);
+        rstdout("Iter %2d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", fcg_iter + 1, r_norm, r_norm / fcg_r_0_norm);
+        return r_norm;
+    }
+
     template <typename PType>
     void fcg_nodes_step_direction(PType &subdomain)
     {
         const int nn = num_local_nodes;
         DType theta_k;
         precondition_nodes(nz, nr1, subdomain);
-        FDD_CALL(fdd_dom_inner_product_flexible(scalars.as<double>(), reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
-        fetch_scalars(&theta_k, 1);
-        const DType beta_k = theta_k / fcg_gamma_k;
-        FDD_CALL(fdd_dom_residual_and_search_update(np.as<double>(), nr.as<double>(), nz.as<double>(), nr1.as<double>(), beta_k, nn, fdd::dev().stream));
+        if (device_scalars)
+        {
+            // beta = scalars[2] / scalars[0] (theta / gamma), read by the update kernel
+            FDD_CALL(fdd_dom_inner_product_flexible(scalars.as<double>() + 2, reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
+            if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>() + 2, 1);
+            FDD_CALL(fdd_dom_residual_and_search_update_dev(np.as<double>(), nr.as<double>(), nz.as<double>(), nr1.as<double>(), scalars.as<double>() + 2, scalars.as<double>(), nn, fdd::dev().stream));
+        }
+        else
+        {
+            FDD_CALL(fdd_dom_inner_product_flexible(scalars.as<double>(), reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
+            fetch_scalars(&theta_k, 1);
+            const DType beta_k = theta_k / fcg_gamma_k;
+            FDD_CALL(fdd_dom_residual_and_search_update(np.as<double>(), nr.as<double>(), nz.as<double>(), nr1.as<double>(), beta_k, nn, fdd::dev().stream));
+        }
         num_iterations++;
         fcg_iter++;
     }
@@ -878,6 +924,16 @@ class Domain
     DType fcg_step(PType &subdomain)
     {
         DType r_norm = fcg_step_residual();
+        if (fcg_norm_pending)
+        {
+            // the norm's reductions are in the queue; the preconditioner is enqueued behind them
+            // before the host waits for the value (the inner solve synchronises at its end anyway)
+            fcg_step_direction(subdomain);
+            fcg_iter--; // the history line belongs to the iteration just counted
+            r_norm = fcg_nodes_norm();
+            fcg_iter++;
+            return r_norm;
+        }
         fcg_step_direction(subdomain);
         return r_norm;
     }
@@ -889,20 +945,33 @@ class Domain
 
         for (int iter = 0; iter < max_iterations; iter++)
         {
-            const DType r_norm = fcg_step_residual();
-
-            if (use_relative)
+            DType r_norm = fcg_step_residual();
+            bool direction_done = false;
+            if (fcg_norm_pending)
             {
-                if (r_norm / fcg_r_0_norm < tolerance) break;
+                // device_scalars: the second half of the iteration is enqueued before the host reads
+                // the norm.  If the tests below stop the solve, that half was speculative: it touched
+                // z, p, r only, never the solution, and its iteration count is taken back.
+                fcg_step_direction(subdomain);
+                direction_done = true;
+                fcg_iter--;
+                r_norm = fcg_nodes_norm();
+                fcg_iter++;
             }
-            else
+
+            bool stop = use_relative ? (r_norm / fcg_r_0_norm < tolerance) : (r_norm < tolerance);
+            if (std::isnan(r_norm)) stop = true;
+            if (stop)
             {
-                if (r_norm < tolerance) break;
+                if (direction_done)
+                {
+                    num_iterations--;
+                    fcg_iter--;
+                }
+                break;
             }
 
-            if (std::isnan(r_norm)) break;
-
-            fcg_step_direction(subdomain);
+            if (not direction_done) fcg_step_direction(subdomain);
         }
         fcg_finish();
     }

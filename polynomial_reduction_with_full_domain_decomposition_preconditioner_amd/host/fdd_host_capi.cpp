@@ -429,6 +429,11 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
     {
         for (auto &kv : p->domains) kv.second.assembled_outer = value != 0;
     }
+    else if (s == "device_bookkeeping")
+    {
+        if (p->subdomain) p->subdomain->device_bookkeeping = value != 0;
+        for (auto &kv : p->domains) kv.second.device_scalars = value != 0;
+    }
     else if (s == "assembled_inner_solve")
     {
         if (p->subdomain) p->subdomain->assembled_inner = value != 0;

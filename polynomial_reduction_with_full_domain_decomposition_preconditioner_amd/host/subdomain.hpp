@@ -131,6 +131,7 @@ class Subdomain
     std::vector<fdd::memory> ZA;  // assembled-space inner solve: preconditioned basis (only with the AMG preconditioner)
     fdd::memory ua, fa;          // assembled-space inner solve from point vectors: solution and right-hand side over the dofs
     fdd::memory point_dof_dev;   // dof of every level-0 point (-1: none): Q as an index array
+    fdd::memory gmres_state;     // device-side GMRES bookkeeping (fdd_gmres_*_dev)
 
     fdd::memory points_without_dof; // Dirichlet points: empty rows of Q
     int num_points_without_dof = 0;
@@ -349,6 +350,7 @@ class Subdomain
     bool fused_dssum = true;              // gather-scatter kernel instead of the Qt / QQt_int / Q SpMV chain
     bool restructured = true;             // inner GMRES with cached assembled basis, multi-dot / multi-axpy
     bool assembled_inner = true;          // inner GMRES on vectors over the dofs: Q fused into the stiffness load, no point-space Krylov basis
+    bool device_bookkeeping = true;       // assembled inner GMRES: Givens / stopping tests in one-thread kernels, one host sync per cycle
     bool mfma_stiffness = true;           // N >= 11 element lists on the fp64 matrix cores
     std::vector<DType> residual_history;  // inner history of the last application
 
@@ -994,9 +996,132 @@ class Subdomain
         subdomain_operator.Q.multiply(u_sub_l, ua);
     }
 
+    // The same solve with the scalar bookkeeping (Hessenberg column, Givens rotations,
+    // residual recurrence, stopping tests, back-substitution) in one-thread kernels
+    // (fdd_gmres_*_dev): a whole restart cycle is enqueued back to back and the host
+    // synchronises ONCE per cycle, to read the history and the stopping column.  A stop
+    // inside a cycle is recorded, not acted on: the remaining steps run on vectors
+    // nobody uses and the update takes the columns the reference would have taken.
+    void gmres_dofs_device(fdd::memory &ua, fdd::memory &fa, bool print_history, bool use_relative)
+    {
+        const int nd = subdomain_operator.num_extended_dofs;
+        const int m = num_vectors;
+        void *stream = fdd::dev().stream;
+        if ((int)VA.size() != m + 1)
+        {
+            for (auto &v : VA) v.free();
+            VA.resize(m + 1);
+            for (auto &v : VA) v = fdd::dev().malloc<DType>(std::max(nd, 1));
+            qa.free();
+            qa = fdd::dev().malloc<DType>(std::max(nd, 1));
+        }
+        if (use_preconditioner and (int)ZA.size() != m)
+        {
+            for (auto &v : ZA) v.free();
+            ZA.resize(m);
+            for (auto &v : ZA) v = fdd::dev().malloc<DType>(std::max(nd, 1));
+        }
+        if (not gmres_state.ptr()) gmres_state = fdd::dev().malloc<char>(fdd_gmres_state_bytes());
+        residual_history.clear();
+        double *sc = scalars.as<double>();
+        double *ws = reduce_ws.as<double>();
+        const double *nw = norm_weight.as<double>();
+        void *st = gmres_state.ptr();
+        const double *y_dev = nullptr;
+        FDD_CALL(fdd_gmres_coefficients(st, &y_dev));
+
+        auto dot_dofs = [&](double *out_dev, fdd::memory &a, const double *const *b, int count) {
+            fdd::ProfileScope prof("reduce_vec2_kernel<MultiDotW>", 8.0 * nd * (count + 2));
+            FDD_CALL(fdd_multi_weighted_inner_product(out_dev, ws, a.as<double>(), b, count, nw, nd, stream));
+        };
+
+        FDD_CALL(fdd_set_to_value(ua.as<double>(), 0.0, nd, 0, stream));
+
+        int iter = 0;
+        bool first_cycle = true;
+        std::vector<const double *> ptrs(m + 1);
+        std::vector<double> hist(FDD_MULTI_MAX + 1);
+        fdd::memory *ra = &fa;
+
+        while (iter < max_iterations)
+        {
+            if (not first_cycle)
+            {
+                // r~ = f~ - Qt A Q u~
+                stiffness_from_dofs(q_k, ua);
+                gather_weighted(qa, q_k);
+                FDD_CALL(fdd_vector_vector_addition(qa.as<double>(), 1.0, fa.as<double>(), -1.0, qa.as<double>(), nd, stream));
+                ra = &qa;
+            }
+            {
+                const double *self[1] = {ra->template as<double>()};
+                dot_dofs(sc, *ra, self, 1);
+            }
+            FDD_CALL(fdd_gmres_begin_dev(st, sc, first_cycle ? 1 : 0, stream));
+            FDD_CALL(fdd_vector_scaling_rsqrt_dev(VA[0].template as<double>(), sc, ra->template as<double>(), nd, stream)); // V0 = r / gamma_0
+
+            for (int j = 0; j < m; j++)
+            {
+                fdd::memory *za = &VA[j];
+                if (use_preconditioner)
+                {
+                    amg::Level &fine = amg_checked();
+                    fine.f.copyFrom(VA[j], (size_t)nd * sizeof(DType));
+                    amg_hierarchy.vcycle();
+                    ZA[j].copyFrom(fine.u, (size_t)nd * sizeof(DType));
+                    za = &ZA[j];
+                }
+                stiffness_from_dofs(q_k, *za);
+                gather_weighted(qa, q_k);
+
+                // the scalar slots alternate so that step j+1's reductions never overwrite what step j's bookkeeping reads
+                double *slot = sc + (j & 1) * FDD_MULTI_MAX;
+                for (int i = 0; i < j + 1; i++) ptrs[i] = VA[i].template as<double>();
+                dot_dofs(slot, qa, ptrs.data(), j + 1);
+                {
+                    fdd::ProfileScope prof("reduce_vec2_kernel<MultiAxpyNorm>", 8.0 * nd * (j + 4));
+                    FDD_CALL(fdd_multi_axpy_norm2_dev(slot + (j + 1), ws, qa.as<double>(), slot, -1.0, ptrs.data(), j + 1, nw, nd, stream));
+                }
+                FDD_CALL(fdd_gmres_step_dev(st, slot, j, iter, max_iterations, tolerance, use_relative ? 1 : 0, stream));
+                FDD_CALL(fdd_vector_scaling_rsqrt_dev(VA[j + 1].template as<double>(), slot + (j + 1), qa.as<double>(), nd, stream));
+            }
+            FDD_CALL(fdd_gmres_finish_dev(st, m, stream));
+
+            // the one synchronisation of the cycle
+            int nh = 0, j_last = -1, steps = 0, converged = 0;
+            FDD_CALL(fdd_gmres_fetch(st, nullptr, hist.data(), &nh, &j_last, &steps, &converged, stream));
+            if (first_cycle)
+            {
+                residual_history.push_back(hist[0]);
+                if (print_history) pstdout("- Iter %3d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", 0, hist[0], 1.0);
+            }
+            for (int k = 1; k < nh; k++)
+            {
+                residual_history.push_back(hist[k]);
+                if (print_history) pstdout("- Iter %3d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", iter + k, hist[k], hist[k] / residual_history[0]);
+            }
+            iter += steps;
+
+            for (int i = 0; i < j_last + 1; i++) ptrs[i] = use_preconditioner ? ZA[i].template as<double>() : VA[i].template as<double>();
+            if (j_last >= 0)
+            {
+                fdd::ProfileScope prof("ew_vec2_kernel<MultiAxpy>", 8.0 * nd * (j_last + 3));
+                FDD_CALL(fdd_multi_axpy_dev(ua.as<double>(), y_dev, ptrs.data(), j_last + 1, nd, stream));
+            }
+            first_cycle = false;
+            if (converged) break;
+        }
+        num_iterations += iter;
+    }
+
     // the solve itself, dof vectors in and out (callers that already hold assembled data skip Qt / Q)
     void gmres_dofs(fdd::memory &ua, fdd::memory &fa, bool print_history = true, bool use_relative = false)
     {
+        if (device_bookkeeping and num_vectors + 2 <= FDD_MULTI_MAX)
+        {
+            gmres_dofs_device(ua, fa, print_history, use_relative);
+            return;
+        }
         const int nd = subdomain_operator.num_extended_dofs;
         const int m = num_vectors;
         void *stream = fdd::dev().stream;

@@ -324,3 +324,112 @@ int fdd_csr_plan_gather_weighted_norm2(const fdd_csr_plan *plan, double *out, do
 /* ---- interface exchange ---- */
 int fdd_interface_pack(double *slots, const int *slot_of, const double *prefix, int n, void *s) { (void)s; for (int i = 0; i < n; i++) slots[slot_of[i]] = prefix[i]; return 0; }
 int fdd_interface_unpack(double *prefix, const double *slots, const int *slot_of, int n, void *s) { (void)s; for (int i = 0; i < n; i++) prefix[i] = slots[slot_of[i]]; return 0; }
+
+/* ---- device-side GMRES bookkeeping (csrc/fdd_krylov.hip), same statements on the host ---- */
+#define KMAX FDD_MULTI_MAX
+typedef struct
+{
+    double H[KMAX][KMAX];
+    double c[KMAX], s[KMAX], gamma[KMAX + 1];
+    double y[KMAX];
+    double hist[KMAX + 1];
+    double r0, num_hist, stopped, j_last, steps, converged;
+} shim_gmres_state;
+
+size_t fdd_gmres_state_bytes(void) { return sizeof(shim_gmres_state); }
+
+int fdd_gmres_begin_dev(void *state, const double *norm2, int first_cycle, void *s)
+{
+    (void)s;
+    shim_gmres_state *st = (shim_gmres_state *)state;
+    double g0 = sqrt(*norm2);
+    st->gamma[0] = g0;
+    if (first_cycle) st->r0 = g0;
+    st->hist[0] = g0;
+    st->num_hist = 1.0;
+    st->stopped = 0.0;
+    st->j_last = -1.0;
+    st->steps = 0.0;
+    st->converged = 0.0;
+    for (int k = 0; k < KMAX; k++) st->y[k] = 0.0;
+    return 0;
+}
+
+int fdd_gmres_step_dev(void *state, const double *dots, int j, int iterations_before, int max_iterations, double tolerance, int use_relative, void *s)
+{
+    (void)s;
+    shim_gmres_state *st = (shim_gmres_state *)state;
+    if (st->stopped != 0.0) return 0;
+    st->steps += 1.0;
+    int iter = iterations_before + (int)st->steps;
+    for (int i = 0; i < j + 1; i++) st->H[i][j] = dots[i];
+    for (int i = 0; i < j; i++)
+    {
+        double h_ij = st->H[i][j];
+        st->H[i][j] = st->c[i] * h_ij + st->s[i] * st->H[i + 1][j];
+        st->H[i + 1][j] = -st->s[i] * h_ij + st->c[i] * st->H[i + 1][j];
+    }
+    double alpha_j = sqrt(dots[j + 1]);
+    st->j_last = (double)j;
+    if (fabs(alpha_j) == 0.0)
+    {
+        st->stopped = 1.0;
+        st->converged = 1.0;
+        return 0;
+    }
+    double beta_j = sqrt(st->H[j][j] * st->H[j][j] + alpha_j * alpha_j);
+    double gamma_j = 1.0 / beta_j;
+    st->c[j] = st->H[j][j] * gamma_j;
+    st->s[j] = alpha_j * gamma_j;
+    st->H[j][j] = beta_j;
+    st->gamma[j + 1] = -st->s[j] * st->gamma[j];
+    st->gamma[j] = st->c[j] * st->gamma[j];
+    double r_norm = fabs(st->gamma[j + 1]);
+    st->hist[(int)st->num_hist] = r_norm;
+    st->num_hist += 1.0;
+    int small = use_relative ? (r_norm / st->r0 < tolerance) : (r_norm < tolerance);
+    if (small || iter >= max_iterations)
+    {
+        st->stopped = 1.0;
+        st->converged = 1.0;
+    }
+    return 0;
+}
+
+int fdd_gmres_finish_dev(void *state, int m, void *s)
+{
+    (void)s;
+    shim_gmres_state *st = (shim_gmres_state *)state;
+    int j = (int)st->j_last;
+    if (st->stopped == 0.0) j = m - 1;
+    st->j_last = (double)j;
+    for (int k = j; k >= 0; k--)
+    {
+        double gamma_k = st->gamma[k];
+        for (int i = j; i > k; i--) gamma_k -= st->H[k][i] * st->c[i];
+        st->c[k] = gamma_k / st->H[k][k];
+    }
+    for (int k = 0; k < KMAX; k++) st->y[k] = (k <= j) ? st->c[k] : 0.0;
+    return 0;
+}
+
+int fdd_gmres_fetch(void *state, double *y, double *hist, int *num_hist, int *j_last, int *steps, int *converged, void *s)
+{
+    (void)s;
+    shim_gmres_state *st = (shim_gmres_state *)state;
+    if (y) memcpy(y, st->y, sizeof(st->y));
+    if (hist) memcpy(hist, st->hist, sizeof(double) * (size_t)st->num_hist);
+    if (num_hist) *num_hist = (int)st->num_hist;
+    if (j_last) *j_last = (int)st->j_last;
+    if (steps) *steps = (int)st->steps;
+    if (converged) *converged = (int)st->converged;
+    return 0;
+}
+
+int fdd_gmres_coefficients(void *state, const double **y_dev)
+{
+    *y_dev = ((shim_gmres_state *)state)->y;
+    return 0;
+}
+
+int fdd_multi_axpy_dev(double *q, const double *c, const double *const *v, int m, int n, void *s) { return fdd_multi_axpy(q, c, v, m, n, s); }

@@ -198,23 +198,27 @@ def test_reference_shaped_and_restructured_paths_agree(setup):
     inner GMRES entirely on dof vectors) give the same solve: bit-identical
     where only bit-exact kernels changed, within reduction rounding otherwise."""
     out = {}
-    for fused, restructured, assembled, outer in ((0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 0), (1, 1, 1, 1)):
+    for fused, restructured, assembled, outer, dev_book in ((0, 0, 0, 0, 0), (1, 0, 0, 0, 0), (1, 1, 0, 0, 0), (1, 1, 1, 0, 0), (1, 1, 1, 1, 0), (1, 1, 1, 1, 1)):
         p = make_problem(E1, N1, RED1, True)
         p.set_flag("fused_dssum", fused)
         p.set_flag("restructured_inner_solve", restructured)
         p.set_flag("assembled_inner_solve", assembled)
         p.set_flag("assembled_outer_solve", outer)
+        p.set_flag("device_bookkeeping", dev_book)
         _, f = p.make_rhs_from(S.seeded_uniform(p.n, 1234))
         r = S.seeded_uniform(p.n, 5) - 0.5
-        out[(fused, restructured, assembled, outer)] = (p.solve(f, "fcg"), p.precond_apply(r, "gmres"), p.dssum(r, True, True), p.sub_op("dssum", r))
+        out[(fused, restructured, assembled, outer, dev_book)] = (p.solve(f, "fcg"), p.precond_apply(r, "gmres"), p.dssum(r, True, True), p.sub_op("dssum", r))
         p.close()
-    ref, fus, res, asm, nod = out[(0, 0, 0, 0)], out[(1, 0, 0, 0)], out[(1, 1, 0, 0)], out[(1, 1, 1, 0)], out[(1, 1, 1, 1)]
+    ref, fus, res, asm, nod, dbk = out[(0, 0, 0, 0, 0)], out[(1, 0, 0, 0, 0)], out[(1, 1, 0, 0, 0)], out[(1, 1, 1, 0, 0)], out[(1, 1, 1, 1, 0)], out[(1, 1, 1, 1, 1)]
     # fused dssum: same bits everywhere
     assert np.array_equal(ref[2], fus[2]) and np.array_equal(ref[3], fus[3])
     assert ref[0][1] == fus[0][1] and np.array_equal(ref[0][2], fus[0][2]) and np.array_equal(ref[0][0], fus[0][0])
     assert np.array_equal(ref[1][0], fus[1][0])
     # restructured / assembled inner solve: same iterates up to the rounding of the dots
-    for alt in (res, asm, nod):
+    # device-side bookkeeping repeats the host statements: the same bits as the host-driven node-space solve
+    assert nod[0][1] == dbk[0][1] and np.array_equal(nod[0][2], dbk[0][2]) and np.array_equal(nod[0][0], dbk[0][0])
+    assert np.array_equal(nod[1][0], dbk[1][0]) and np.array_equal(nod[1][1], dbk[1][1])
+    for alt in (res, asm, nod, dbk):
         assert ref[0][1] == alt[0][1]
         assert np.abs(ref[0][0] - alt[0][0]).max() <= 1e-9 * np.abs(ref[0][0]).max()
         assert np.abs(ref[0][2] - alt[0][2]).max() <= 1e-10 * ref[0][2][0]

@@ -943,6 +943,109 @@ def test_graph_capture_and_replay(gpu):
     L.call("fdd_stream_destroy", st)
 
 
+def _host_gmres_cycle(norm2, cols, m, iters_before, max_iterations, tol, use_relative, r0=None):
+    """The reference's scalar bookkeeping of one restart cycle (subdomain.tpp:4396-4477) in Python floats."""
+    import math
+
+    H = [[0.0] * m for _ in range(m)]
+    c, s, gamma = [0.0] * m, [0.0] * m, [0.0] * (m + 1)
+    gamma[0] = math.sqrt(norm2)
+    r0 = gamma[0] if r0 is None else r0
+    hist = [gamma[0]]
+    it = iters_before
+    converged = False
+    j = 0
+    while j < m:
+        it += 1
+        dots = cols[j]
+        for i in range(j + 1):
+            H[i][j] = dots[i]
+        for i in range(j):
+            h = H[i][j]
+            H[i][j] = c[i] * h + s[i] * H[i + 1][j]
+            H[i + 1][j] = -s[i] * h + c[i] * H[i + 1][j]
+        alpha = math.sqrt(dots[j + 1])
+        if abs(alpha) == 0.0:
+            converged = True
+            break
+        beta = math.sqrt(H[j][j] * H[j][j] + alpha * alpha)
+        g = 1.0 / beta
+        c[j] = H[j][j] * g
+        s[j] = alpha * g
+        H[j][j] = beta
+        gamma[j + 1] = -s[j] * gamma[j]
+        gamma[j] = c[j] * gamma[j]
+        r = abs(gamma[j + 1])
+        hist.append(r)
+        if (r / r0 < tol) if use_relative else (r < tol):
+            converged = True
+            break
+        if it >= max_iterations:
+            converged = True
+            break
+        j += 1
+    if j == m:
+        j -= 1
+    for k in range(j, -1, -1):
+        gk = gamma[k]
+        for i in range(j, k, -1):
+            gk -= H[k][i] * c[i]
+        c[k] = gk / H[k][k]
+    return c[: j + 1], hist, j, it - iters_before, converged
+
+
+@pytest.mark.parametrize("case", ["full", "tolerance", "max_iterations", "breakdown"])
+def test_gmres_bookkeeping_on_device(gpu, case):
+    """fdd_gmres_*_dev against the host statements they replace, bit for bit; a stop inside
+    the cycle is recorded while the later steps are still fed (with garbage) and ignored."""
+    L = lib.hip()
+    m = 5
+    rng = np.random.default_rng({"full": 1, "tolerance": 2, "max_iterations": 3, "breakdown": 4}[case])
+    cols = [np.concatenate([rng.uniform(-1, 1, j + 1), [rng.uniform(0.1, 1.0)]]) for j in range(m)]
+    norm2, tol, max_it, before, rel = 3.7, 1e-30, 100, 0, 0
+    if case == "tolerance":
+        full = _host_gmres_cycle(norm2, cols, m, 0, 100, 1e-30, True)[1]  # monotone: stop exactly at column 2
+        tol, rel = 0.5 * (full[2] + full[3]) / full[0], 1
+    elif case == "max_iterations":
+        max_it, before = 7, 4
+    elif case == "breakdown":
+        cols[2][3] = 0.0
+    y, hist, j_last, steps, conv = _host_gmres_cycle(norm2, cols, m, before, max_it, tol, bool(rel))
+    if case != "full":
+        assert j_last < m - 1 and conv
+
+    nbytes = L.raw("fdd_gmres_state_bytes")()
+    st = torch.zeros(nbytes // 8 + 1, dtype=torch.float64, device=gpu)
+    d_norm = dev(np.array([norm2]), gpu)
+    stream = lib.current_stream()
+    L.call("fdd_gmres_begin_dev", vp(st.data_ptr()), vp(d_norm.data_ptr()), 1, stream)
+    keep = []
+    for j in range(m):
+        d = dev(cols[j] if j <= j_last or case == "full" else np.full(j + 2, np.nan), gpu)  # garbage after the stop
+        keep.append(d)
+        L.call("fdd_gmres_step_dev", vp(st.data_ptr()), vp(d.data_ptr()), j, before, max_it, ctypes.c_double(tol), rel, stream)
+    L.call("fdd_gmres_finish_dev", vp(st.data_ptr()), m, stream)
+    gy, gh = np.zeros(8), np.zeros(9)
+    nh, jl, stp, cv = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    L.call("fdd_gmres_fetch", vp(st.data_ptr()), P(gy), P(gh), ctypes.byref(nh), ctypes.byref(jl), ctypes.byref(stp), ctypes.byref(cv), stream)
+    assert (jl.value, stp.value, bool(cv.value), nh.value) == (j_last, steps, conv, len(hist))
+    assert np.array_equal(gh[: nh.value], np.array(hist))
+    assert np.array_equal(gy[: j_last + 1], np.array(y)) and not gy[j_last + 1 :].any()
+    # the coefficient pointer the update kernel reads
+    yp = vp()
+    L.call("fdd_gmres_coefficients", vp(st.data_ptr()), ctypes.byref(yp))
+    n = 1001
+    q = rnd(n, 5)
+    V = [rnd(n, 10 + i) for i in range(j_last + 1)]
+    ref = q.copy()
+    O = S.oracle()
+    for i in range(j_last + 1):
+        O.orc_vector_vector_addition(P(ref), ctypes.c_double(1.0), P(ref), ctypes.c_double(y[i]), P(V[i]), n)
+    dq = dev(q, gpu)
+    k("fdd_multi_axpy_dev", dq, yp, [dev(v, gpu) for v in V], j_last + 1, n)
+    assert np.array_equal(host(dq), ref)
+
+
 def test_fetch_scalars(gpu):
     L = lib.hip()
     a = rnd(32, 95)
