@@ -81,9 +81,11 @@ class _DevView:
         self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def comm_torch_callbacks(on_gpu: bool = True) -> None:
+def comm_torch_callbacks(on_gpu: bool = True, staged: bool = False) -> None:
     """Collectives through torch.distributed (backend "nccl" = RCCL on GPUs,
-    "gloo" on CPU buffers in the CPU test build)."""
+    "gloo" on CPU buffers in the CPU test build).  staged: device buffers go
+    through a host copy around the collective (a gloo group driving GPU ranks:
+    the one-GPU rehearsal of the multi-rank path)."""
     import torch
     import torch.distributed as dist
 
@@ -101,7 +103,12 @@ def comm_torch_callbacks(on_gpu: bool = True) -> None:
         def fn(ctx, buf, n):
             try:
                 t = wrap(buf, int(n), torch.float64)
-                dist.all_reduce(t, op=op)
+                if staged:
+                    h = t.cpu()
+                    dist.all_reduce(h, op=op)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t, op=op)
                 return 0
             except Exception as exc:  # pragma: no cover - surfaced by the C++ side
                 print("allreduce callback failed:", exc, flush=True)
@@ -114,7 +121,15 @@ def comm_torch_callbacks(on_gpu: bool = True) -> None:
             nbytes = int(nbytes)
             s = wrap(send, nbytes, torch.uint8)
             r = wrap(recv, nbytes * size, torch.uint8)
-            dist.all_gather_into_tensor(r, s) if on_gpu else dist.all_gather(list(r.chunk(size)), s)
+            if staged:
+                hs = s.cpu()
+                hr = [torch.empty_like(hs) for _ in range(size)]
+                dist.all_gather(hr, hs)
+                r.copy_(torch.cat(hr))
+            elif on_gpu:
+                dist.all_gather_into_tensor(r, s)
+            else:
+                dist.all_gather(list(r.chunk(size)), s)
             return 0
         except Exception as exc:  # pragma: no cover
             print("allgather callback failed:", exc, flush=True)

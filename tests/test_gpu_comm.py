@@ -52,3 +52,69 @@ def test_solve_is_identical_under_every_backend(group):
         p.close()
     for u, its, hist in results[1:]:
         assert its == results[0][1] and np.array_equal(hist, results[0][2]) and np.array_equal(u, results[0][0])
+
+
+def _two_rank_worker(rank, world, port, E, N, red):
+    """One of `world` ranks that all drive cuda:0; collectives go through a gloo
+    group with the device buffers staged over the host (the solver's multi-rank
+    code path -- interface exchange, device-side scalars, node-space PCG -- is
+    exactly the one RCCL serves on a multi-GPU node)."""
+    import sys
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+
+    import support as S
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H.init(0, use_torch_stream=True)
+        H.set_print(False)
+        H.comm_torch_callbacks(on_gpu=True, staged=True)
+        lib.host().call("fddh_comm_selftest", 1000)
+        Pg = S.rank_grid(world)
+        p = H.Problem.box(E, Pg, N, red, True)
+        for lvl in range(p.info["num_levels"]):
+            p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
+        meshes = [S.BoxMesh(E, N, Pg, r) for r in range(world)]
+        W = S.OracleWorld(meshes, N)
+        us = [np.sin(3 * mm.x + 1) * np.cos(2 * mm.y) + mm.z * mm.x for mm in meshes]
+        o_f = W.stiffness(W.dssum(us, True, True))
+        _, f = p.make_rhs_from(us[rank])
+        assert np.abs(f - o_f[rank]).max() <= 1e-13 * np.abs(o_f[rank]).max()
+        sds = [S.OracleSubdomain(E, N, red, Pg, r) for r in range(world)]
+
+        def pre(z, r):
+            for k in range(world):
+                out, _, _ = sds[k].solve(r[k], "gmres")
+                z[k][:] = out
+
+        for method in ("fcg", "gmres"):
+            u, its, hist = p.solve(f, method)
+            ou, oits, ohist = W.solve(o_f, method, precond=pre)
+            assert its == oits, (method, its, oits)
+            assert np.abs(hist - ohist).max() <= 1e-8 * ohist[0]
+            assert np.abs(u - ou[rank]).max() <= 1e-8 * np.abs(ou[rank]).max()
+        # the stepwise interface bench.py drives
+        p.pcg_begin(f)
+        last = p.pcg_steps(3)
+        _, _, ohist = W.solve(o_f, "fcg", max_iterations=3, tolerance=0.0, precond=pre)
+        assert abs(last - ohist[3]) <= 1e-8 * ohist[0]
+        p.close()
+        W.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_against_the_oracle_world(gpu):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, (4, 4, 4), 3, 2), nprocs=2, join=True)
