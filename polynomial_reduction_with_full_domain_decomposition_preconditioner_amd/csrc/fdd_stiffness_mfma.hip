@@ -133,9 +133,9 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
 #pragma unroll
         for (int m = 0; m < kPts; m++)
         {
-            ru[m] = valid(m) ? __builtin_nontemporal_load(u + base + goff(m)) : 0.0;
+            ru[m] = valid(m) ? u[base + goff(m)] : 0.0;
 #pragma unroll
-            for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? __builtin_nontemporal_load(G.g[g] + base + goff(m)) : 0.0;
+            for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? G.g[g][base + goff(m)] : 0.0;
         }
     }
 
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
         if (more)
         {
 #pragma unroll
-            for (int m = 0; m < kPts; m++) ru[m] = valid(m) ? __builtin_nontemporal_load(u + base_n + goff(m)) : 0.0;
+            for (int m = 0; m < kPts; m++) ru[m] = valid(m) ? u[base_n + goff(m)] : 0.0;
         }
 
         // P1: first derivatives
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
 #pragma unroll
             for (int m = 0; m < kPts; m++)
 #pragma unroll
-                for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? __builtin_nontemporal_load(G.g[g] + base_n + goff(m)) : 0.0;
+                for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? G.g[g][base_n + goff(m)] : 0.0;
         }
         lds_barrier();
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
         // P4: LDS -> global
 #pragma unroll
         for (int m = 0; m < kPts; m++)
-            if (valid(m)) __builtin_nontemporal_store(sU[lidx(m)], Au + base + goff(m));
+            if (valid(m)) Au[base + goff(m)] = sU[lidx(m)]; // default cache policy: non-temporal accesses measured 4 % slower here
     }
 #undef lidx
 #undef goff
