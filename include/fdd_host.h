@@ -120,6 +120,12 @@ int fddh_problem_sub_point_dofs(const fddh_problem *p, int *dof, int n);
 int fddh_problem_amg_add_level(fddh_problem *p, int n, const int *A_ptr, const int *A_col, const double *A_val, const double *D_val, const double *coefs, int num_coefs, int n_coarse, const int *P_ptr, const int *P_col, const double *P_val);
 int fddh_problem_amg_finalize(fddh_problem *p);
 int fddh_problem_amg_apply(fddh_problem *p, const double *r, double *z);
+/* Or let the host layer build both the low-order FEM matrix (P1 on the 6 tetrahedra of every GLL sub-cell,
+ * subdomain.tpp:2823-3060) and this build's own smoothed-aggregation hierarchy for it (HYPRE BoomerAMG's stand-in,
+ * subdomain.tpp:3383-3549), and attach it.  coarsest_size / strength <= 0 take the defaults (400 rows, 0.08). */
+int fddh_problem_amg_build(fddh_problem *p, int coarsest_size, double strength, int smooth_prolongator, int verbose, int *num_levels);
+int fddh_problem_amg_level_info(const fddh_problem *p, int level, int *n, int *nnz_A, int *n_coarse, int *nnz_P);
+int fddh_problem_amg_level_arrays(const fddh_problem *p, int level, int *A_ptr, int *A_col, double *A_val, double *D_val, double *coefs, int *P_ptr, int *P_col, double *P_val);
 
 /* Domain operations on host vectors of num_local_points */
 int fddh_problem_dssum(fddh_problem *p, double *out, const double *in, int apply_mask, int apply_weight);          /* Domain::direct_stiffness_summation */

@@ -495,6 +495,52 @@ int fddh_problem_amg_finalize(fddh_problem *p)
     return 0;
 }
 
+int fddh_problem_amg_build(fddh_problem *p, int coarsest_size, double strength, int smooth_prolongator, int verbose, int *num_levels)
+{
+    if (!p) return fail("null argument");
+    if (!p->subdomain) return fail("problem was created without a Subdomain");
+    fdd::low_order::Options o;
+    if (coarsest_size > 0) o.coarsest_size = coarsest_size;
+    if (strength > 0.0) o.strength = strength;
+    o.smooth_prolongator = smooth_prolongator != 0;
+    const int nl = p->subdomain->amg_build(o, verbose != 0);
+    if (num_levels) *num_levels = nl;
+    return 0;
+}
+
+int fddh_problem_amg_level_info(const fddh_problem *p, int level, int *n, int *nnz_A, int *n_coarse, int *nnz_P)
+{
+    if (!p || !p->subdomain) return fail("no Subdomain");
+    const auto &lv = p->subdomain->amg_hierarchy.levels;
+    if (level < 0 || level >= (int)lv.size()) return fail("the hierarchy has %d levels", (int)lv.size());
+    if (n) *n = lv[level].n;
+    if (nnz_A) *nnz_A = lv[level].A.num_nnz;
+    if (n_coarse) *n_coarse = lv[level].P.num_cols;
+    if (nnz_P) *nnz_P = lv[level].P.num_nnz;
+    return 0;
+}
+
+int fddh_problem_amg_level_arrays(const fddh_problem *cp, int level, int *A_ptr, int *A_col, double *A_val, double *D_val, double *coefs, int *P_ptr, int *P_col, double *P_val)
+{
+    if (!cp || !cp->subdomain) return fail("no Subdomain");
+    fddh_problem *p = const_cast<fddh_problem *>(cp);
+    auto &lv = p->subdomain->amg_hierarchy.levels;
+    if (level < 0 || level >= (int)lv.size()) return fail("the hierarchy has %d levels", (int)lv.size());
+    amg::Level &L = lv[level];
+    if (A_ptr) memcpy(A_ptr, L.A.ptr_hst.data(), L.A.ptr_hst.size() * sizeof(int));
+    if (A_col) memcpy(A_col, L.A.col_hst.data(), L.A.col_hst.size() * sizeof(int));
+    if (A_val) memcpy(A_val, L.A.val_hst.data(), L.A.val_hst.size() * sizeof(double));
+    if (D_val) L.D_val.copyTo(D_val, (size_t)L.n * sizeof(double));
+    if (coefs) memcpy(coefs, L.coefs.data(), L.coefs.size() * sizeof(double));
+    if (L.P.num_rows > 0)
+    {
+        if (P_ptr) memcpy(P_ptr, L.P.ptr_hst.data(), L.P.ptr_hst.size() * sizeof(int));
+        if (P_col) memcpy(P_col, L.P.col_hst.data(), L.P.col_hst.size() * sizeof(int));
+        if (P_val) memcpy(P_val, L.P.val_hst.data(), L.P.val_hst.size() * sizeof(double));
+    }
+    return 0;
+}
+
 // z = low_order_preconditioner(r) on level-0 subdomain points (subdomain.tpp:3987-4159)
 int fddh_problem_amg_apply(fddh_problem *p, const double *r, double *z)
 {

@@ -1,0 +1,475 @@
+/*
+ * low_order.hpp -- the operators the AMG V-cycle of the FDD preconditioner runs
+ * on, built on the host once per Subdomain:
+ *
+ *   assemble_fem   the low-order FEM matrix on the GLL sub-cells: every cell
+ *                  between adjacent GLL nodes of a spectral element is cut into
+ *                  6 tetrahedra (the reference's vertex table) and the P1
+ *                  stiffness of each tetrahedron is summed onto the dofs
+ *                  (subdomain.tpp:2823-3060, 3300-3412; conforming region: one
+ *                  degree, boolean Q).
+ *   build          an algebraic multigrid hierarchy for it.  The reference hands
+ *                  the matrix to HYPRE BoomerAMG (subdomain.tpp:3383-3549); HYPRE
+ *                  is not available, so this is this build's own hierarchy
+ *                  (documented deviation): smoothed aggregation with
+ *                  Galerkin coarse operators, Chebyshev data per level in the
+ *                  form the V-cycle consumes (diagonal scaling D = diag(A)^-1/2
+ *                  and the coefficients of p(DAD), hypre's `ds` / `coefs`).
+ *
+ * Pure host code (setup is outside the hot path).
+ */
+#ifndef FDD_LOW_ORDER_HPP
+#define FDD_LOW_ORDER_HPP
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace fdd
+{
+namespace low_order
+{
+
+struct HostCSR
+{
+    int rows = 0, cols = 0;
+    std::vector<int> ptr, col;
+    std::vector<double> val;
+    long long nnz() const { return (long long)col.size(); }
+};
+
+// rows of (row, col, val) triplets -> CSR with duplicates summed, columns sorted
+inline HostCSR from_triplets(int rows, int cols, std::vector<int> &ti, std::vector<int> &tj, std::vector<double> &tv)
+{
+    HostCSR A;
+    A.rows = rows;
+    A.cols = cols;
+    A.ptr.assign(rows + 1, 0);
+    const size_t n = ti.size();
+    for (size_t t = 0; t < n; t++) A.ptr[ti[t] + 1]++;
+    for (int i = 0; i < rows; i++) A.ptr[i + 1] += A.ptr[i];
+    std::vector<int> cj(n);
+    std::vector<double> cv(n);
+    {
+        std::vector<int> fill(A.ptr.begin(), A.ptr.end() - 1);
+        for (size_t t = 0; t < n; t++)
+        {
+            const int p = fill[ti[t]]++;
+            cj[p] = tj[t];
+            cv[p] = tv[t];
+        }
+    }
+    std::vector<int>().swap(ti);
+    std::vector<int>().swap(tj);
+    std::vector<double>().swap(tv);
+    // sort each row by column (stable: insertion order of equal columns is kept) and merge duplicates
+    std::vector<int> order;
+    std::vector<int> out_ptr(rows + 1, 0);
+    for (int i = 0; i < rows; i++)
+    {
+        const int a = A.ptr[i], b = A.ptr[i + 1];
+        order.resize(b - a);
+        for (int k = 0; k < b - a; k++) order[k] = a + k;
+        std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return cj[p] < cj[q]; });
+        int last = -1;
+        for (int k = 0; k < b - a; k++)
+        {
+            const int p = order[k];
+            if (cj[p] != last)
+            {
+                A.col.push_back(cj[p]);
+                A.val.push_back(cv[p]);
+                last = cj[p];
+            }
+            else
+                A.val.back() += cv[p];
+        }
+        out_ptr[i + 1] = (int)A.col.size();
+    }
+    A.ptr.swap(out_ptr);
+    return A;
+}
+
+// subdomain.tpp:2823-3060: P1 stiffness of the 6 tetrahedra of every GLL sub-cell, summed on the dofs.
+// x, y, z: coordinates of the level-0 points (element-major, x fastest); point_dof[p] < 0: no dof (Dirichlet).
+inline HostCSR assemble_fem(const double *x, const double *y, const double *z, const int *point_dof, int num_dofs, int poly_degree, int num_elements, double epsilon = 1.0e-12)
+{
+    // vertex offsets (i, j, k) of the 6 tetrahedra of a cell (subdomain.tpp:2878-2885)
+    static const int tets[6][4][3] = {
+        {{0, 0, 0}, {0, 1, 0}, {1, 0, 0}, {1, 0, 1}}, {{1, 0, 0}, {0, 1, 0}, {1, 1, 0}, {1, 0, 1}}, {{0, 0, 0}, {0, 0, 1}, {0, 1, 0}, {1, 0, 1}},
+        {{1, 0, 1}, {1, 1, 0}, {1, 1, 1}, {0, 1, 0}}, {{0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {0, 1, 0}}, {{1, 0, 1}, {1, 1, 1}, {0, 1, 1}, {0, 1, 0}}};
+    // gradients of the 4 P1 shape functions on the reference tetrahedron (subdomain.tpp:2841-2843: one row per direction)
+    static const double Dref[3][4] = {{1.0, 0.0, 0.0, -1.0}, {0.0, 1.0, 0.0, -1.0}, {0.0, 0.0, 1.0, -1.0}};
+
+    const int N = poly_degree, n = N + 1, n3 = n * n * n;
+    std::vector<int> ti, tj;
+    std::vector<double> tv;
+    const size_t guess = (size_t)num_elements * N * N * N * 6 * 10;
+    ti.reserve(guess);
+    tj.reserve(guess);
+    tv.reserve(guess);
+
+    for (int e = 0; e < num_elements; e++)
+    {
+        const size_t base = (size_t)e * n3;
+        for (int sz = 0; sz < N; sz++)
+            for (int sy = 0; sy < N; sy++)
+                for (int sx = 0; sx < N; sx++)
+                    for (int t = 0; t < 6; t++)
+                    {
+                        size_t loc[4];
+                        double xs[4], ys[4], zs[4];
+                        for (int v = 0; v < 4; v++)
+                        {
+                            loc[v] = base + (size_t)(sx + tets[t][v][0]) + (size_t)(sy + tets[t][v][1]) * n + (size_t)(sz + tets[t][v][2]) * n * n;
+                            xs[v] = x[loc[v]];
+                            ys[v] = y[loc[v]];
+                            zs[v] = z[loc[v]];
+                        }
+                        // H = [x_v - x_3], inverse and determinant (subdomain.tpp:2975-2989, 2788-2817)
+                        const double H[9] = {xs[0] - xs[3], xs[1] - xs[3], xs[2] - xs[3], ys[0] - ys[3], ys[1] - ys[3], ys[2] - ys[3], zs[0] - zs[3], zs[1] - zs[3], zs[2] - zs[3]};
+                        const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
+                        const double id = 1.0 / det;
+                        const double iH[9] = {id * (H[4] * H[8] - H[7] * H[5]), id * (H[2] * H[7] - H[8] * H[1]), id * (H[1] * H[5] - H[4] * H[2]),
+                                              id * (H[5] * H[6] - H[8] * H[3]), id * (H[0] * H[8] - H[6] * H[2]), id * (H[2] * H[3] - H[5] * H[0]),
+                                              id * (H[3] * H[7] - H[6] * H[4]), id * (H[1] * H[6] - H[7] * H[0]), id * (H[0] * H[4] - H[3] * H[1])};
+                        // G_mn = (det / 24) sum_k iH[m][k] iH[n][k] at each of the 4 quadrature points (subdomain.tpp:2994-3007)
+                        double G[3][3];
+                        for (int m = 0; m < 3; m++)
+                            for (int nn = 0; nn < 3; nn++)
+                            {
+                                double g = 0.0;
+                                for (int k = 0; k < 3; k++) g += (det / 24.0) * iH[m * 3 + k] * iH[nn * 3 + k];
+                                G[m][nn] = g;
+                            }
+                        // A_tet = sum_mn D_m^T G_mn D_n over the 4 (identical) quadrature points (subdomain.tpp:3009-3027)
+                        double At[4][4];
+                        for (int i = 0; i < 4; i++)
+                            for (int j = 0; j < 4; j++)
+                            {
+                                double a = 0.0;
+                                for (int m = 0; m < 3; m++)
+                                    for (int nn = 0; nn < 3; nn++)
+                                        for (int q = 0; q < 4; q++) a += Dref[m][i] * (G[m][nn] * Dref[nn][j]);
+                                At[i][j] = a;
+                            }
+                        for (int i = 0; i < 4; i++)
+                        {
+                            const int di = point_dof[loc[i]];
+                            if (di < 0) continue;
+                            for (int j = 0; j < 4; j++)
+                            {
+                                const int dj = point_dof[loc[j]];
+                                if (dj < 0 or not(std::abs(At[i][j]) > epsilon)) continue; // :3031
+                                ti.push_back(di);
+                                tj.push_back(dj);
+                                tv.push_back(At[i][j]);
+                            }
+                        }
+                    }
+    }
+    return from_triplets(num_dofs, num_dofs, ti, tj, tv);
+}
+
+// C = A * B (Gustavson, one dense accumulator row)
+inline HostCSR multiply(const HostCSR &A, const HostCSR &B)
+{
+    HostCSR C;
+    C.rows = A.rows;
+    C.cols = B.cols;
+    C.ptr.assign(A.rows + 1, 0);
+    std::vector<int> marker(B.cols, -1);
+    std::vector<double> acc(B.cols, 0.0);
+    std::vector<int> cols;
+    for (int i = 0; i < A.rows; i++)
+    {
+        cols.clear();
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+        {
+            const int k = A.col[p];
+            const double a = A.val[p];
+            for (int q = B.ptr[k]; q < B.ptr[k + 1]; q++)
+            {
+                const int j = B.col[q];
+                if (marker[j] != i)
+                {
+                    marker[j] = i;
+                    acc[j] = 0.0;
+                    cols.push_back(j);
+                }
+                acc[j] += a * B.val[q];
+            }
+        }
+        std::sort(cols.begin(), cols.end());
+        for (int j : cols)
+        {
+            C.col.push_back(j);
+            C.val.push_back(acc[j]);
+        }
+        C.ptr[i + 1] = (int)C.col.size();
+    }
+    return C;
+}
+
+inline HostCSR transpose(const HostCSR &A)
+{
+    HostCSR T;
+    T.rows = A.cols;
+    T.cols = A.rows;
+    T.ptr.assign(T.rows + 1, 0);
+    for (int c : A.col) T.ptr[c + 1]++;
+    for (int i = 0; i < T.rows; i++) T.ptr[i + 1] += T.ptr[i];
+    T.col.resize(A.col.size());
+    T.val.resize(A.val.size());
+    std::vector<int> fill(T.ptr.begin(), T.ptr.end() - 1);
+    for (int i = 0; i < A.rows; i++)
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+        {
+            const int q = fill[A.col[p]]++;
+            T.col[q] = i;
+            T.val[q] = A.val[p];
+        }
+    return T;
+}
+
+inline std::vector<double> diagonal(const HostCSR &A)
+{
+    std::vector<double> d(A.rows, 0.0);
+    for (int i = 0; i < A.rows; i++)
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+            if (A.col[p] == i) d[i] = A.val[p];
+    return d;
+}
+
+inline void spmv(std::vector<double> &y, const HostCSR &A, const std::vector<double> &x)
+{
+    y.resize(A.rows);
+    for (int i = 0; i < A.rows; i++)
+    {
+        double s = 0.0;
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++) s += A.val[p] * x[A.col[p]];
+        y[i] = s;
+    }
+}
+
+// largest eigenvalue of D A D, D = diag(A)^-1/2, by power iteration from a fixed start
+inline double max_eigenvalue_scaled(const HostCSR &A, const std::vector<double> &D, int iterations)
+{
+    const int n = A.rows;
+    std::vector<double> v(n), w(n), t(n);
+    for (int i = 0; i < n; i++) v[i] = 1.0 + 0.5 * std::sin(0.7 * i + 0.3); // deterministic, no symmetry
+    double lambda = 1.0;
+    for (int it = 0; it < iterations; it++)
+    {
+        double nrm = 0.0;
+        for (int i = 0; i < n; i++) nrm += v[i] * v[i];
+        nrm = std::sqrt(nrm);
+        for (int i = 0; i < n; i++) t[i] = D[i] * (v[i] / nrm);
+        spmv(w, A, t);
+        double num = 0.0;
+        for (int i = 0; i < n; i++)
+        {
+            w[i] *= D[i];
+            num += w[i] * (v[i] / nrm);
+        }
+        lambda = num;
+        v.swap(w);
+    }
+    return lambda;
+}
+
+struct Options
+{
+    int cheby_order = 2;          // subdomain.hpp:237
+    int max_levels = 12;
+    int coarsest_size = 400;      // stop coarsening at or below this many rows (solved with a dense inverse)
+    double strength = 0.08;       // |a_ij| >= strength * sqrt(a_ii a_jj)
+    double eig_ratio = 0.3;       // smoother targets [eig_ratio, 1.1] * lambda_max (hypre's Chebyshev defaults)
+    double upper_factor = 1.1;
+    int power_iterations = 25;
+    bool smooth_prolongator = true;
+};
+
+struct Level
+{
+    HostCSR A, P; // P empty on the coarsest level
+    std::vector<double> D, coefs;
+};
+
+// greedy aggregation on the strength graph: returns the aggregate of every row and the number of aggregates
+inline int aggregate(const HostCSR &A, double theta, std::vector<int> &agg)
+{
+    const int n = A.rows;
+    const std::vector<double> d = diagonal(A);
+    agg.assign(n, -1);
+    auto strong = [&](int i, int p) {
+        const int j = A.col[p];
+        return j != i and std::abs(A.val[p]) >= theta * std::sqrt(std::abs(d[i] * d[j]));
+    };
+    int count = 0;
+    // pass 1: a row whose strong neighbourhood is untouched seeds an aggregate with all of it
+    for (int i = 0; i < n; i++)
+    {
+        if (agg[i] != -1) continue;
+        bool free_nbhd = true;
+        bool has_strong = false;
+        for (int p = A.ptr[i]; p < A.ptr[i + 1] and free_nbhd; p++)
+            if (strong(i, p))
+            {
+                has_strong = true;
+                if (agg[A.col[p]] != -1) free_nbhd = false;
+            }
+        if (not free_nbhd or not has_strong) continue;
+        agg[i] = count;
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+            if (strong(i, p)) agg[A.col[p]] = count;
+        count++;
+    }
+    // pass 2: leftovers join the aggregate of their strongest aggregated neighbour
+    std::vector<int> joined(n, -1);
+    for (int i = 0; i < n; i++)
+    {
+        if (agg[i] != -1) continue;
+        double best = 0.0;
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+            if (strong(i, p) and agg[A.col[p]] != -1 and std::abs(A.val[p]) > best)
+            {
+                best = std::abs(A.val[p]);
+                joined[i] = agg[A.col[p]];
+            }
+    }
+    for (int i = 0; i < n; i++)
+        if (agg[i] == -1 and joined[i] != -1) agg[i] = joined[i];
+    // pass 3: what is still alone (isolated rows) forms aggregates with its unaggregated strong neighbours
+    for (int i = 0; i < n; i++)
+    {
+        if (agg[i] != -1) continue;
+        agg[i] = count;
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+            if (strong(i, p) and agg[A.col[p]] == -1) agg[A.col[p]] = count;
+        count++;
+    }
+    return count;
+}
+
+inline std::vector<double> chebyshev_coefficients(double lambda_max, const Options &o)
+{
+    // p(x) ~ 1/x on [a, b] = [eig_ratio, upper_factor] * lambda_max: `order` steps of the Chebyshev iteration
+    // written as a polynomial in x, coefs[k] multiplying x^k (the form of subdomain.tpp:45-67)
+    const double a = o.eig_ratio * lambda_max, b = o.upper_factor * lambda_max;
+    const double theta = 0.5 * (a + b), delta = 0.5 * (b - a);
+    if (o.cheby_order == 1) return {1.0 / theta};
+    if (o.cheby_order == 2)
+    {
+        const double den = 2.0 * theta * theta - delta * delta;
+        return {4.0 * theta / den, -2.0 / den};
+    }
+    // general order: expand p(x) = (1 - T_m((theta - x)/delta) / T_m(theta/delta)) / x in the monomial basis
+    const int m = o.cheby_order;
+    std::vector<std::vector<double>> T(m + 1); // T_k(t) coefficients in t
+    T[0] = {1.0};
+    T[1] = {0.0, 1.0};
+    for (int k = 2; k <= m; k++)
+    {
+        T[k].assign(k + 1, 0.0);
+        for (int i = 0; i < (int)T[k - 1].size(); i++) T[k][i + 1] += 2.0 * T[k - 1][i];
+        for (int i = 0; i < (int)T[k - 2].size(); i++) T[k][i] -= T[k - 2][i];
+    }
+    // q(x) = T_m((theta - x)/delta): substitute t = theta/delta - x/delta
+    std::vector<double> q(m + 1, 0.0), pw(1, 1.0); // pw = t^i as a polynomial in x
+    const double c0 = theta / delta, c1 = -1.0 / delta;
+    for (int i = 0; i <= m; i++)
+    {
+        for (int k = 0; k < (int)pw.size(); k++) q[k] += T[m][i] * pw[k];
+        std::vector<double> nx(pw.size() + 1, 0.0);
+        for (int k = 0; k < (int)pw.size(); k++)
+        {
+            nx[k] += c0 * pw[k];
+            nx[k + 1] += c1 * pw[k];
+        }
+        pw.swap(nx);
+    }
+    double Tm0 = 0.0, tp = 1.0;
+    for (int i = 0; i <= m; i++)
+    {
+        Tm0 += T[m][i] * tp;
+        tp *= c0;
+    }
+    std::vector<double> coefs(m);
+    for (int k = 0; k < m; k++) coefs[k] = -q[k + 1] / Tm0; // (1 - q(x)/Tm0)/x, q(0) = Tm0
+    return coefs;
+}
+
+inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = false)
+{
+    std::vector<Level> levels;
+    HostCSR A = std::move(A0);
+    for (int l = 0; l < o.max_levels; l++)
+    {
+        Level L;
+        const int n = A.rows;
+        std::vector<double> d = diagonal(A);
+        L.D.resize(n);
+        for (int i = 0; i < n; i++) L.D[i] = 1.0 / std::sqrt(d[i]);
+        const double lmax = max_eigenvalue_scaled(A, L.D, o.power_iterations);
+        L.coefs = chebyshev_coefficients(lmax, o);
+        if (verbose) printf("low_order: level %d rows %d nnz %lld lambda_max(DAD) %.4f\n", l, n, A.nnz(), lmax);
+
+        bool last = (n <= o.coarsest_size) or (l == o.max_levels - 1);
+        HostCSR P;
+        if (not last)
+        {
+            std::vector<int> agg;
+            const int nc = aggregate(A, o.strength * std::pow(0.5, l), agg); // Galerkin operators spread: weaker threshold per level
+            if (nc >= n or nc == 0)
+                last = true;
+            else
+            {
+                // tentative prolongator: 1 on the aggregate of each row; smoothed: (I - omega D^-1 A) P_tent
+                HostCSR T;
+                T.rows = n;
+                T.cols = nc;
+                T.ptr.resize(n + 1);
+                T.col.resize(n);
+                T.val.assign(n, 1.0);
+                for (int i = 0; i <= n; i++) T.ptr[i] = i;
+                for (int i = 0; i < n; i++) T.col[i] = agg[i];
+                if (o.smooth_prolongator)
+                {
+                    const double omega = (4.0 / 3.0) / lmax; // lambda_max(D^-1 A) = lambda_max(DAD)
+                    HostCSR S = A; // I - omega D^-1 A
+                    for (int i = 0; i < n; i++)
+                        for (int p = S.ptr[i]; p < S.ptr[i + 1]; p++)
+                        {
+                            S.val[p] = -omega * S.val[p] / d[i];
+                            if (S.col[p] == i) S.val[p] += 1.0;
+                        }
+                    P = multiply(S, T);
+                }
+                else
+                    P = T;
+            }
+        }
+        if (last)
+        {
+            L.A = std::move(A);
+            levels.push_back(std::move(L));
+            break;
+        }
+        HostCSR R = transpose(P);
+        HostCSR AP = multiply(A, P);
+        HostCSR Ac = multiply(R, AP);
+        L.A = std::move(A);
+        L.P = std::move(P);
+        levels.push_back(std::move(L));
+        A = std::move(Ac);
+    }
+    return levels;
+}
+
+} // namespace low_order
+} // namespace fdd
+
+#endif

@@ -44,6 +44,7 @@
 #include "csr_matrix.hpp"
 #include "domain.hpp"
 #include "gll.hpp"
+#include "low_order.hpp"
 #include "math.hpp"
 #include "timer.hpp"
 
@@ -132,6 +133,7 @@ class Subdomain
     fdd::memory ua, fa;          // assembled-space inner solve from point vectors: solution and right-hand side over the dofs
     fdd::memory point_dof_dev;   // dof of every level-0 point (-1: none): Q as an index array
     fdd::memory gmres_state;     // device-side GMRES bookkeeping (fdd_gmres_*_dev)
+    const MeshData<DType> *fine_mesh = nullptr; // level-0 coordinates (low-order FEM assembly)
 
     fdd::memory points_without_dof; // Dirichlet points: empty rows of Q
     int num_points_without_dof = 0;
@@ -344,6 +346,30 @@ class Subdomain
         amg_hierarchy.add_level(n, A_ptr, A_col, A_val, D_val, coefs, n_coarse, P_ptr, P_col, P_val);
     }
     void amg_finalize() { amg_hierarchy.finalize(); }
+
+    // Build the low-order FEM matrix of the region and an AMG hierarchy for it on the host and attach it
+    // (stands in for subdomain.tpp:2749-3549, see low_order.hpp).  Returns the number of levels.
+    int amg_build(fdd::low_order::Options options, bool verbose = false)
+    {
+        if (dim != 3 or fine_mesh == nullptr or poly_degree[0] < 2)
+        {
+            fprintf(stderr, "ERROR: Subdomain::amg_build handles 3-D regions of degree >= 2\n");
+            exit(EXIT_FAILURE);
+        }
+        options.cheby_order = cheby_order;
+        fdd::low_order::HostCSR A = fdd::low_order::assemble_fem(fine_mesh->x.data(), fine_mesh->y.data(), fine_mesh->z.data(), point_dof.data(), num_dofs, poly_degree[0], fine_mesh->num_local_elements, epsilon);
+        std::vector<fdd::low_order::Level> lv = fdd::low_order::build(std::move(A), options, verbose);
+        amg_hierarchy = amg::Hierarchy();
+        for (size_t l = 0; l < lv.size(); l++)
+        {
+            const bool coarsest = (l + 1 == lv.size());
+            amg_add_level(lv[l].A.rows, lv[l].A.ptr.data(), lv[l].A.col.data(), lv[l].A.val.data(), lv[l].D.data(), lv[l].coefs.data(), coarsest ? 0 : lv[l].P.cols, coarsest ? nullptr : lv[l].P.ptr.data(),
+                          coarsest ? nullptr : lv[l].P.col.data(), coarsest ? nullptr : lv[l].P.val.data());
+            lv[l] = fdd::low_order::Level(); // free the host copy as we go
+        }
+        amg_finalize();
+        return (int)amg_hierarchy.levels.size();
+    }
     void apply_low_order_preconditioner(fdd::memory &z, fdd::memory &r) { low_order_preconditioner(z, r); }
 
     bool build_tree = true;               // run the degree-tree restrictions as the reference always does
@@ -377,6 +403,7 @@ class Subdomain
     {
         PType &domain = domains[poly_degree_];
         dim = domain.mesh.dim;
+        fine_mesh = &domain.mesh;
 
         poly_reduction = poly_reduction_;
         subdomain_overlap = subdomain_overlap_;

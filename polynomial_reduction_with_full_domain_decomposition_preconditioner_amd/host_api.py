@@ -322,6 +322,38 @@ class Problem:
             _H().call("fddh_problem_amg_add_level", self.h, A.shape[0], a[0].ctypes.data_as(ip), a[1].ctypes.data_as(ip), _dp(a[2]), _dp(D), _dp(coefs), len(coefs), *pargs)
         _H().call("fddh_problem_amg_finalize", self.h)
 
+    def amg_build(self, coarsest_size=0, strength=0.0, smooth_prolongator=True, verbose=False):
+        """Low-order FEM matrix + smoothed-aggregation hierarchy built by the host layer; returns the level count."""
+        nl = ctypes.c_int()
+        _H().call("fddh_problem_amg_build", self.h, int(coarsest_size), float(strength), int(smooth_prolongator), int(verbose), ctypes.byref(nl))
+        return nl.value
+
+    def amg_levels(self, cheby_order=2):
+        """The attached hierarchy as scipy matrices (finest first), as amg_attach takes it."""
+        import scipy.sparse as sp
+
+        ip = ctypes.POINTER(ctypes.c_int)
+        out = []
+        level = 0
+        while True:
+            n, nnz, nc, nnzp = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            try:
+                _H().call("fddh_problem_amg_level_info", self.h, level, ctypes.byref(n), ctypes.byref(nnz), ctypes.byref(nc), ctypes.byref(nnzp))
+            except lib.FddError:
+                break
+            ap, ac, av = np.zeros(n.value + 1, np.int32), np.zeros(nnz.value, np.int32), np.zeros(nnz.value)
+            D, coefs = np.zeros(n.value), np.zeros(8)
+            has_p = nnzp.value > 0
+            pp, pc, pv = np.zeros(n.value + 1, np.int32), np.zeros(max(nnzp.value, 1), np.int32), np.zeros(max(nnzp.value, 1))
+            _H().call("fddh_problem_amg_level_arrays", self.h, level, ap.ctypes.data_as(ip), ac.ctypes.data_as(ip), _dp(av), _dp(D), _dp(coefs),
+                      pp.ctypes.data_as(ip) if has_p else None, pc.ctypes.data_as(ip) if has_p else None, _dp(pv) if has_p else None)
+            lv = {"A": sp.csr_matrix((av, ac, ap), shape=(n.value, n.value)), "D": D, "coefs": coefs[:cheby_order].copy(), "P": None}
+            if has_p:
+                lv["P"] = sp.csr_matrix((pv[: nnzp.value], pc[: nnzp.value], pp), shape=(n.value, nc.value))
+            out.append(lv)
+            level += 1
+        return out
+
     def amg_apply(self, r):
         z = np.zeros(self.n)
         _H().call("fddh_problem_amg_apply", self.h, _dp(np.ascontiguousarray(r)), _dp(z))

@@ -17,7 +17,7 @@ import numpy as np
 import support as S
 
 
-def check_amg(p, N, red, outer_solve=True):
+def check_amg(p, N, red, outer_solve=True, builder="scipy"):
     meshes = [S.ArrayMesh.from_problem(p, lvl) for lvl in range(p.info["num_levels"])]
     sd = S.OracleSubdomain(None, N, red, meshes=meshes)
     W = S.OracleWorld([meshes[0]], N)
@@ -33,7 +33,12 @@ def check_amg(p, N, red, outer_solve=True):
         for a, b in zip(dof[dof >= 0], odof[odof >= 0]):
             assert pair.setdefault(int(a), int(b)) == int(b)  # a bijection between the two numberings
 
-        levels = S.low_order_hierarchy(meshes[0], dof, nd)
+        if builder == "scipy":
+            levels = S.low_order_hierarchy(meshes[0], dof, nd)
+        else:
+            # the host layer's own FEM matrix + smoothed-aggregation hierarchy (host/low_order.hpp)
+            assert p.amg_build(coarsest_size=40) >= 2
+            levels = p.amg_levels()
         assert len(levels) >= 2 and levels[0]["A"].shape[0] == nd and levels[-1]["P"] is None
         # the oracle's copy: level 0 renumbered (same values, same Chebyshev data), coarse levels shared
         import scipy.sparse as sp
@@ -45,7 +50,8 @@ def check_amg(p, N, red, outer_solve=True):
         fine["D"] = np.asarray(Pm @ levels[0]["D"])
         fine["P"] = (Pm @ levels[0]["P"]).tocsr()
         olevels = [fine] + levels[1:]
-        p.amg_attach(levels)
+        if builder == "scipy":
+            p.amg_attach(levels)
         sd.attach_amg(olevels)
 
         # one application of the V-cycle preconditioner

@@ -72,3 +72,15 @@ def test_errors(own_stream):
             p.amg_attach(bad)  # finest level must have the subdomain's dofs
     finally:
         p.close()
+
+
+@pytest.mark.parametrize("E,N,red", [((4, 4, 4), 3, 2), ((3, 2, 2), 6, 2)])
+def test_amg_with_the_host_layers_own_hierarchy(own_stream, E, N, red):
+    """Low-order FEM matrix + smoothed-aggregation hierarchy built by host/low_order.hpp,
+    V-cycle on the GPU (one hipGraph), against the oracle fed with the same arrays."""
+    p = make_problem(E, N, red)
+    try:
+        its = amg_checks.check_amg(p, N, red, builder="product")
+        assert its is not None and its <= 8
+    finally:
+        p.close()
