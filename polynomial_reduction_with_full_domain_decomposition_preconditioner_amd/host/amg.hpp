@@ -49,13 +49,15 @@ class Hierarchy
     static void copy(fdd::memory &dst, const fdd::memory &src, int n) { dst.copyFrom(src, (size_t)n * sizeof(double)); }
 
     // Chebyshev smoother, device branches of subdomain.tpp:19-83
-    void smooth(int l)
+    // u_is_zero: the level's u was just set to 0 (every pre-smoothing), so f - A u is f itself
+    // bit for bit and the SpMV of scaled_residual is skipped (the reference multiplies by the zero vector)
+    void smooth(int l, bool u_is_zero = false)
     {
         Level &L = levels[l];
         void *s = fdd::dev().stream;
         // scaled_residual (:34-39)
         copy(L.work, L.f, L.n);
-        L.A.matvec(L.work, L.u, -1.0, 1.0);
+        if (not u_is_zero) L.A.matvec(L.work, L.u, -1.0, 1.0);
         FDD_CALL(fdd_amg_main_scaled_residual(L.r.as<double>(), L.w.as<double>(), L.work.as<double>(), L.D_val.as<double>(), L.coefs[cheby_order - 1], L.n, s));
         // polynomial_evaluation (:62-67)
         for (int p = cheby_order - 2; p >= 0; p--)
@@ -80,7 +82,7 @@ class Hierarchy
             {
                 Level &L = levels[l];
                 if (l > 0) FDD_CALL(fdd_amg_vector_set_to_value(L.u.as<double>(), 0.0, L.n, s));
-                smooth(l);
+                smooth(l, l > 0 or iter == 0);
                 copy(L.v, L.f, L.n);             // v = f
                 L.A.matvec(L.v, L.u, -1.0, 1.0); // v = f - A u
                 L.R.matvec(levels[l + 1].f, L.v, 1.0, 0.0);
@@ -154,23 +156,50 @@ class Hierarchy
         finalized = true;
     }
 
+    // algorithmic bytes of the SpMVs of one application (the element-wise kernels between them are not counted)
+    double spmv_bytes() const
+    {
+        double b = 0.0;
+        const int nl = (int)levels.size();
+        for (int iter = 0; iter < num_vcycles; iter++)
+            for (int l = 0; l < nl - 1; l++)
+            {
+                const int with_A = 2 * cheby_order + ((l > 0 or iter == 0) ? 0 : 1); // pre-smoothing (no residual SpMV from u = 0), residual, post-smoothing
+                b += with_A * levels[l].A.algorithmic_bytes(true) + levels[l].R.algorithmic_bytes(false) + levels[l].P.algorithmic_bytes(true);
+            }
+        return b + num_vcycles * coarse_inverse.algorithmic_bytes(false);
+    }
+
     // u_fem[0] = V-cycle applied to f_fem[0] from u = 0; both live in levels[0]
     void vcycle()
     {
         void *s = fdd::dev().stream;
-        if (use_graph and s != nullptr and not graph_failed and not fdd::profiler().enabled)
+        if (use_graph and not graph_failed)
         {
             if (graph == nullptr)
             {
-                if (fdd_graph_begin_capture(s) == 0)
+                // captured once on a private stream (the caller's may be the default stream, which
+                // cannot be captured); the launches record there while fdd::dev().stream points at it
+                void *cs = nullptr;
+                if (fdd_stream_create(&cs) == 0)
                 {
-                    vcycle_launches();
-                    if (fdd_graph_end_capture(s, &graph) != 0) graph = nullptr;
+                    if (fdd_graph_begin_capture(cs) == 0)
+                    {
+                        const bool profiling = fdd::profiler().enabled; // no event records inside a capture
+                        fdd::profiler().enabled = false;
+                        fdd::dev().stream = cs;
+                        vcycle_launches();
+                        fdd::dev().stream = s;
+                        fdd::profiler().enabled = profiling;
+                        if (fdd_graph_end_capture(cs, &graph) != 0) graph = nullptr;
+                    }
+                    (void)fdd_stream_destroy(cs);
                 }
                 if (graph == nullptr) graph_failed = true;
             }
             if (graph != nullptr)
             {
+                fdd::ProfileScope prof("amg_vcycle<hipGraph>", spmv_bytes());
                 FDD_CALL(fdd_graph_launch(graph, s));
                 return;
             }
