@@ -235,6 +235,14 @@ int fdd_gmres_step_dev(void *state, const double *dots_dev, int j, int iteration
 int fdd_gmres_finish_dev(void *state, int m, void *stream);
 int fdd_gmres_fetch(void *state, double *y, double *hist, int *num_hist, int *j_last, int *steps, int *converged, void *stream);
 int fdd_gmres_coefficients(void *state, const double **y_dev);
+/* the basis may stay unnormalised: inv[0] = 1/gamma_0, inv[j+1] = 1/||q_j|| are kept in the state (the factors
+ * vector_scaling would have applied, subdomain.tpp:4358, 4457) for the *_scaled entries below to apply on load */
+int fdd_gmres_scales(void *state, const double **inv_dev);
+int fdd_sub_stiffness_matrix_gather_scaled(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
+int fdd_multi_weighted_inner_product_scaled(double *out, double *ws, const double *a, const double *const *b, const double *b_scale_dev, int m, const double *w, int n, void *stream);
+int fdd_multi_axpy_norm2_scaled_dev(double *out, double *ws, double *dst, const double *y, const double *coeffs_dev, double sign, const double *const *x, const double *x_scale_dev, int m, const double *w, int n, void *stream);
+int fdd_multi_axpy_scaled_dev(double *q, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream);
+int fdd_vector_scaling_dev(double *au, const double *scale_dev, const double *u, int n, void *stream); /* au = (*scale_dev) * u */
 /* out[0] = sum_nodes s*s*w with s = (Qt u)[node]*w[node]: Subdomain::residual_norm
  * (subdomain.tpp:4491-4515: multiply_weight + weighted_inner_product) without the dof vector */
 int fdd_gather_weighted_norm2(double *out, double *ws, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, int num_nodes, void *stream);

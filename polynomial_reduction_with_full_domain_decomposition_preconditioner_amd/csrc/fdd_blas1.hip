@@ -111,6 +111,21 @@ struct ScaleRsqrtDevOp
     __device__ void one(long long i) const { au[i] = (1.0 / sqrt(*s2)) * u[i]; }
 };
 
+// au = (*scale) * u: math.okl:29-35 with the factor read from device memory
+struct ScaleDevOp
+{
+    double *au;
+    const double *u;
+    const double *scale;
+    __device__ void vec2(long long i) const
+    {
+        const double alpha = *scale;
+        double2 a = ld2(u, i);
+        st2(au, i, make_double2(alpha * a.x, alpha * a.y));
+    }
+    __device__ void one(long long i) const { au[i] = (*scale) * u[i]; }
+};
+
 struct ScaleOp // math.okl:29-35
 {
     double *au;
@@ -291,6 +306,7 @@ struct MultiAxpyDevOp
     double *q;
     const double *v[M];
     const double *c;
+    const double *vs; // optional per-vector scales: v_k stands for vs[k] * v_k
     __device__ void vec2(long long i) const
     {
         double2 x = ld2(q, i);
@@ -298,7 +314,13 @@ struct MultiAxpyDevOp
         for (int k = 0; k < M; k++)
         {
             const double ck = c[k];
-            const double2 b = ld2(v[k], i);
+            double2 b = ld2(v[k], i);
+            if (vs)
+            {
+                const double sk = vs[k];
+                b.x = sk * b.x;
+                b.y = sk * b.y;
+            }
             x.x = 1.0 * x.x + ck * b.x;
             x.y = 1.0 * x.y + ck * b.y;
         }
@@ -308,17 +330,18 @@ struct MultiAxpyDevOp
     {
         double x = q[i];
 #pragma unroll
-        for (int k = 0; k < M; k++) x = 1.0 * x + c[k] * v[k][i];
+        for (int k = 0; k < M; k++) x = 1.0 * x + c[k] * (vs ? vs[k] * v[k][i] : v[k][i]);
         q[i] = x;
     }
 };
 
 template <int M>
-int launch_multi_axpy_dev(double *q, const double *coeffs_dev, const double *const *v, int n, void *stream)
+int launch_multi_axpy_dev(double *q, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int n, void *stream)
 {
     MultiAxpyDevOp<M> op;
     op.q = q;
     op.c = coeffs_dev;
+    op.vs = v_scale_dev;
     bool al = fdd_aligned16(q);
     for (int k = 0; k < M; k++)
     {
@@ -465,6 +488,14 @@ int fdd_vector_scaling(double *au, double alpha, const double *u, int n, void *s
     return launch_ew(ScaleOp{au, u, alpha}, n, fdd_aligned16(au) && fdd_aligned16(u), stream);
 }
 
+int fdd_vector_scaling_dev(double *au, const double *scale_dev, const double *u, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(au != nullptr && u != nullptr && scale_dev != nullptr);
+    return launch_ew(ScaleDevOp{au, u, scale_dev}, n, fdd_aligned16(au) && fdd_aligned16(u), stream);
+}
+
 int fdd_vector_scaling_rsqrt_dev(double *au, const double *norm2_dev, const double *u, int n, void *stream)
 {
     FDD_REQUIRE(n >= 0);
@@ -562,20 +593,25 @@ int fdd_multi_axpy(double *q, const double *coeffs, const double *const *v, int 
 
 int fdd_multi_axpy_dev(double *q, const double *coeffs_dev, const double *const *v, int m, int n, void *stream)
 {
+    return fdd_multi_axpy_scaled_dev(q, coeffs_dev, v, nullptr, m, n, stream);
+}
+
+int fdd_multi_axpy_scaled_dev(double *q, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream)
+{
     FDD_REQUIRE(n >= 0 && m >= 1 && m <= FDD_MULTI_MAX);
     if (n == 0) return 0;
     FDD_REQUIRE(q != nullptr && coeffs_dev != nullptr && v != nullptr);
     for (int k = 0; k < m; k++) FDD_REQUIRE(v[k] != nullptr && v[k] != q);
     switch (m)
     {
-    case 1: return launch_multi_axpy_dev<1>(q, coeffs_dev, v, n, stream);
-    case 2: return launch_multi_axpy_dev<2>(q, coeffs_dev, v, n, stream);
-    case 3: return launch_multi_axpy_dev<3>(q, coeffs_dev, v, n, stream);
-    case 4: return launch_multi_axpy_dev<4>(q, coeffs_dev, v, n, stream);
-    case 5: return launch_multi_axpy_dev<5>(q, coeffs_dev, v, n, stream);
-    case 6: return launch_multi_axpy_dev<6>(q, coeffs_dev, v, n, stream);
-    case 7: return launch_multi_axpy_dev<7>(q, coeffs_dev, v, n, stream);
-    default: return launch_multi_axpy_dev<8>(q, coeffs_dev, v, n, stream);
+    case 1: return launch_multi_axpy_dev<1>(q, coeffs_dev, v, v_scale_dev, n, stream);
+    case 2: return launch_multi_axpy_dev<2>(q, coeffs_dev, v, v_scale_dev, n, stream);
+    case 3: return launch_multi_axpy_dev<3>(q, coeffs_dev, v, v_scale_dev, n, stream);
+    case 4: return launch_multi_axpy_dev<4>(q, coeffs_dev, v, v_scale_dev, n, stream);
+    case 5: return launch_multi_axpy_dev<5>(q, coeffs_dev, v, v_scale_dev, n, stream);
+    case 6: return launch_multi_axpy_dev<6>(q, coeffs_dev, v, v_scale_dev, n, stream);
+    case 7: return launch_multi_axpy_dev<7>(q, coeffs_dev, v, v_scale_dev, n, stream);
+    default: return launch_multi_axpy_dev<8>(q, coeffs_dev, v, v_scale_dev, n, stream);
     }
 }
 

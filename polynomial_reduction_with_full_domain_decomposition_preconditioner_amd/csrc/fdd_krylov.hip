@@ -25,6 +25,7 @@ struct GmresState
     double j_last;         // last column that enters the update
     double steps;          // steps counted until the stop (the reference's `iter` increment of this cycle)
     double converged;      // the reference's `converged` flag at the end of the cycle
+    double inv[kMax + 1];  // 1/gamma_0 and 1/||q_j||: the normalisation of basis vector j, applied by its readers
 };
 
 __global__ void gmres_begin_kernel(GmresState *st, const double *norm2, int first_cycle)
@@ -32,6 +33,7 @@ __global__ void gmres_begin_kernel(GmresState *st, const double *norm2, int firs
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double g0 = sqrt(*norm2);
     st->gamma[0] = g0;
+    st->inv[0] = 1.0 / g0; // subdomain.tpp:4358
     if (first_cycle) st->r0 = g0;
     st->hist[0] = g0;
     st->num_hist = 1.0;
@@ -65,6 +67,7 @@ __global__ void gmres_step_kernel(GmresState *st, const double *dots, int j, int
         st->converged = 1.0;
         return;
     }
+    st->inv[j + 1] = 1.0 / alpha_j; // subdomain.tpp:4457
     const double beta_j = sqrt(st->H[j][j] * st->H[j][j] + alpha_j * alpha_j);
     const double gamma_j = 1.0 / beta_j;
     st->c[j] = st->H[j][j] * gamma_j;
@@ -146,6 +149,13 @@ int fdd_gmres_fetch(void *state, double *y, double *hist, int *num_hist, int *j_
     if (j_last) *j_last = (int)h.j_last;
     if (steps) *steps = (int)h.steps;
     if (converged) *converged = (int)h.converged;
+    return 0;
+}
+
+int fdd_gmres_scales(void *state, const double **inv_dev)
+{
+    FDD_REQUIRE(state != nullptr && inv_dev != nullptr);
+    *inv_dev = static_cast<GmresState *>(state)->inv;
     return 0;
 }
 

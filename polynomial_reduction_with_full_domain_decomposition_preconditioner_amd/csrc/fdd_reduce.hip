@@ -252,13 +252,20 @@ struct MultiDotWOp
     static constexpr int NV = M;
     const double *a, *w;
     const double *b[M];
+    const double *bs; // optional: b_k stands for bs[k] * b_k (a Krylov basis kept unnormalised, its 1/norm on the device)
     __device__ void vec2(long long i, Acc<M> &acc) const
     {
         const double2 aa = ld2(a, i), ww = ld2(w, i);
 #pragma unroll
         for (int k = 0; k < M; k++)
         {
-            const double2 bb = ld2(b[k], i);
+            double2 bb = ld2(b[k], i);
+            if (bs)
+            {
+                const double sk = bs[k];
+                bb.x = sk * bb.x;
+                bb.y = sk * bb.y;
+            }
             acc.v[k] += aa.x * bb.x * ww.x;
             acc.v[k] += aa.y * bb.y * ww.y;
         }
@@ -266,16 +273,17 @@ struct MultiDotWOp
     __device__ void one(long long i, Acc<M> &acc) const
     {
 #pragma unroll
-        for (int k = 0; k < M; k++) acc.v[k] += a[i] * b[k][i] * w[i];
+        for (int k = 0; k < M; k++) acc.v[k] += a[i] * (bs ? bs[k] * b[k][i] : b[k][i]) * w[i];
     }
 };
 
 template <int M>
-int launch_multi_dot(double *out, double *ws, const double *a, const double *const *b, const double *w, int n, void *stream)
+int launch_multi_dot(double *out, double *ws, const double *a, const double *const *b, const double *b_scale_dev, const double *w, int n, void *stream)
 {
     MultiDotWOp<M> op;
     op.a = a;
     op.w = w;
+    op.bs = b_scale_dev;
     bool al = al2(a, w);
     for (int k = 0; k < M; k++)
     {
@@ -292,9 +300,11 @@ template <int M>
 struct MultiAxpyNormOp
 {
     static constexpr int NV = 1;
-    double *y;
+    double *dst;     // where the updated vector goes (y itself, or the next basis slot)
+    const double *y;
     const double *w, *c;
     const double *x[M];
+    const double *xs; // optional per-vector scales: x_k stands for xs[k] * x_k
     double sign;
     __device__ void vec2(long long i, Acc<1> &acc) const
     {
@@ -304,11 +314,17 @@ struct MultiAxpyNormOp
         for (int k = 0; k < M; k++)
         {
             const double ck = sign * c[k];
-            const double2 b = ld2(x[k], i);
+            double2 b = ld2(x[k], i);
+            if (xs)
+            {
+                const double sk = xs[k];
+                b.x = sk * b.x;
+                b.y = sk * b.y;
+            }
             yy.x = 1.0 * yy.x + ck * b.x;
             yy.y = 1.0 * yy.y + ck * b.y;
         }
-        reinterpret_cast<double2 *>(y)[i] = yy;
+        reinterpret_cast<double2 *>(dst)[i] = yy;
         acc.v[0] += yy.x * yy.x * ww.x;
         acc.v[0] += yy.y * yy.y * ww.y;
     }
@@ -316,21 +332,23 @@ struct MultiAxpyNormOp
     {
         double v = y[i];
 #pragma unroll
-        for (int k = 0; k < M; k++) v = 1.0 * v + (sign * c[k]) * x[k][i];
-        y[i] = v;
+        for (int k = 0; k < M; k++) v = 1.0 * v + (sign * c[k]) * (xs ? xs[k] * x[k][i] : x[k][i]);
+        dst[i] = v;
         acc.v[0] += v * v * w[i];
     }
 };
 
 template <int M>
-int launch_multi_axpy_norm(double *out, double *ws, double *y, const double *c, double sign, const double *const *x, const double *w, int n, void *stream)
+int launch_multi_axpy_norm(double *out, double *ws, double *dst, const double *y, const double *c, double sign, const double *const *x, const double *x_scale_dev, const double *w, int n, void *stream)
 {
     MultiAxpyNormOp<M> op;
+    op.dst = dst;
     op.y = y;
     op.w = w;
     op.c = c;
+    op.xs = x_scale_dev;
     op.sign = sign;
-    bool al = al2(y, w);
+    bool al = al2(y, w) && fdd_aligned16(dst);
     for (int k = 0; k < M; k++)
     {
         op.x[k] = x[k];
@@ -444,37 +462,48 @@ int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int s
 
 int fdd_multi_weighted_inner_product(double *out, double *ws, const double *a, const double *const *b, int m, const double *w, int n, void *stream)
 {
+    return fdd_multi_weighted_inner_product_scaled(out, ws, a, b, nullptr, m, w, n, stream);
+}
+
+int fdd_multi_weighted_inner_product_scaled(double *out, double *ws, const double *a, const double *const *b, const double *b_scale_dev, int m, const double *w, int n, void *stream)
+{
     FDD_REQUIRE(out != nullptr && ws != nullptr && n >= 0 && m >= 1 && m <= FDD_MULTI_MAX && b != nullptr);
     FDD_REQUIRE(n == 0 || (a != nullptr && w != nullptr));
     for (int k = 0; k < m; k++) FDD_REQUIRE(n == 0 || b[k] != nullptr);
     switch (m)
     {
-    case 1: return launch_multi_dot<1>(out, ws, a, b, w, n, stream);
-    case 2: return launch_multi_dot<2>(out, ws, a, b, w, n, stream);
-    case 3: return launch_multi_dot<3>(out, ws, a, b, w, n, stream);
-    case 4: return launch_multi_dot<4>(out, ws, a, b, w, n, stream);
-    case 5: return launch_multi_dot<5>(out, ws, a, b, w, n, stream);
-    case 6: return launch_multi_dot<6>(out, ws, a, b, w, n, stream);
-    case 7: return launch_multi_dot<7>(out, ws, a, b, w, n, stream);
-    default: return launch_multi_dot<8>(out, ws, a, b, w, n, stream);
+    case 1: return launch_multi_dot<1>(out, ws, a, b, b_scale_dev, w, n, stream);
+    case 2: return launch_multi_dot<2>(out, ws, a, b, b_scale_dev, w, n, stream);
+    case 3: return launch_multi_dot<3>(out, ws, a, b, b_scale_dev, w, n, stream);
+    case 4: return launch_multi_dot<4>(out, ws, a, b, b_scale_dev, w, n, stream);
+    case 5: return launch_multi_dot<5>(out, ws, a, b, b_scale_dev, w, n, stream);
+    case 6: return launch_multi_dot<6>(out, ws, a, b, b_scale_dev, w, n, stream);
+    case 7: return launch_multi_dot<7>(out, ws, a, b, b_scale_dev, w, n, stream);
+    default: return launch_multi_dot<8>(out, ws, a, b, b_scale_dev, w, n, stream);
     }
 }
 
 int fdd_multi_axpy_norm2_dev(double *out, double *ws, double *y, const double *coeffs_dev, double sign, const double *const *x, int m, const double *w, int n, void *stream)
 {
+    return fdd_multi_axpy_norm2_scaled_dev(out, ws, y, y, coeffs_dev, sign, x, nullptr, m, w, n, stream);
+}
+
+int fdd_multi_axpy_norm2_scaled_dev(double *out, double *ws, double *dst, const double *y, const double *coeffs_dev, double sign, const double *const *x, const double *x_scale_dev, int m, const double *w, int n, void *stream)
+{
+    FDD_REQUIRE(n == 0 || dst != nullptr);
     FDD_REQUIRE(out != nullptr && ws != nullptr && n >= 0 && m >= 1 && m <= FDD_MULTI_MAX && x != nullptr && coeffs_dev != nullptr);
     FDD_REQUIRE(n == 0 || (y != nullptr && w != nullptr));
     for (int k = 0; k < m; k++) FDD_REQUIRE(n == 0 || x[k] != nullptr);
     switch (m)
     {
-    case 1: return launch_multi_axpy_norm<1>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
-    case 2: return launch_multi_axpy_norm<2>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
-    case 3: return launch_multi_axpy_norm<3>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
-    case 4: return launch_multi_axpy_norm<4>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
-    case 5: return launch_multi_axpy_norm<5>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
-    case 6: return launch_multi_axpy_norm<6>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
-    case 7: return launch_multi_axpy_norm<7>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
-    default: return launch_multi_axpy_norm<8>(out, ws, y, coeffs_dev, sign, x, w, n, stream);
+    case 1: return launch_multi_axpy_norm<1>(out, ws, dst, y, coeffs_dev, sign, x, x_scale_dev, w, n, stream);
+    case 2: return launch_multi_axpy_norm<2>(out, ws, dst, y, coeffs_dev, sign, x, x_scale_dev, w, n, stream);
+    case 3: return launch_multi_axpy_norm<3>(out, ws, dst, y, coeffs_dev, sign, x, x_scale_dev, w, n, stream);
+    case 4: return launch_multi_axpy_norm<4>(out, ws, dst, y, coeffs_dev, sign, x, x_scale_dev, w, n, stream);
+    case 5: return launch_multi_axpy_norm<5>(out, ws, dst, y, coeffs_dev, sign, x, x_scale_dev, w, n, stream);
+    case 6: return launch_multi_axpy_norm<6>(out, ws, dst, y, coeffs_dev, sign, x, x_scale_dev, w, n, stream);
+    case 7: return launch_multi_axpy_norm<7>(out, ws, dst, y, coeffs_dev, sign, x, x_scale_dev, w, n, stream);
+    default: return launch_multi_axpy_norm<8>(out, ws, dst, y, coeffs_dev, sign, x, x_scale_dev, w, n, stream);
     }
 }
 

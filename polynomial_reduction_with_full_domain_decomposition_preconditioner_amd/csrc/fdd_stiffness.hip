@@ -250,7 +250,7 @@ __device__ __forceinline__ void element_sync()
 // kGather: u is read through point_dof (u[e,i,j,k] = v[point_dof[...]], 0 where
 // the point has no dof): the boolean scatter Q of Subdomain fused into the load.
 template <int n, bool kGather, bool kNTStore>
-__global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
+__global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ u_scale, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
 {
     using C = FusedCfg<n>;
     constexpr int nn = C::nn;
@@ -307,6 +307,12 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
 #pragma unroll
             for (int k = 0; k < n; k++)
                 if (d[k] >= 0) r_u[k] = u[d[k]];
+            if (u_scale) // v stands for (*u_scale) * v: a Krylov vector kept unnormalised (math.okl:29-35 applied on load)
+            {
+                const double sc = *u_scale;
+#pragma unroll
+                for (int k = 0; k < n; k++) r_u[k] = sc * r_u[k];
+            }
         }
         else
         {
@@ -440,24 +446,24 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
 }
 
 template <int n>
-int launch_fused(double *Au, const double *u, const int *point_dof, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
+int launch_fused(double *Au, const double *u, const int *point_dof, const double *u_scale, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
 {
     using C = FusedCfg<n>;
     const int grid = (num_elements + C::epb - 1) / C::epb;
     static const bool nt_store = fdd_env_int("FDD_TUNE_STIFFNESS_NT_STORE", 1) != 0;
     if (point_dof and nt_store)
-        hipLaunchKernelGGL((fused_stiffness_kernel<n, true, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((fused_stiffness_kernel<n, true, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
     else if (point_dof)
-        hipLaunchKernelGGL((fused_stiffness_kernel<n, true, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((fused_stiffness_kernel<n, true, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
     else if (nt_store)
-        hipLaunchKernelGGL((fused_stiffness_kernel<n, false, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((fused_stiffness_kernel<n, false, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
     else
-        hipLaunchKernelGGL((fused_stiffness_kernel<n, false, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((fused_stiffness_kernel<n, false, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
     FDD_LAUNCH_CHECK();
     return 0;
 }
 
-int fused_dispatch(double *Au, const double *u, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+int fused_dispatch(double *Au, const double *u, const int *point_dof, const double *u_scale, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
 {
     FDD_REQUIRE(num_elements >= 0);
     if (num_elements == 0) return 0;
@@ -471,21 +477,21 @@ int fused_dispatch(double *Au, const double *u, const int *point_dof, const doub
 
     switch (poly_degree + 1)
     {
-    case 2: return launch_fused<2>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 3: return launch_fused<3>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 4: return launch_fused<4>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 5: return launch_fused<5>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 6: return launch_fused<6>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 7: return launch_fused<7>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 8: return launch_fused<8>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 9: return launch_fused<9>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 10: return launch_fused<10>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 11: return launch_fused<11>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 12: return launch_fused<12>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 13: return launch_fused<13>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 14: return launch_fused<14>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 15: return launch_fused<15>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
-    case 16: return launch_fused<16>(Au, u, point_dof, D_hat, g, elem_offset, num_elements, stream);
+    case 2: return launch_fused<2>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 3: return launch_fused<3>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 4: return launch_fused<4>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 5: return launch_fused<5>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 6: return launch_fused<6>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 7: return launch_fused<7>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 8: return launch_fused<8>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 9: return launch_fused<9>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 10: return launch_fused<10>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 11: return launch_fused<11>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 12: return launch_fused<12>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 13: return launch_fused<13>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 14: return launch_fused<14>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 15: return launch_fused<15>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 16: return launch_fused<16>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
     default:
         fdd_set_error("fused stiffness kernel supports poly_degree 1..15, got %d (use the two-launch form)", poly_degree);
         return FDD_ERR_UNSUPPORTED;
@@ -543,18 +549,24 @@ int fdd_dom_stiffness_matrix_2(double *Au, const double *const GDu[3], const dou
 
 int fdd_dom_stiffness_matrix(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], int num_elements, int poly_degree, void *stream)
 {
-    return fused_dispatch(Au, u, nullptr, D_hat, G, nullptr, num_elements, poly_degree, stream);
+    return fused_dispatch(Au, u, nullptr, nullptr, D_hat, G, nullptr, num_elements, poly_degree, stream);
 }
 
 int fdd_sub_stiffness_matrix(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
 {
-    return fused_dispatch(Au, u, nullptr, D_hat, G, elem_offset, num_elements, poly_degree, stream);
+    return fused_dispatch(Au, u, nullptr, nullptr, D_hat, G, elem_offset, num_elements, poly_degree, stream);
 }
 
 int fdd_sub_stiffness_matrix_gather(double *Au, const double *v, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
 {
     FDD_REQUIRE(point_dof != nullptr);
-    return fused_dispatch(Au, v, point_dof, D_hat, G, elem_offset, num_elements, poly_degree, stream);
+    return fused_dispatch(Au, v, point_dof, nullptr, D_hat, G, elem_offset, num_elements, poly_degree, stream);
+}
+
+int fdd_sub_stiffness_matrix_gather_scaled(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    FDD_REQUIRE(point_dof != nullptr);
+    return fused_dispatch(Au, v, point_dof, v_scale_dev, D_hat, G, elem_offset, num_elements, poly_degree, stream);
 }
 
 int fdd_sub_stiffness_matrix_1(double *const GDu[3], const double *u, const double *const *D_hat_ptr, const int *offset, const int *vert, const int *level, const int *poly_degree, int num_levels, const double *const G[FDD_NUM_GEOM_FACTS], int num_points, int dim, void *stream)

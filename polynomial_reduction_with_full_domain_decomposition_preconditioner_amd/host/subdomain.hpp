@@ -133,6 +133,7 @@ class Subdomain
     fdd::memory ua, fa;          // assembled-space inner solve from point vectors: solution and right-hand side over the dofs
     fdd::memory point_dof_dev;   // dof of every level-0 point (-1: none): Q as an index array
     fdd::memory gmres_state;     // device-side GMRES bookkeeping (fdd_gmres_*_dev)
+    fdd::memory scaled_tmp;      // a normalised copy of a basis vector where a kernel cannot scale on load
     const MeshData<DType> *fine_mesh = nullptr; // level-0 coordinates (low-order FEM assembly)
 
     fdd::memory points_without_dof; // Dirichlet points: empty rows of Q
@@ -974,8 +975,8 @@ class Subdomain
         return true;
     }
 
-    // q (points) = A_local (Q z~)
-    void stiffness_from_dofs(fdd::memory &q, fdd::memory &za)
+    // q (points) = A_local (Q (s z~)), s = *scale_dev when given (a basis vector kept unnormalised)
+    void stiffness_from_dofs(fdd::memory &q, fdd::memory &za, const double *scale_dev = nullptr)
     {
         for (auto &ll : subdomain_operator.level_lists)
         {
@@ -983,7 +984,14 @@ class Subdomain
             if (ll.poly_degree >= 11 and mfma_stiffness)
             {
                 // the matrix-core kernel streams contiguous elements: scatter first (unit-value SpMV), then apply
-                subdomain_operator.Q.multiply(work_dev[0], za);
+                if (scale_dev)
+                {
+                    if (not scaled_tmp.ptr()) scaled_tmp = fdd::dev().malloc<DType>(std::max(subdomain_operator.num_extended_dofs, 1));
+                    FDD_CALL(fdd_vector_scaling_dev(scaled_tmp.as<double>(), scale_dev, za.as<double>(), subdomain_operator.num_extended_dofs, fdd::dev().stream));
+                    subdomain_operator.Q.multiply(work_dev[0], scaled_tmp);
+                }
+                else
+                    subdomain_operator.Q.multiply(work_dev[0], za);
                 stiffness_matrix(q, work_dev[0]);
                 return;
             }
@@ -992,10 +1000,10 @@ class Subdomain
             {
                 const double *Gs[NUM_GEOM_FACTS];
                 for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = subdomain_operator.G_ptrs[g] + ll.first_offset;
-                FDD_CALL(fdd_sub_stiffness_matrix_gather(q.as<double>() + ll.first_offset, za.as<double>(), point_dof_dev.template as<int>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), Gs, nullptr, ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                FDD_CALL(fdd_sub_stiffness_matrix_gather_scaled(q.as<double>() + ll.first_offset, za.as<double>(), scale_dev, point_dof_dev.template as<int>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), Gs, nullptr, ll.num_elements, ll.poly_degree, fdd::dev().stream));
             }
             else
-                FDD_CALL(fdd_sub_stiffness_matrix_gather(q.as<double>(), za.as<double>(), point_dof_dev.template as<int>(), subdomain_operator.D_hat[ll.level].template as<double>(), subdomain_operator.G_ptrs, ll.elem_offset.template as<int>(), ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                FDD_CALL(fdd_sub_stiffness_matrix_gather_scaled(q.as<double>(), za.as<double>(), scale_dev, point_dof_dev.template as<int>(), subdomain_operator.D_hat[ll.level].template as<double>(), subdomain_operator.G_ptrs, ll.elem_offset.template as<int>(), ll.num_elements, ll.poly_degree, fdd::dev().stream));
         }
     }
 
@@ -1054,63 +1062,72 @@ class Subdomain
         double *ws = reduce_ws.as<double>();
         const double *nw = norm_weight.as<double>();
         void *st = gmres_state.ptr();
-        const double *y_dev = nullptr;
+        const double *y_dev = nullptr, *inv_dev = nullptr;
         FDD_CALL(fdd_gmres_coefficients(st, &y_dev));
+        FDD_CALL(fdd_gmres_scales(st, &inv_dev));
 
-        auto dot_dofs = [&](double *out_dev, fdd::memory &a, const double *const *b, int count) {
+        // The basis is kept UNNORMALISED: W_j = r (j = 0) or the orthogonalised q (j > 0), with
+        // inv[j] = 1/gamma_0 or 1/||q|| in the device state.  Every reader forms inv[j] * W_j[d] on load
+        // -- the value vector_scaling would have stored (subdomain.tpp:4358, 4457), bit for bit -- so the
+        // normalisation pass per step disappears.
+        auto dot_dofs = [&](double *out_dev, fdd::memory &a, const double *const *b, const double *b_scale, int count) {
             fdd::ProfileScope prof("reduce_vec2_kernel<MultiDotW>", 8.0 * nd * (count + 2));
-            FDD_CALL(fdd_multi_weighted_inner_product(out_dev, ws, a.as<double>(), b, count, nw, nd, stream));
+            FDD_CALL(fdd_multi_weighted_inner_product_scaled(out_dev, ws, a.as<double>(), b, b_scale, count, nw, nd, stream));
         };
 
         FDD_CALL(fdd_set_to_value(ua.as<double>(), 0.0, nd, 0, stream));
 
         int iter = 0;
         bool first_cycle = true;
-        std::vector<const double *> ptrs(m + 1);
+        std::vector<const double *> W(m + 1), ptrs(m + 1);
+        std::vector<fdd::memory *> Wm(m + 1);
         std::vector<double> hist(FDD_MULTI_MAX + 1);
-        fdd::memory *ra = &fa;
 
         while (iter < max_iterations)
         {
-            if (not first_cycle)
+            if (first_cycle)
+            {
+                Wm[0] = &fa; // read only
+            }
+            else
             {
                 // r~ = f~ - Qt A Q u~
                 stiffness_from_dofs(q_k, ua);
                 gather_weighted(qa, q_k);
-                FDD_CALL(fdd_vector_vector_addition(qa.as<double>(), 1.0, fa.as<double>(), -1.0, qa.as<double>(), nd, stream));
-                ra = &qa;
+                FDD_CALL(fdd_vector_vector_addition(VA[0].template as<double>(), 1.0, fa.as<double>(), -1.0, qa.as<double>(), nd, stream));
+                Wm[0] = &VA[0];
             }
+            W[0] = Wm[0]->template as<double>();
             {
-                const double *self[1] = {ra->template as<double>()};
-                dot_dofs(sc, *ra, self, 1);
+                const double *self[1] = {W[0]};
+                dot_dofs(sc, *Wm[0], self, nullptr, 1);
             }
             FDD_CALL(fdd_gmres_begin_dev(st, sc, first_cycle ? 1 : 0, stream));
-            FDD_CALL(fdd_vector_scaling_rsqrt_dev(VA[0].template as<double>(), sc, ra->template as<double>(), nd, stream)); // V0 = r / gamma_0
 
             for (int j = 0; j < m; j++)
             {
-                fdd::memory *za = &VA[j];
                 if (use_preconditioner)
                 {
+                    // z~_j = V(inv_j W_j): the V-cycle wants the normalised vector in its own buffer anyway
                     amg::Level &fine = amg_checked();
-                    fine.f.copyFrom(VA[j], (size_t)nd * sizeof(DType));
+                    FDD_CALL(fdd_vector_scaling_dev(fine.f.as<double>(), inv_dev + j, W[j], nd, stream));
                     amg_hierarchy.vcycle();
                     ZA[j].copyFrom(fine.u, (size_t)nd * sizeof(DType));
-                    za = &ZA[j];
+                    stiffness_from_dofs(q_k, ZA[j]);
                 }
-                stiffness_from_dofs(q_k, *za);
+                else
+                    stiffness_from_dofs(q_k, *Wm[j], inv_dev + j);
                 gather_weighted(qa, q_k);
 
-                // the scalar slots alternate so that step j+1's reductions never overwrite what step j's bookkeeping reads
                 double *slot = sc + (j & 1) * FDD_MULTI_MAX;
-                for (int i = 0; i < j + 1; i++) ptrs[i] = VA[i].template as<double>();
-                dot_dofs(slot, qa, ptrs.data(), j + 1);
+                dot_dofs(slot, qa, W.data(), inv_dev, j + 1);
                 {
                     fdd::ProfileScope prof("reduce_vec2_kernel<MultiAxpyNorm>", 8.0 * nd * (j + 4));
-                    FDD_CALL(fdd_multi_axpy_norm2_dev(slot + (j + 1), ws, qa.as<double>(), slot, -1.0, ptrs.data(), j + 1, nw, nd, stream));
+                    FDD_CALL(fdd_multi_axpy_norm2_scaled_dev(slot + (j + 1), ws, VA[j + 1].template as<double>(), qa.as<double>(), slot, -1.0, W.data(), inv_dev, j + 1, nw, nd, stream));
                 }
+                Wm[j + 1] = &VA[j + 1];
+                W[j + 1] = VA[j + 1].template as<double>();
                 FDD_CALL(fdd_gmres_step_dev(st, slot, j, iter, max_iterations, tolerance, use_relative ? 1 : 0, stream));
-                FDD_CALL(fdd_vector_scaling_rsqrt_dev(VA[j + 1].template as<double>(), slot + (j + 1), qa.as<double>(), nd, stream));
             }
             FDD_CALL(fdd_gmres_finish_dev(st, m, stream));
 
@@ -1129,11 +1146,16 @@ class Subdomain
             }
             iter += steps;
 
-            for (int i = 0; i < j_last + 1; i++) ptrs[i] = use_preconditioner ? ZA[i].template as<double>() : VA[i].template as<double>();
             if (j_last >= 0)
             {
                 fdd::ProfileScope prof("ew_vec2_kernel<MultiAxpy>", 8.0 * nd * (j_last + 3));
-                FDD_CALL(fdd_multi_axpy_dev(ua.as<double>(), y_dev, ptrs.data(), j_last + 1, nd, stream));
+                if (use_preconditioner)
+                {
+                    for (int i = 0; i < j_last + 1; i++) ptrs[i] = ZA[i].template as<double>();
+                    FDD_CALL(fdd_multi_axpy_dev(ua.as<double>(), y_dev, ptrs.data(), j_last + 1, nd, stream));
+                }
+                else
+                    FDD_CALL(fdd_multi_axpy_scaled_dev(ua.as<double>(), y_dev, W.data(), inv_dev, j_last + 1, nd, stream));
             }
             first_cycle = false;
             if (converged) break;

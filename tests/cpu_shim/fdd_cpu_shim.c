@@ -334,6 +334,7 @@ typedef struct
     double y[KMAX];
     double hist[KMAX + 1];
     double r0, num_hist, stopped, j_last, steps, converged;
+    double inv[KMAX + 1];
 } shim_gmres_state;
 
 size_t fdd_gmres_state_bytes(void) { return sizeof(shim_gmres_state); }
@@ -344,6 +345,7 @@ int fdd_gmres_begin_dev(void *state, const double *norm2, int first_cycle, void 
     shim_gmres_state *st = (shim_gmres_state *)state;
     double g0 = sqrt(*norm2);
     st->gamma[0] = g0;
+    st->inv[0] = 1.0 / g0;
     if (first_cycle) st->r0 = g0;
     st->hist[0] = g0;
     st->num_hist = 1.0;
@@ -377,6 +379,7 @@ int fdd_gmres_step_dev(void *state, const double *dots, int j, int iterations_be
         st->converged = 1.0;
         return 0;
     }
+    st->inv[j + 1] = 1.0 / alpha_j;
     double beta_j = sqrt(st->H[j][j] * st->H[j][j] + alpha_j * alpha_j);
     double gamma_j = 1.0 / beta_j;
     st->c[j] = st->H[j][j] * gamma_j;
@@ -433,3 +436,79 @@ int fdd_gmres_coefficients(void *state, const double **y_dev)
 }
 
 int fdd_multi_axpy_dev(double *q, const double *c, const double *const *v, int m, int n, void *s) { return fdd_multi_axpy(q, c, v, m, n, s); }
+
+int fdd_gmres_scales(void *state, const double **inv_dev)
+{
+    *inv_dev = ((shim_gmres_state *)state)->inv;
+    return 0;
+}
+
+int fdd_vector_scaling_dev(double *au, const double *scale, const double *u, int n, void *s)
+{
+    (void)s;
+    orc_vector_scaling(au, *scale, u, n);
+    return 0;
+}
+
+/* the *_scaled forms: materialise scale * vector as vector_scaling would have, then the unscaled entry */
+static double **shim_scaled(const double *const *v, const double *scale, int m, int n)
+{
+    double **t = (double **)malloc(sizeof(double *) * (size_t)m);
+    for (int k = 0; k < m; k++)
+    {
+        t[k] = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+        orc_vector_scaling(t[k], scale[k], v[k], n);
+    }
+    return t;
+}
+static void shim_scaled_free(double **t, int m)
+{
+    for (int k = 0; k < m; k++) free(t[k]);
+    free(t);
+}
+
+int fdd_multi_weighted_inner_product_scaled(double *out, double *ws, const double *a, const double *const *b, const double *bs, int m, const double *w, int n, void *s)
+{
+    if (!bs) return fdd_multi_weighted_inner_product(out, ws, a, b, m, w, n, s);
+    double **t = shim_scaled(b, bs, m, n);
+    int rc = fdd_multi_weighted_inner_product(out, ws, a, (const double *const *)t, m, w, n, s);
+    shim_scaled_free(t, m);
+    return rc;
+}
+
+int fdd_multi_axpy_norm2_scaled_dev(double *out, double *ws, double *dst, const double *y, const double *c, double sign, const double *const *x, const double *xs, int m, const double *w, int n, void *s)
+{
+    if (dst != y) memmove(dst, y, sizeof(double) * (size_t)n);
+    if (!xs) return fdd_multi_axpy_norm2_dev(out, ws, dst, c, sign, x, m, w, n, s);
+    double **t = shim_scaled(x, xs, m, n);
+    int rc = fdd_multi_axpy_norm2_dev(out, ws, dst, c, sign, (const double *const *)t, m, w, n, s);
+    shim_scaled_free(t, m);
+    return rc;
+}
+
+int fdd_multi_axpy_scaled_dev(double *q, const double *c, const double *const *v, const double *vs, int m, int n, void *s)
+{
+    if (!vs) return fdd_multi_axpy(q, c, v, m, n, s);
+    double **t = shim_scaled(v, vs, m, n);
+    int rc = fdd_multi_axpy(q, c, (const double *const *)t, m, n, s);
+    shim_scaled_free(t, m);
+    return rc;
+}
+
+int fdd_sub_stiffness_matrix_gather_scaled(double *Au, const double *v, const double *vscale, const int *pd, const double *D, const double *const G[6], const int *eo, int ne, int N, void *s)
+{
+    if (!vscale) return fdd_sub_stiffness_matrix_gather(Au, v, pd, D, G, eo, ne, N, s);
+    /* the dof vector's length is not passed: scale what the index array reaches */
+    int n3 = (N + 1) * (N + 1) * (N + 1), maxd = -1;
+    for (int e = 0; e < ne; e++)
+    {
+        size_t o = eo ? (size_t)eo[e] : (size_t)e * n3;
+        for (int q = 0; q < n3; q++)
+            if (pd[o + q] > maxd) maxd = pd[o + q];
+    }
+    double *t = (double *)malloc(sizeof(double) * (size_t)(maxd + 2));
+    orc_vector_scaling(t, *vscale, v, maxd + 1);
+    int rc = fdd_sub_stiffness_matrix_gather(Au, t, pd, D, G, eo, ne, N, s);
+    free(t);
+    return rc;
+}

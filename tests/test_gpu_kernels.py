@@ -863,6 +863,61 @@ def test_multi_axpy_norm2_with_device_coefficients(gpu, m):
         assert np.array_equal(host(dx), sref)
 
 
+def test_scaled_forms_equal_scaling_first(gpu):
+    """The *_scaled entries read inv[k] * x_k[d] on load: exactly the values vector_scaling
+    would have stored, so each must equal (bit for bit / to reduction rounding) its unscaled
+    sibling applied to pre-scaled vectors."""
+    L = S.oracle()
+    ws = reduce_workspace(gpu)
+    m, n = 4, 300001
+    X = [rnd(n, 200 + i) for i in range(m)]
+    inv = np.abs(rnd(m, 210)) + 0.5
+    Xs = []
+    for i in range(m):
+        t = np.zeros(n)
+        L.orc_vector_scaling(P(t), ctypes.c_double(inv[i]), P(X[i]), n)
+        Xs.append(t)
+    a, w, c = rnd(n, 220), np.abs(rnd(n, 221)), rnd(m, 222)
+    dX, dXs, dinv = [dev(x, gpu) for x in X], [dev(x, gpu) for x in Xs], dev(inv, gpu)
+    # multi-dot
+    o1, o2 = torch.zeros(8, dtype=torch.float64, device=gpu), torch.zeros(8, dtype=torch.float64, device=gpu)
+    k("fdd_multi_weighted_inner_product_scaled", o1, ws, dev(a, gpu), dX, dinv, m, dev(w, gpu), n)
+    k("fdd_multi_weighted_inner_product", o2, ws, dev(a, gpu), dXs, m, dev(w, gpu), n)
+    assert np.array_equal(host(o1), host(o2))
+    # Gram-Schmidt update into a separate destination + norm
+    dy, dst1 = dev(a, gpu), torch.zeros(n, dtype=torch.float64, device=gpu)
+    n1, n2 = torch.zeros(1, dtype=torch.float64, device=gpu), torch.zeros(1, dtype=torch.float64, device=gpu)
+    k("fdd_multi_axpy_norm2_scaled_dev", n1, ws, dst1, dy, dev(c, gpu), -1.0, dX, dinv, m, dev(w, gpu), n)
+    assert np.array_equal(host(dy), a)  # the source is left alone
+    dy2 = dev(a, gpu)
+    k("fdd_multi_axpy_norm2_dev", n2, ws, dy2, dev(c, gpu), -1.0, dXs, m, dev(w, gpu), n)
+    assert np.array_equal(host(dst1), host(dy2)) and np.array_equal(host(n1), host(n2))
+    # solution update
+    q1, q2 = dev(a, gpu), dev(a, gpu)
+    k("fdd_multi_axpy_scaled_dev", q1, dev(c, gpu), dX, dinv, m, n)
+    k("fdd_multi_axpy_dev", q2, dev(c, gpu), dXs, m, n)
+    assert np.array_equal(host(q1), host(q2))
+    # scaling by a device scalar
+    out = torch.zeros(n, dtype=torch.float64, device=gpu)
+    k("fdd_vector_scaling_dev", out, dinv, dX[0], n)
+    assert np.array_equal(host(out), Xs[0])
+    # gather-on-load stiffness of a scaled dof vector
+    N, E = 7, 9
+    n3 = (N + 1) ** 3
+    _, G, D = stiffness_inputs(E, N, 230)
+    rng = np.random.default_rng(231)
+    ndof = 2000
+    pd = rng.integers(-1, ndof, E * n3).astype(np.int32)
+    v = rng.uniform(-1, 1, ndof)
+    vs = np.zeros(ndof)
+    L.orc_vector_scaling(P(vs), ctypes.c_double(inv[1]), P(v), ndof)
+    dG = [dev(g, gpu) for g in G]
+    A1, A2 = torch.zeros(E * n3, dtype=torch.float64, device=gpu), torch.zeros(E * n3, dtype=torch.float64, device=gpu)
+    k("fdd_sub_stiffness_matrix_gather_scaled", A1, dev(v, gpu), dinv[1:], dev(pd, gpu), dev(D, gpu), dG, None, E, N)
+    k("fdd_sub_stiffness_matrix_gather", A2, dev(vs, gpu), dev(pd, gpu), dev(D, gpu), dG, None, E, N)
+    assert np.array_equal(host(A1), host(A2))
+
+
 def test_gather_indexed(gpu):
     n_in, n_out = 5000, 7001
     x, sc = rnd(n_in, 70), rnd(n_out, 71)
