@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--comm", choices=["torch", "rccl"], default="torch", help="N>1: torch.distributed(nccl=RCCL) callbacks, or RCCL called directly")
     ap.add_argument("--no-precond", action="store_true")
     ap.add_argument("--amg", action="store_true", help="inner solve preconditioned by the low-order AMG V-cycle (config C5's preconditioner; hierarchy built by the host layer)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N>1 ranks all on cuda:0 with a gloo group staging device buffers over the host: exercises the multi-rank code path on a one-GPU box (not a measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-elements", type=int, default=20)
     ap.add_argument("--cpu-sample-steps", type=int, default=12)
@@ -130,12 +131,17 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
     from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
@@ -144,6 +150,8 @@ def main():
     H.set_print(False)
     if world == 1:
         H.comm_single()
+    elif args.rehearse_on_one_gpu:
+        H.comm_torch_callbacks(on_gpu=True, staged=True)
     elif args.comm == "rccl":
         H.comm_rccl_from_torch()
     else:
@@ -166,7 +174,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -242,7 +250,7 @@ def main():
             "points_per_gpu": info["num_local_points"],
             "unique_nodes": nodes,
             "preconditioner": "none" if args.no_precond else ("fdd_gmres4+amg_vcycle(%d levels)" % amg_levels if amg_levels else "fdd_gmres4"),
-            "comm": "single" if world == 1 else args.comm,
+            "comm": "single" if world == 1 else ("gloo-staged rehearsal on one GPU" if args.rehearse_on_one_gpu else args.comm),
         },
         "points_updates_per_s": info["num_local_points"] * world * args.steps / dt,
         "last_residual_norm": last_res,
