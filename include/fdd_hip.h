@@ -129,6 +129,7 @@ int fdd_dom_stiffness_matrix(double *Au, const double *u, const double *D_hat, c
  * NOT bit-identical to the reference arithmetic (agrees to ~1e-15 * max|Au|).  elem_offset as in
  * fdd_sub_stiffness_matrix (NULL => contiguous elements).  Au must not alias u. */
 int fdd_stiffness_matrix_mfma(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
+int fdd_stiffness_matrix_mfma_gather(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream); /* u[p] = (*v_scale_dev) * v[point_dof[p]] on load (scale may be NULL) */
 
 int fdd_dom_initialize_arrays(double *u_k, double *r_k, const double *f, int num_points, void *stream); /* domain.okl:100-107, domain.tpp:618,734 */
 

@@ -85,8 +85,9 @@ __device__ __forceinline__ void tile_add(double *dst, int base, int rs, int cs, 
     }
 }
 
-template <int n>
-__global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
+// kGather: u[p] = (*u_scale) * v[point_dof[p]] (0 where the point has no dof), as in fused_stiffness_kernel
+template <int n, bool kGather>
+__global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ u_scale, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *sU = smem;
@@ -124,6 +125,14 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
 #define valid(m) (vij && (k0 + 4 * (m) < n))
 
     auto elem_base = [&](int e) -> size_t { return elem_offset ? (size_t)elem_offset[e] : (size_t)e * n3; };
+    const double uscale = (kGather && u_scale) ? *u_scale : 1.0;
+    auto load_u = [&](size_t p, bool ok) -> double {
+        if (!ok) return 0.0;
+        if (!kGather) return u[p];
+        const int d = point_dof[p];
+        if (d < 0) return 0.0;
+        return u_scale ? uscale * u[d] : u[d];
+    };
 
     double ru[kPts], rg[FDD_NUM_GEOM_FACTS][kPts];
     int e = blockIdx.x;
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
 #pragma unroll
         for (int m = 0; m < kPts; m++)
         {
-            ru[m] = valid(m) ? u[base + goff(m)] : 0.0;
+            ru[m] = load_u(base + goff(m), valid(m));
 #pragma unroll
             for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? G.g[g][base + goff(m)] : 0.0;
         }
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
         if (more)
         {
 #pragma unroll
-            for (int m = 0; m < kPts; m++) ru[m] = valid(m) ? u[base_n + goff(m)] : 0.0;
+            for (int m = 0; m < kPts; m++) ru[m] = load_u(base_n + goff(m), valid(m));
         }
 
         // P1: first derivatives
@@ -212,26 +221,26 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
 }
 
 template <int n>
-int launch_mfma(double *Au, const double *u, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
+int launch_mfma(double *Au, const double *u, const int *point_dof, const double *u_scale, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
 {
     const size_t lds = 4 * (size_t)ARR * sizeof(double);
     static bool configured = false;
     if (!configured)
     {
-        FDD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_stiffness_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FDD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_stiffness_kernel<n, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FDD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_stiffness_kernel<n, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
     const int grid = num_elements < FDD_CU_COUNT ? num_elements : FDD_CU_COUNT;
-    hipLaunchKernelGGL(mfma_stiffness_kernel<n>, dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, D_hat, G, elem_offset, num_elements);
+    if (point_dof)
+        hipLaunchKernelGGL((mfma_stiffness_kernel<n, true>), dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
+    else
+        hipLaunchKernelGGL((mfma_stiffness_kernel<n, false>), dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
     FDD_LAUNCH_CHECK();
     return 0;
 }
 
-} // namespace
-
-extern "C" {
-
-int fdd_stiffness_matrix_mfma(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+int mfma_dispatch(double *Au, const double *u, const int *point_dof, const double *u_scale, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
 {
     FDD_REQUIRE(num_elements >= 0);
     if (num_elements == 0) return 0;
@@ -244,18 +253,33 @@ int fdd_stiffness_matrix_mfma(double *Au, const double *u, const double *D_hat, 
     }
     switch (poly_degree + 1)
     {
-    case 9: return launch_mfma<9>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 10: return launch_mfma<10>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 11: return launch_mfma<11>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 12: return launch_mfma<12>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 13: return launch_mfma<13>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 14: return launch_mfma<14>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 15: return launch_mfma<15>(Au, u, D_hat, g, elem_offset, num_elements, stream);
-    case 16: return launch_mfma<16>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+    case 9: return launch_mfma<9>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 10: return launch_mfma<10>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 11: return launch_mfma<11>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 12: return launch_mfma<12>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 13: return launch_mfma<13>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 14: return launch_mfma<14>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 15: return launch_mfma<15>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 16: return launch_mfma<16>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
     default:
         fdd_set_error("fp64-MFMA stiffness kernel supports poly_degree 8..15, got %d", poly_degree);
         return FDD_ERR_UNSUPPORTED;
     }
+}
+
+} // namespace
+
+extern "C" {
+
+int fdd_stiffness_matrix_mfma(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    return mfma_dispatch(Au, u, nullptr, nullptr, D_hat, G, elem_offset, num_elements, poly_degree, stream);
+}
+
+int fdd_stiffness_matrix_mfma_gather(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    FDD_REQUIRE(point_dof != nullptr);
+    return mfma_dispatch(Au, v, point_dof, v_scale_dev, D_hat, G, elem_offset, num_elements, poly_degree, stream);
 }
 
 } // extern "C"

@@ -662,8 +662,8 @@ class Domain
     {
         if (poly_degree >= 11 and mfma_stiffness)
         {
-            Q.multiply(work_dev[0], pn);
-            stiffness_matrix(q, work_dev[0]);
+            fdd::ProfileScope prof("mfma_stiffness_kernel<gather>", 60.0 * num_local_points + 8.0 * num_local_nodes);
+            FDD_CALL(fdd_stiffness_matrix_mfma_gather(q.as<double>(), pn.as<double>(), nullptr, point_node_dev.as<int>(), D_hat.as<double>(), G_ptrs, nullptr, num_local_elements, poly_degree, fdd::dev().stream));
             return;
         }
         fdd::ProfileScope prof("fused_stiffness_kernel<gather>", 60.0 * num_local_points + 8.0 * num_local_nodes);

@@ -133,7 +133,6 @@ class Subdomain
     fdd::memory ua, fa;          // assembled-space inner solve from point vectors: solution and right-hand side over the dofs
     fdd::memory point_dof_dev;   // dof of every level-0 point (-1: none): Q as an index array
     fdd::memory gmres_state;     // device-side GMRES bookkeeping (fdd_gmres_*_dev)
-    fdd::memory scaled_tmp;      // a normalised copy of a basis vector where a kernel cannot scale on load
     const MeshData<DType> *fine_mesh = nullptr; // level-0 coordinates (low-order FEM assembly)
 
     fdd::memory points_without_dof; // Dirichlet points: empty rows of Q
@@ -983,17 +982,16 @@ class Subdomain
             const double n3 = (double)(ll.poly_degree + 1) * (ll.poly_degree + 1) * (ll.poly_degree + 1);
             if (ll.poly_degree >= 11 and mfma_stiffness)
             {
-                // the matrix-core kernel streams contiguous elements: scatter first (unit-value SpMV), then apply
-                if (scale_dev)
+                fdd::ProfileScope prof("mfma_stiffness_kernel<gather>", (60.0 * n3) * ll.num_elements + 8.0 * subdomain_operator.num_extended_dofs);
+                if (ll.contiguous)
                 {
-                    if (not scaled_tmp.ptr()) scaled_tmp = fdd::dev().malloc<DType>(std::max(subdomain_operator.num_extended_dofs, 1));
-                    FDD_CALL(fdd_vector_scaling_dev(scaled_tmp.as<double>(), scale_dev, za.as<double>(), subdomain_operator.num_extended_dofs, fdd::dev().stream));
-                    subdomain_operator.Q.multiply(work_dev[0], scaled_tmp);
+                    const double *Gs[NUM_GEOM_FACTS];
+                    for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = subdomain_operator.G_ptrs[g] + ll.first_offset;
+                    FDD_CALL(fdd_stiffness_matrix_mfma_gather(q.as<double>() + ll.first_offset, za.as<double>(), scale_dev, point_dof_dev.template as<int>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), Gs, nullptr, ll.num_elements, ll.poly_degree, fdd::dev().stream));
                 }
                 else
-                    subdomain_operator.Q.multiply(work_dev[0], za);
-                stiffness_matrix(q, work_dev[0]);
-                return;
+                    FDD_CALL(fdd_stiffness_matrix_mfma_gather(q.as<double>(), za.as<double>(), scale_dev, point_dof_dev.template as<int>(), subdomain_operator.D_hat[ll.level].template as<double>(), subdomain_operator.G_ptrs, ll.elem_offset.template as<int>(), ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                continue;
             }
             fdd::ProfileScope prof("fused_stiffness_kernel<gather>", (60.0 * n3) * ll.num_elements + 8.0 * subdomain_operator.num_extended_dofs);
             if (ll.contiguous)

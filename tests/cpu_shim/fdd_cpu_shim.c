@@ -512,3 +512,8 @@ int fdd_sub_stiffness_matrix_gather_scaled(double *Au, const double *v, const do
     free(t);
     return rc;
 }
+
+int fdd_stiffness_matrix_mfma_gather(double *Au, const double *v, const double *vscale, const int *pd, const double *D, const double *const G[6], const int *eo, int ne, int N, void *s)
+{
+    return fdd_sub_stiffness_matrix_gather_scaled(Au, v, vscale, pd, D, G, eo, ne, N, s);
+}

@@ -519,6 +519,28 @@ def test_stiffness_mfma(gpu, N):
     assert np.all(o.reshape(2 * E, n3)[1::2] == 7.0)  # untouched elements
 
 
+@pytest.mark.parametrize("N", [8, 11, 13, 15])
+def test_stiffness_mfma_gather_on_load(gpu, N):
+    """The matrix-core kernel reading u through the point -> dof index array (and an optional
+    device scale) against the bit-exact scalar kernel fed the same values: MFMA tolerance."""
+    n3 = (N + 1) ** 3
+    E = 5
+    _, G, D = stiffness_inputs(E, N, 400 + N)
+    rng = np.random.default_rng(410 + N)
+    ndof = (E * n3) // 2
+    pd = rng.integers(-1, ndof, E * n3).astype(np.int32)
+    v = rng.uniform(-1, 1, ndof)
+    scale = np.array([0.37])
+    u = np.where(pd >= 0, scale[0] * v[np.maximum(pd, 0)], 0.0)
+    Au, _ = oracle_stiffness(u, G, D, N, 3)
+    dG = [dev(g, gpu) for g in G]
+    for sc in (None, dev(scale, gpu)):
+        ref = Au if sc is not None else oracle_stiffness(np.where(pd >= 0, v[np.maximum(pd, 0)], 0.0), G, D, N, 3)[0]
+        out = torch.full((E * n3,), 7.0, dtype=torch.float64, device=gpu)
+        k("fdd_stiffness_matrix_mfma_gather", out, dev(v, gpu), sc, dev(pd, gpu), dev(D, gpu), dG, None, E, N)
+        assert np.abs(host(out) - ref).max() <= 1e-12 * np.abs(ref).max(), N
+
+
 def test_stiffness_fused_unsupported_degree(gpu):
     z = torch.zeros(8, dtype=torch.float64, device=gpu)
     with pytest.raises(lib.FddError):
