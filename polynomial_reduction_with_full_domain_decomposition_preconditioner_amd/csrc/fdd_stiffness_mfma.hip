@@ -126,25 +126,37 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
 
     auto elem_base = [&](int e) -> size_t { return elem_offset ? (size_t)elem_offset[e] : (size_t)e * n3; };
     const double uscale = (kGather && u_scale) ? *u_scale : 1.0;
-    auto load_u = [&](size_t p, bool ok) -> double {
-        if (!ok) return 0.0;
-        if (!kGather) return u[p];
-        const int d = point_dof[p];
+    // kGather: the dof indices run one element ahead of the values they address (rd), so that the value
+    // loads of the prefetch never wait on an index load issued in the same phase
+    auto load_idx = [&](size_t p, bool ok) -> int { return ok ? point_dof[p] : -1; };
+    auto load_val = [&](int d) -> double {
         if (d < 0) return 0.0;
         return u_scale ? uscale * u[d] : u[d];
     };
 
     double ru[kPts], rg[FDD_NUM_GEOM_FACTS][kPts];
+    int rd[kGather ? kPts : 1];
     int e = blockIdx.x;
     if (e < num_elements)
     {
         const size_t base = elem_base(e);
+        if (kGather)
+        {
+#pragma unroll
+            for (int m = 0; m < kPts; m++) rd[m] = load_idx(base + goff(m), valid(m));
+        }
 #pragma unroll
         for (int m = 0; m < kPts; m++)
         {
-            ru[m] = load_u(base + goff(m), valid(m));
+            ru[m] = kGather ? load_val(rd[kGather ? m : 0]) : (valid(m) ? u[base + goff(m)] : 0.0);
 #pragma unroll
             for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? G.g[g][base + goff(m)] : 0.0;
+        }
+        if (kGather && e + (int)gridDim.x < num_elements)
+        {
+            const size_t base_n = elem_base(e + gridDim.x);
+#pragma unroll
+            for (int m = 0; m < kPts; m++) rd[m] = load_idx(base_n + goff(m), valid(m));
         }
     }
 
@@ -162,7 +174,13 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
         if (more)
         {
 #pragma unroll
-            for (int m = 0; m < kPts; m++) ru[m] = load_u(base_n + goff(m), valid(m));
+            for (int m = 0; m < kPts; m++) ru[m] = kGather ? load_val(rd[kGather ? m : 0]) : (valid(m) ? u[base_n + goff(m)] : 0.0);
+            if (kGather && en + (int)gridDim.x < num_elements)
+            {
+                const size_t base_nn = elem_base(en + gridDim.x);
+#pragma unroll
+                for (int m = 0; m < kPts; m++) rd[m] = load_idx(base_nn + goff(m), valid(m));
+            }
         }
 
         // P1: first derivatives
