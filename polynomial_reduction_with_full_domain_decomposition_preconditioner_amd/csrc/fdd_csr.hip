@@ -106,16 +106,18 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
 #pragma unroll
         for (int it = 0; it < kIts; it++)
         {
+            // unconditional loads on a selected index (see fdd_multi_row_sum): 8 loads per lane in flight
             const int k = threadIdx.x + it * kBlock;
-            const bool on = k < nnz;
-            c[it] = on ? A_col[base + k] : 0;
-            a[it] = (UNIT || !on) ? 1.0 : A_val[base + k];
+            const int ks = (k < nnz) ? k : 0;
+            c[it] = A_col[base + ks];
+            a[it] = UNIT ? 1.0 : A_val[base + ks];
         }
 #pragma unroll
         for (int it = 0; it < kIts; it++)
         {
             const int k = threadIdx.x + it * kBlock;
-            if (k < nnz) prod[k] = a[it] * u[c[it]];
+            const double x = u[c[it]];
+            if (k < nnz) prod[k] = a[it] * x;
         }
         __syncthreads();
 
@@ -185,21 +187,37 @@ template <int MODE, bool WEIGHT, bool MASK>
 __global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double *__restrict__ t, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const double *u, const double *__restrict__ node_weight, const double *__restrict__ point_mask, const int *__restrict__ row_blocks, int block_first, int row_lo, int row_hi)
 {
     __shared__ double x[kBlockNnz];
+    __shared__ int sp[kBlockRowsMax + 1]; // the block's row pointers, relative to its first non-zero
     constexpr int kIts = kBlockNnz / kBlock;
+    constexpr int kRowIts = kBlockRowsMax / kBlock;
 
     const int b = block_first + blockIdx.x;
     const int r0 = row_blocks[b] > row_lo ? row_blocks[b] : row_lo;
     const int r1 = row_blocks[b + 1] < row_hi ? row_blocks[b + 1] : row_hi;
     if (r1 <= r0) return;
+    const int nrows = r1 - r0; // <= kBlockRowsMax (the plan)
     const int base = Qt_ptr[r0];
     const int nnz = Qt_ptr[r1] - base; // <= kBlockNnz: boolean gather rows are short (the plan checks)
 
-    int c[kIts];
+    // Every global load of the block is issued up front and UNCONDITIONALLY (out-of-range slots re-read
+    // entry 0): a load under a lane predicate compiles to a branch with its own s_waitcnt, and the loads
+    // of a lane then complete one HBM latency after the other instead of together.
+    int c[kIts], rp[kRowIts];
+    double wn[kRowIts], tv[kRowIts];
 #pragma unroll
     for (int it = 0; it < kIts; it++)
     {
         const int k = threadIdx.x + it * kBlock;
-        c[it] = (k < nnz) ? __builtin_nontemporal_load(Qt_col + base + k) : 0; // the index stream is read once
+        c[it] = __builtin_nontemporal_load(Qt_col + base + ((k < nnz) ? k : 0)); // the index stream is read once
+    }
+#pragma unroll
+    for (int it = 0; it < kRowIts; it++)
+    {
+        const int r = threadIdx.x + it * kBlock;
+        const int rs = (r < nrows) ? r : 0;
+        rp[it] = Qt_ptr[r0 + rs + 1];
+        if (WEIGHT && MODE != 2) wn[it] = node_weight[r0 + rs];
+        if (MODE == 2) tv[it] = t[r0 + rs];
     }
     if (MODE != 2)
     {
@@ -207,29 +225,41 @@ __global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double
         for (int it = 0; it < kIts; it++)
         {
             const int k = threadIdx.x + it * kBlock;
-            if (k < nnz) x[k] = 1.0 * u[c[it]];
+            const double v = u[c[it]];
+            if (k < nnz) x[k] = 1.0 * v;
         }
-        __syncthreads();
     }
-
-    for (int row = r0 + threadIdx.x; row < r1; row += kBlock)
+    if (threadIdx.x == 0) sp[0] = 0;
+#pragma unroll
+    for (int it = 0; it < kRowIts; it++)
     {
-        const int j0 = Qt_ptr[row] - base;
-        const int j1 = Qt_ptr[row + 1] - base;
-        double s;
-        if (MODE != 2)
+        const int r = threadIdx.x + it * kBlock;
+        if (r < nrows) sp[r + 1] = rp[it] - base;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int it = 0; it < kRowIts; it++)
+    {
+        const int r = threadIdx.x + it * kBlock;
+        if (r < nrows)
         {
-            s = 0.0;
-            for (int j = j0; j < j1; j++) s += x[j];
-            if (WEIGHT) s = s * node_weight[row];
-            if (t) t[row] = s;
+            const int j0 = sp[r], j1 = sp[r + 1];
+            double s;
+            if (MODE != 2)
+            {
+                s = 0.0;
+                for (int j = j0; j < j1; j++) s += x[j];
+                if (WEIGHT) s = s * wn[it];
+                if (t) t[r0 + r] = s;
+            }
+            else
+            {
+                s = tv[it];
+            }
+            if (MODE != 1)
+                for (int j = j0; j < j1; j++) x[j] = s;
         }
-        else
-        {
-            s = t[row];
-        }
-        if (MODE != 1)
-            for (int j = j0; j < j1; j++) x[j] = s;
     }
 
     if (MODE != 1)
@@ -239,11 +269,7 @@ __global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double
         if (MASK)
         {
 #pragma unroll
-            for (int it = 0; it < kIts; it++)
-            {
-                const int k = threadIdx.x + it * kBlock;
-                mk[it] = (k < nnz) ? point_mask[c[it]] : 0.0;
-            }
+            for (int it = 0; it < kIts; it++) mk[it] = point_mask[c[it]];
         }
 #pragma unroll
         for (int it = 0; it < kIts; it++)
@@ -278,14 +304,15 @@ __global__ __launch_bounds__(kBlock) void gather_norm2_block_kernel(double *__re
         for (int it = 0; it < kIts; it++)
         {
             const int k = threadIdx.x + it * kBlock;
-            c[it] = (k < nnz) ? Qt_col[base + k] : 0;
+            c[it] = Qt_col[base + ((k < nnz) ? k : 0)]; // unconditional on a selected index: all loads in flight
         }
         __syncthreads(); // previous block's readers of x are done
 #pragma unroll
         for (int it = 0; it < kIts; it++)
         {
             const int k = threadIdx.x + it * kBlock;
-            if (k < nnz) x[k] = 1.0 * u[c[it]];
+            const double v = u[c[it]];
+            if (k < nnz) x[k] = 1.0 * v;
         }
         __syncthreads();
         for (int row = r0 + threadIdx.x; row < r1; row += kBlock)
