@@ -163,13 +163,30 @@ __global__ __launch_bounds__(kBlock) void fill_indexed_kernel(double *__restrict
 // assembled numberings (domain nodes <-> subdomain dofs) with the stitching weight folded in
 __global__ __launch_bounds__(kBlock) void gather_indexed_kernel(double *__restrict__ out, const double *__restrict__ in, const int *__restrict__ index, const double *__restrict__ scale, int n)
 {
-    const int stride = gridDim.x * kBlock;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    // 4 entries per lane per pass, every load unconditional (index 0 stands in for "none" and past the end)
+    constexpr int U = 4;
+    const int stride = gridDim.x * kBlock * U;
+    for (int i0 = blockIdx.x * kBlock * U + threadIdx.x; i0 < n; i0 += stride)
     {
-        const int s = index[i];
-        double v = (s >= 0) ? in[s] : 0.0;
-        if (scale) v *= scale[i];
-        out[i] = v;
+        int s[U];
+        double v[U], sc[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+        {
+            const int i = i0 + k * kBlock;
+            s[k] = index[i < n ? i : 0];
+            sc[k] = scale ? scale[i < n ? i : 0] : 1.0;
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++) v[k] = in[s[k] < 0 ? 0 : s[k]];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+        {
+            const int i = i0 + k * kBlock;
+            double r = (s[k] >= 0) ? v[k] : 0.0;
+            if (scale) r *= sc[k];
+            if (i < n) out[i] = r;
+        }
     }
 }
 } // namespace
@@ -205,7 +222,7 @@ int fdd_gather_indexed(double *out, const double *in, const int *index, const do
     FDD_REQUIRE(n >= 0);
     if (n == 0) return 0;
     FDD_REQUIRE(out != nullptr && in != nullptr && index != nullptr && out != in);
-    hipLaunchKernelGGL(gather_indexed_kernel, dim3(fdd_stream_grid(n, kBlock)), dim3(kBlock), 0, fdd_stream(stream), out, in, index, scale, n);
+    hipLaunchKernelGGL(gather_indexed_kernel, dim3(fdd_stream_grid((n + 3) / 4, kBlock)), dim3(kBlock), 0, fdd_stream(stream), out, in, index, scale, n);
     FDD_LAUNCH_CHECK();
     return 0;
 }

@@ -304,9 +304,12 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
             int d[n];
 #pragma unroll
             for (int k = 0; k < n; k++) d[k] = __builtin_nontemporal_load(pd + (ij + k * nn));
+            // unconditional loads on a selected index (dof 0 stands in where the point has none): a load
+            // under a lane predicate becomes a branch with its own wait and the n loads serialise
 #pragma unroll
-            for (int k = 0; k < n; k++)
-                if (d[k] >= 0) r_u[k] = u[d[k]];
+            for (int k = 0; k < n; k++) r_u[k] = u[d[k] < 0 ? 0 : d[k]];
+#pragma unroll
+            for (int k = 0; k < n; k++) r_u[k] = (d[k] < 0) ? 0.0 : r_u[k];
             if (u_scale) // v stands for (*u_scale) * v: a Krylov vector kept unnormalised (math.okl:29-35 applied on load)
             {
                 const double sc = *u_scale;
