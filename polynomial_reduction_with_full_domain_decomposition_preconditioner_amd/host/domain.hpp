@@ -78,6 +78,8 @@ class Domain
     fdd::memory r_k, r_kp1, q_k, z_k, p_k;
     std::vector<fdd::memory> V;
     std::vector<fdd::memory> Z;
+    std::vector<fdd::memory> VA; // assembled copies of the outer GMRES basis
+    int va_valid = 0;            // VA[0..va_valid) match V of the current cycle
     std::vector<std::vector<DType>> H;
     std::vector<DType> c_gmres;
     std::vector<DType> s_gmres;
@@ -185,6 +187,20 @@ class Domain
         }
     }
 
+    // VA[i] = mask * QQt V[i], made once per basis vector (restructured outer GMRES)
+    void gmres_cache_assembled(int upto)
+    {
+        if ((int)VA.size() != num_vectors + 1)
+        {
+            for (auto &m : VA) m.free();
+            VA.resize(num_vectors + 1);
+            for (auto &m : VA) m = fdd::dev().malloc<DType>(num_local_points);
+            va_valid = 0;
+        }
+        for (int i = va_valid; i <= upto; i++) direct_stiffness_summation(VA[i], V[i]);
+        va_valid = std::max(va_valid, upto + 1);
+    }
+
     void allocate_gmres()
     {
         if (gmres_allocated) return;
@@ -226,6 +242,7 @@ class Domain
     int preconditioner_type = 1;
     bool use_preconditioner = true;
     bool fused_dssum = true; // gather-scatter kernel instead of the reference's Qt / Q SpMV pair
+    bool restructured_outer = true; // outer GMRES: cached assembled basis, multi-dot, multi-axpy
     bool assembled_outer = true; // flexible CG on node vectors (one value per assembled node) when the configuration allows it
     bool device_scalars = true;  // node-space flexible CG: alpha / beta read by the update kernels from device memory, residual norm fetched late
     bool mfma_stiffness = true; // N >= 11: stiffness on the fp64 matrix cores (not bit-identical; 1e-12 tolerance)
@@ -1030,6 +1047,7 @@ class Domain
             timer.start("domain.vector_operations");
             math.vector_scaling(V[0], 1.0 / gamma[0], r_k, num_local_points);
             timer.stop("domain.vector_operations");
+            va_valid = 0; // a new basis
 
             for (j = 0; j < num_vectors; j++)
             {
@@ -1040,18 +1058,55 @@ class Domain
                 timer.stop("domain.operator_application");
 
                 // classical Gram-Schmidt: every H[i][j] from the same q_k (domain.tpp:810-815)
-                for (int i = 0; i < j + 1; i++)
+                if (restructured_outer)
                 {
+                    // <q, V_i> = sum q * (QQt V_i) * mask with the assembled copy VA[i] = mask * QQt V_i cached when
+                    // V_i was made (the reference redoes the dssum inside each of the (j+1)(j+2)/2 products);
+                    // the (j+1) dots read q once per group of FDD_MULTI_MAX, the (j+1) updates are one pass per group
                     timer.start("domain.inner_products");
-                    assembled_inner_product(H[i][j], q_k, V[i]);
+                    gmres_cache_assembled(j);
+                    std::vector<double> h(j + 1);
+                    for (int g0 = 0; g0 < j + 1; g0 += FDD_MULTI_MAX)
+                    {
+                        const int cnt = std::min(FDD_MULTI_MAX, j + 1 - g0);
+                        const double *ptrs[FDD_MULTI_MAX];
+                        for (int i = 0; i < cnt; i++) ptrs[i] = VA[g0 + i].template as<double>();
+                        FDD_CALL(fdd_multi_weighted_inner_product(scalars.as<double>(), reduce_ws.as<double>(), q_k.as<double>(), ptrs, cnt, dirichlet_mask.as<double>(), num_local_points, fdd::dev().stream));
+                        fetch_scalars(h.data() + g0, cnt);
+                    }
+                    for (int i = 0; i < j + 1; i++) H[i][j] = h[i];
                     timer.stop("domain.inner_products");
-                }
 
-                for (int i = 0; i < j + 1; i++)
-                {
                     timer.start("domain.vector_operations");
-                    math.vector_vector_addition(q_k, 1.0, q_k, -H[i][j], V[i], num_local_points);
+                    for (int g0 = 0; g0 < j + 1; g0 += FDD_MULTI_MAX)
+                    {
+                        const int cnt = std::min(FDD_MULTI_MAX, j + 1 - g0);
+                        const double *ptrs[FDD_MULTI_MAX];
+                        double coeffs[FDD_MULTI_MAX];
+                        for (int i = 0; i < cnt; i++)
+                        {
+                            ptrs[i] = V[g0 + i].template as<double>();
+                            coeffs[i] = -H[g0 + i][j];
+                        }
+                        FDD_CALL(fdd_multi_axpy(q_k.as<double>(), coeffs, ptrs, cnt, num_local_points, fdd::dev().stream));
+                    }
                     timer.stop("domain.vector_operations");
+                }
+                else
+                {
+                    for (int i = 0; i < j + 1; i++)
+                    {
+                        timer.start("domain.inner_products");
+                        assembled_inner_product(H[i][j], q_k, V[i]);
+                        timer.stop("domain.inner_products");
+                    }
+
+                    for (int i = 0; i < j + 1; i++)
+                    {
+                        timer.start("domain.vector_operations");
+                        math.vector_vector_addition(q_k, 1.0, q_k, -H[i][j], V[i], num_local_points);
+                        timer.stop("domain.vector_operations");
+                    }
                 }
 
                 for (int i = 0; i < j; i++)
@@ -1129,11 +1184,26 @@ class Domain
                 c_gmres[k] = gamma_k / H[k][k];
             }
 
-            for (int i = 0; i < j + 1; i++)
+            if (restructured_outer)
             {
                 timer.start("domain.vector_operations");
-                math.vector_vector_addition(u_k, 1.0, u_k, c_gmres[i], Z[i], num_local_points);
+                for (int g0 = 0; g0 < j + 1; g0 += FDD_MULTI_MAX)
+                {
+                    const int cnt = std::min(FDD_MULTI_MAX, j + 1 - g0);
+                    const double *ptrs[FDD_MULTI_MAX];
+                    for (int i = 0; i < cnt; i++) ptrs[i] = Z[g0 + i].template as<double>();
+                    FDD_CALL(fdd_multi_axpy(u_k.as<double>(), c_gmres.data() + g0, ptrs, cnt, num_local_points, fdd::dev().stream));
+                }
                 timer.stop("domain.vector_operations");
+            }
+            else
+            {
+                for (int i = 0; i < j + 1; i++)
+                {
+                    timer.start("domain.vector_operations");
+                    math.vector_vector_addition(u_k, 1.0, u_k, c_gmres[i], Z[i], num_local_points);
+                    timer.stop("domain.vector_operations");
+                }
             }
 
             if (converged) break;

@@ -424,6 +424,7 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
     else if (s == "restructured_inner_solve")
     {
         if (p->subdomain) p->subdomain->restructured = value != 0;
+        for (auto &kv : p->domains) kv.second.restructured_outer = value != 0; // the same restructure of the outer GMRES
     }
     else if (s == "assembled_outer_solve")
     {
