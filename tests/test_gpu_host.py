@@ -303,3 +303,25 @@ def test_mesh_file_roundtrip(setup, tmp_path):
     finally:
         p.close()
         q.close()
+
+
+@pytest.mark.parametrize("nv,mi", [(2, 5), (3, 7), (4, 9)])
+@pytest.mark.parametrize("device_bookkeeping", [0, 1])
+def test_inner_gmres_restarts_and_stops_inside_a_cycle(setup, nv, mi, device_bookkeeping):
+    """Inner GMRES(nv) with max_iterations not a multiple of nv: restart cycles (the residual is
+    rebuilt from the dof-space solution) and a stop in the middle of the last cycle -- recorded by the
+    device-side bookkeeping while the remaining steps still run -- against the oracle's host loop."""
+    p = make_problem(E1, N1, RED1, True)
+    sd = oracle_subdomain(p, N1, RED1)
+    try:
+        p.set_options(sub_num_vectors=nv, sub_max_iterations=mi)
+        p.set_flag("device_bookkeeping", device_bookkeeping)
+        r = S.seeded_uniform(p.n, 15) - 0.5
+        z, hist = p.precond_apply(r, "gmres")
+        oz, oits, ohist = sd.solve(r, "gmres", num_vectors=nv, max_iterations=mi)
+        assert len(hist) == len(ohist) == mi + 1
+        assert np.abs(hist - ohist).max() <= 1e-9 * ohist[0]
+        assert np.abs(z - oz).max() <= 1e-9 * np.abs(oz).max()
+    finally:
+        sd.close()
+        p.close()
