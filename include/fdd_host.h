@@ -100,6 +100,9 @@ int fddh_problem_set_options(fddh_problem *p, int max_iterations, double toleran
  *   "assembled_outer_solve"    1: flexible CG on node vectors (one value per assembled node): Q fused into the stiffness
  *                              load, no dssum pass, the inner solve entered and left in dof numbering (default when the
  *                              inner solve is the assembled GMRES or there is no preconditioner); 0: point vectors
+ *   "device_bookkeeping"       1: Givens rotations / stopping tests of the inner GMRES in one-thread kernels and alpha, beta
+ *                              of the node-space PCG read from device memory: two host synchronisations per PCG step
+ *                              (default); 0: the host computes them between launches, as the reference does
  *   "assembled_inner_solve"    1: inner GMRES on vectors over the dofs, Q fused into the stiffness load, one host
  *                              synchronisation per step (default); 0: the point-space forms above
  *   "mfma_stiffness"           1: degrees 11..15 apply the stiffness on the fp64 matrix cores (default;
