@@ -240,6 +240,7 @@ int fdd_gmres_coefficients(void *state, const double **y_dev);
  * vector_scaling would have applied, subdomain.tpp:4358, 4457) for the *_scaled entries below to apply on load */
 int fdd_gmres_scales(void *state, const double **inv_dev);
 int fdd_sub_stiffness_matrix_gather_scaled(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
+/* in the multi-vector reductions below w == NULL means unit weights: nothing is read, and x * 1.0 is x bit for bit */
 int fdd_multi_weighted_inner_product_scaled(double *out, double *ws, const double *a, const double *const *b, const double *b_scale_dev, int m, const double *w, int n, void *stream);
 int fdd_multi_axpy_norm2_scaled_dev(double *out, double *ws, double *dst, const double *y, const double *coeffs_dev, double sign, const double *const *x, const double *x_scale_dev, int m, const double *w, int n, void *stream);
 int fdd_multi_axpy_scaled_dev(double *q, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream);

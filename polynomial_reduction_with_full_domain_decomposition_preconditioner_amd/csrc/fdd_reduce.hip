@@ -255,7 +255,7 @@ struct MultiDotWOp
     const double *bs; // optional: b_k stands for bs[k] * b_k (a Krylov basis kept unnormalised, its 1/norm on the device)
     __device__ void vec2(long long i, Acc<M> &acc) const
     {
-        const double2 aa = ld2(a, i), ww = ld2(w, i);
+        const double2 aa = ld2(a, i), ww = w ? ld2(w, i) : make_double2(1.0, 1.0); // w == NULL: unit weights, not read (x * 1.0 is x)
 #pragma unroll
         for (int k = 0; k < M; k++)
         {
@@ -273,7 +273,7 @@ struct MultiDotWOp
     __device__ void one(long long i, Acc<M> &acc) const
     {
 #pragma unroll
-        for (int k = 0; k < M; k++) acc.v[k] += a[i] * (bs ? bs[k] * b[k][i] : b[k][i]) * w[i];
+        for (int k = 0; k < M; k++) acc.v[k] += a[i] * (bs ? bs[k] * b[k][i] : b[k][i]) * (w ? w[i] : 1.0);
     }
 };
 
@@ -284,7 +284,7 @@ int launch_multi_dot(double *out, double *ws, const double *a, const double *con
     op.a = a;
     op.w = w;
     op.bs = b_scale_dev;
-    bool al = al2(a, w);
+    bool al = al2(a, w); // NULL counts as aligned
     for (int k = 0; k < M; k++)
     {
         op.b[k] = b[k];
@@ -309,7 +309,7 @@ struct MultiAxpyNormOp
     __device__ void vec2(long long i, Acc<1> &acc) const
     {
         double2 yy = ld2(y, i);
-        const double2 ww = ld2(w, i);
+        const double2 ww = w ? ld2(w, i) : make_double2(1.0, 1.0);
 #pragma unroll
         for (int k = 0; k < M; k++)
         {
@@ -334,7 +334,7 @@ struct MultiAxpyNormOp
 #pragma unroll
         for (int k = 0; k < M; k++) v = 1.0 * v + (sign * c[k]) * (xs ? xs[k] * x[k][i] : x[k][i]);
         dst[i] = v;
-        acc.v[0] += v * v * w[i];
+        acc.v[0] += v * v * (w ? w[i] : 1.0);
     }
 };
 
@@ -468,7 +468,7 @@ int fdd_multi_weighted_inner_product(double *out, double *ws, const double *a, c
 int fdd_multi_weighted_inner_product_scaled(double *out, double *ws, const double *a, const double *const *b, const double *b_scale_dev, int m, const double *w, int n, void *stream)
 {
     FDD_REQUIRE(out != nullptr && ws != nullptr && n >= 0 && m >= 1 && m <= FDD_MULTI_MAX && b != nullptr);
-    FDD_REQUIRE(n == 0 || (a != nullptr && w != nullptr));
+    FDD_REQUIRE(n == 0 || a != nullptr); // w == NULL: unit weights
     for (int k = 0; k < m; k++) FDD_REQUIRE(n == 0 || b[k] != nullptr);
     switch (m)
     {
@@ -492,7 +492,7 @@ int fdd_multi_axpy_norm2_scaled_dev(double *out, double *ws, double *dst, const 
 {
     FDD_REQUIRE(n == 0 || dst != nullptr);
     FDD_REQUIRE(out != nullptr && ws != nullptr && n >= 0 && m >= 1 && m <= FDD_MULTI_MAX && x != nullptr && coeffs_dev != nullptr);
-    FDD_REQUIRE(n == 0 || (y != nullptr && w != nullptr));
+    FDD_REQUIRE(n == 0 || y != nullptr); // w == NULL: unit weights
     for (int k = 0; k < m; k++) FDD_REQUIRE(n == 0 || x[k] != nullptr);
     switch (m)
     {

@@ -133,6 +133,7 @@ class Subdomain
     fdd::memory ua, fa;          // assembled-space inner solve from point vectors: solution and right-hand side over the dofs
     fdd::memory point_dof_dev;   // dof of every level-0 point (-1: none): Q as an index array
     fdd::memory gmres_state;     // device-side GMRES bookkeeping (fdd_gmres_*_dev)
+    bool norm_weight_is_one = false; // norm_weight == 1 everywhere (subdomain.tpp:2731-2747 without interface dofs)
     const MeshData<DType> *fine_mesh = nullptr; // level-0 coordinates (low-order FEM assembly)
 
     fdd::memory points_without_dof; // Dirichlet points: empty rows of Q
@@ -559,6 +560,7 @@ class Subdomain
             std::vector<DType> w(std::max(nw, 1), 1.0);
             norm_weight = fdd::dev().malloc<DType>(std::max(nw, 1));
             norm_weight.copyFrom(w.data(), w.size() * sizeof(DType));
+            norm_weight_is_one = true; // no interface dofs shared with a superdomain: the kernels need not read it
         }
 
         num_values = subdomain_operator.num_points + superdomain_operator.num_extended_dofs; // subdomain.tpp:3858
@@ -798,7 +800,7 @@ class Subdomain
 
     void gather_weighted(fdd::memory &t, fdd::memory &v)
     {
-        subdomain_operator.Qt.gather_scatter(nullptr, t.as<double>(), v.as<double>(), norm_weight.as<double>(), nullptr, 0, subdomain_operator.num_extended_dofs, 1);
+        subdomain_operator.Qt.gather_scatter(nullptr, t.as<double>(), v.as<double>(), norm_weight_is_one ? nullptr : norm_weight.as<double>(), nullptr, 0, subdomain_operator.num_extended_dofs, 1);
     }
 
     void gather_norm(DType &r_norm, fdd::memory &r)
@@ -1058,7 +1060,7 @@ class Subdomain
         residual_history.clear();
         double *sc = scalars.as<double>();
         double *ws = reduce_ws.as<double>();
-        const double *nw = norm_weight.as<double>();
+        const double *nw = norm_weight_is_one ? nullptr : norm_weight.as<double>(); // NULL: unit weights, not read
         void *st = gmres_state.ptr();
         const double *y_dev = nullptr, *inv_dev = nullptr;
         FDD_CALL(fdd_gmres_coefficients(st, &y_dev));
@@ -1069,7 +1071,7 @@ class Subdomain
         // -- the value vector_scaling would have stored (subdomain.tpp:4358, 4457), bit for bit -- so the
         // normalisation pass per step disappears.
         auto dot_dofs = [&](double *out_dev, fdd::memory &a, const double *const *b, const double *b_scale, int count) {
-            fdd::ProfileScope prof("reduce_vec2_kernel<MultiDotW>", 8.0 * nd * (count + 2));
+            fdd::ProfileScope prof("reduce_vec2_kernel<MultiDotW>", 8.0 * nd * (count + 1 + (nw ? 1 : 0)));
             FDD_CALL(fdd_multi_weighted_inner_product_scaled(out_dev, ws, a.as<double>(), b, b_scale, count, nw, nd, stream));
         };
 
@@ -1120,7 +1122,7 @@ class Subdomain
                 double *slot = sc + (j & 1) * FDD_MULTI_MAX;
                 dot_dofs(slot, qa, W.data(), inv_dev, j + 1);
                 {
-                    fdd::ProfileScope prof("reduce_vec2_kernel<MultiAxpyNorm>", 8.0 * nd * (j + 4));
+                    fdd::ProfileScope prof("reduce_vec2_kernel<MultiAxpyNorm>", 8.0 * nd * (j + 3 + (nw ? 1 : 0)));
                     FDD_CALL(fdd_multi_axpy_norm2_scaled_dev(slot + (j + 1), ws, VA[j + 1].template as<double>(), qa.as<double>(), slot, -1.0, W.data(), inv_dev, j + 1, nw, nd, stream));
                 }
                 Wm[j + 1] = &VA[j + 1];
@@ -1190,10 +1192,10 @@ class Subdomain
         residual_history.clear();
         double *sc = scalars.as<double>();
         double *ws = reduce_ws.as<double>();
-        const double *nw = norm_weight.as<double>();
+        const double *nw = norm_weight_is_one ? nullptr : norm_weight.as<double>(); // NULL: unit weights, not read
 
         auto dot_dofs = [&](double *out_dev, fdd::memory &a, const double *const *b, int count) {
-            fdd::ProfileScope prof("reduce_vec2_kernel<MultiDotW>", 8.0 * nd * (count + 2));
+            fdd::ProfileScope prof("reduce_vec2_kernel<MultiDotW>", 8.0 * nd * (count + 1 + (nw ? 1 : 0)));
             FDD_CALL(fdd_multi_weighted_inner_product(out_dev, ws, a.as<double>(), b, count, nw, nd, stream));
         };
 
@@ -1261,7 +1263,7 @@ class Subdomain
                 for (int i = 0; i < j + 1; i++) ptrs[i] = VA[i].template as<double>();
                 dot_dofs(sc, qa, ptrs.data(), j + 1);
                 {
-                    fdd::ProfileScope prof("reduce_vec2_kernel<MultiAxpyNorm>", 8.0 * nd * (j + 4));
+                    fdd::ProfileScope prof("reduce_vec2_kernel<MultiAxpyNorm>", 8.0 * nd * (j + 3 + (nw ? 1 : 0)));
                     FDD_CALL(fdd_multi_axpy_norm2_dev(sc + (j + 1), ws, qa.as<double>(), sc, -1.0, ptrs.data(), j + 1, nw, nd, stream));
                 }
                 // v~_{j+1} = q~ / ||q~||, launched before the host looks at the numbers (unused if this was the last step)

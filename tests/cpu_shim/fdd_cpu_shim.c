@@ -234,8 +234,22 @@ int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int n
 int fdd_csr_plan_matvec(const fdd_csr_plan *plan, double *y, const int *p, const int *c, const double *v, const double *x, double a, double b, void *s) { (void)s; orc_amg_matvec(y, p, c, v, x, a, b, plan->num_rows); return 0; }
 
 /* ---- multi-vector forms: the reference's launch-per-vector sequences ---- */
+static const double *shim_unit_weights(int n) /* w == NULL: unit weights */
+{
+    static double *ones = NULL;
+    static int cap = 0;
+    if (n > cap)
+    {
+        free(ones);
+        ones = (double *)malloc(sizeof(double) * (size_t)n);
+        for (int i = 0; i < n; i++) ones[i] = 1.0;
+        cap = n;
+    }
+    return ones;
+}
 int fdd_multi_weighted_inner_product(double *out, double *ws, const double *a, const double *const *b, int m, const double *w, int n, void *s)
 {
+    if (!w) w = shim_unit_weights(n);
     for (int k = 0; k < m; k++) fdd_sub_weighted_inner_product(out + k, ws, a, b[k], w, n, s);
     return 0;
 }
@@ -247,7 +261,7 @@ int fdd_multi_axpy_norm2_dev(double *out, double *ws, double *y, const double *c
         for (int k = 0; k < m; k++) v = 1.0 * v + (sign * c[k]) * x[k][i];
         y[i] = v;
     }
-    return fdd_sub_weighted_inner_product(out, ws, y, y, w, n, s);
+    return fdd_sub_weighted_inner_product(out, ws, y, y, w ? w : shim_unit_weights(n), n, s);
 }
 int fdd_vector_scaling_rsqrt_dev(double *au, const double *s2, const double *u, int n, void *s)
 {
