@@ -245,6 +245,8 @@ int fdd_multi_weighted_inner_product_scaled(double *out, double *ws, const doubl
 int fdd_multi_axpy_norm2_scaled_dev(double *out, double *ws, double *dst, const double *y, const double *coeffs_dev, double sign, const double *const *x, const double *x_scale_dev, int m, const double *w, int n, void *stream);
 int fdd_multi_axpy_scaled_dev(double *q, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream);
 int fdd_vector_scaling_dev(double *au, const double *scale_dev, const double *u, int n, void *stream); /* au = (*scale_dev) * u */
+int fdd_multi_lincomb_scaled_dev(double *q, int q_is_zero, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream); /* fdd_multi_axpy_scaled_dev; q_is_zero: q is taken to be 0 and is not read (it need not have been cleared) */
+int fdd_xpby_ratio_dev(double *out, const double *x, const double *num_dev, const double *den_dev, const double *y, int n, void *stream); /* out = x + (*num / *den) * y (domain.okl:226: p = z + beta p; out may be y) */
 /* out[0] = sum_nodes s*s*w with s = (Qt u)[node]*w[node]: Subdomain::residual_norm
  * (subdomain.tpp:4491-4515: multiply_weight + weighted_inner_product) without the dof vector */
 int fdd_gather_weighted_norm2(double *out, double *ws, const int *Qt_ptr, const int *Qt_col, const double *u, const double *node_weight, int num_nodes, void *stream);

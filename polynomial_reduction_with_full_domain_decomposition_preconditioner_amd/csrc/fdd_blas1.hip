@@ -126,6 +126,21 @@ struct ScaleDevOp
     __device__ void one(long long i) const { au[i] = (*scale) * u[i]; }
 };
 
+// out = x + (*num / *den) * y: the p = z + beta*p half of residual_and_search_update (domain.okl:218-233)
+// when r = r+ is a buffer swap instead of a copy
+struct XpbyRatioDevOp
+{
+    double *out;
+    const double *x, *y, *num, *den;
+    __device__ void vec2(long long i) const
+    {
+        const double beta = *num / *den;
+        const double2 a = ld2(x, i), b = ld2(y, i);
+        st2(out, i, make_double2(a.x + beta * b.x, a.y + beta * b.y));
+    }
+    __device__ void one(long long i) const { out[i] = x[i] + (*num / *den) * y[i]; }
+};
+
 struct ScaleOp // math.okl:29-35
 {
     double *au;
@@ -307,9 +322,10 @@ struct MultiAxpyDevOp
     const double *v[M];
     const double *c;
     const double *vs; // optional per-vector scales: v_k stands for vs[k] * v_k
+    bool from_zero;   // q is known to be 0 (it was just cleared): it is not read, 1.0*0 + c*v is c*v all the same
     __device__ void vec2(long long i) const
     {
-        double2 x = ld2(q, i);
+        double2 x = from_zero ? make_double2(0.0, 0.0) : ld2(q, i);
 #pragma unroll
         for (int k = 0; k < M; k++)
         {
@@ -328,7 +344,7 @@ struct MultiAxpyDevOp
     }
     __device__ void one(long long i) const
     {
-        double x = q[i];
+        double x = from_zero ? 0.0 : q[i];
 #pragma unroll
         for (int k = 0; k < M; k++) x = 1.0 * x + c[k] * (vs ? vs[k] * v[k][i] : v[k][i]);
         q[i] = x;
@@ -336,12 +352,13 @@ struct MultiAxpyDevOp
 };
 
 template <int M>
-int launch_multi_axpy_dev(double *q, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int n, void *stream)
+int launch_multi_axpy_dev(double *q, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, bool from_zero, int n, void *stream)
 {
     MultiAxpyDevOp<M> op;
     op.q = q;
     op.c = coeffs_dev;
     op.vs = v_scale_dev;
+    op.from_zero = from_zero;
     bool al = fdd_aligned16(q);
     for (int k = 0; k < M; k++)
     {
@@ -488,6 +505,14 @@ int fdd_vector_scaling(double *au, double alpha, const double *u, int n, void *s
     return launch_ew(ScaleOp{au, u, alpha}, n, fdd_aligned16(au) && fdd_aligned16(u), stream);
 }
 
+int fdd_xpby_ratio_dev(double *out, const double *x, const double *num_dev, const double *den_dev, const double *y, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(out != nullptr && x != nullptr && y != nullptr && num_dev != nullptr && den_dev != nullptr);
+    return launch_ew(XpbyRatioDevOp{out, x, y, num_dev, den_dev}, n, fdd_aligned16(out) && fdd_aligned16(x) && fdd_aligned16(y), stream);
+}
+
 int fdd_vector_scaling_dev(double *au, const double *scale_dev, const double *u, int n, void *stream)
 {
     FDD_REQUIRE(n >= 0);
@@ -598,20 +623,26 @@ int fdd_multi_axpy_dev(double *q, const double *coeffs_dev, const double *const 
 
 int fdd_multi_axpy_scaled_dev(double *q, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream)
 {
+    return fdd_multi_lincomb_scaled_dev(q, 0, coeffs_dev, v, v_scale_dev, m, n, stream);
+}
+
+int fdd_multi_lincomb_scaled_dev(double *q, int q_is_zero, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream)
+{
+    const bool from_zero = q_is_zero != 0;
     FDD_REQUIRE(n >= 0 && m >= 1 && m <= FDD_MULTI_MAX);
     if (n == 0) return 0;
     FDD_REQUIRE(q != nullptr && coeffs_dev != nullptr && v != nullptr);
     for (int k = 0; k < m; k++) FDD_REQUIRE(v[k] != nullptr && v[k] != q);
     switch (m)
     {
-    case 1: return launch_multi_axpy_dev<1>(q, coeffs_dev, v, v_scale_dev, n, stream);
-    case 2: return launch_multi_axpy_dev<2>(q, coeffs_dev, v, v_scale_dev, n, stream);
-    case 3: return launch_multi_axpy_dev<3>(q, coeffs_dev, v, v_scale_dev, n, stream);
-    case 4: return launch_multi_axpy_dev<4>(q, coeffs_dev, v, v_scale_dev, n, stream);
-    case 5: return launch_multi_axpy_dev<5>(q, coeffs_dev, v, v_scale_dev, n, stream);
-    case 6: return launch_multi_axpy_dev<6>(q, coeffs_dev, v, v_scale_dev, n, stream);
-    case 7: return launch_multi_axpy_dev<7>(q, coeffs_dev, v, v_scale_dev, n, stream);
-    default: return launch_multi_axpy_dev<8>(q, coeffs_dev, v, v_scale_dev, n, stream);
+    case 1: return launch_multi_axpy_dev<1>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
+    case 2: return launch_multi_axpy_dev<2>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
+    case 3: return launch_multi_axpy_dev<3>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
+    case 4: return launch_multi_axpy_dev<4>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
+    case 5: return launch_multi_axpy_dev<5>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
+    case 6: return launch_multi_axpy_dev<6>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
+    case 7: return launch_multi_axpy_dev<7>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
+    default: return launch_multi_axpy_dev<8>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
     }
 }
 

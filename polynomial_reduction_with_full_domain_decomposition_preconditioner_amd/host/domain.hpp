@@ -823,7 +823,9 @@ class Domain
             // beta = scalars[2] / scalars[0] (theta / gamma), read by the update kernel
             FDD_CALL(fdd_dom_inner_product_flexible(scalars.as<double>() + 2, reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
             if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>() + 2, 1);
-            FDD_CALL(fdd_dom_residual_and_search_update_dev(np.as<double>(), nr.as<double>(), nz.as<double>(), nr1.as<double>(), scalars.as<double>() + 2, scalars.as<double>(), nn, fdd::dev().stream));
+            // p = z + beta p; "r = r+" (domain.okl:226-233) is a swap of the two node vectors, not a copy
+            FDD_CALL(fdd_xpby_ratio_dev(np.as<double>(), nz.as<double>(), scalars.as<double>() + 2, scalars.as<double>(), np.as<double>(), nn, fdd::dev().stream));
+            std::swap(nr, nr1);
         }
         else
         {

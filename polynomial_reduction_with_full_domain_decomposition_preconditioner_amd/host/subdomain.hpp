@@ -1075,8 +1075,7 @@ class Subdomain
             FDD_CALL(fdd_multi_weighted_inner_product_scaled(out_dev, ws, a.as<double>(), b, b_scale, count, nw, nd, stream));
         };
 
-        FDD_CALL(fdd_set_to_value(ua.as<double>(), 0.0, nd, 0, stream));
-
+        // u~ starts at 0 (subdomain.tpp:4270-4275); the first update writes it without reading it
         int iter = 0;
         bool first_cycle = true;
         std::vector<const double *> W(m + 1), ptrs(m + 1);
@@ -1148,15 +1147,17 @@ class Subdomain
 
             if (j_last >= 0)
             {
-                fdd::ProfileScope prof("ew_vec2_kernel<MultiAxpy>", 8.0 * nd * (j_last + 3));
+                fdd::ProfileScope prof("ew_vec2_kernel<MultiAxpy>", 8.0 * nd * (j_last + (first_cycle ? 2 : 3)));
                 if (use_preconditioner)
                 {
                     for (int i = 0; i < j_last + 1; i++) ptrs[i] = ZA[i].template as<double>();
-                    FDD_CALL(fdd_multi_axpy_dev(ua.as<double>(), y_dev, ptrs.data(), j_last + 1, nd, stream));
+                    FDD_CALL(fdd_multi_lincomb_scaled_dev(ua.as<double>(), first_cycle ? 1 : 0, y_dev, ptrs.data(), nullptr, j_last + 1, nd, stream));
                 }
                 else
-                    FDD_CALL(fdd_multi_axpy_scaled_dev(ua.as<double>(), y_dev, W.data(), inv_dev, j_last + 1, nd, stream));
+                    FDD_CALL(fdd_multi_lincomb_scaled_dev(ua.as<double>(), first_cycle ? 1 : 0, y_dev, W.data(), inv_dev, j_last + 1, nd, stream));
             }
+            else if (first_cycle)
+                FDD_CALL(fdd_set_to_value(ua.as<double>(), 0.0, nd, 0, stream));
             first_cycle = false;
             if (converged) break;
         }

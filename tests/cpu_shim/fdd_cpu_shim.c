@@ -531,3 +531,17 @@ int fdd_stiffness_matrix_mfma_gather(double *Au, const double *v, const double *
 {
     return fdd_sub_stiffness_matrix_gather_scaled(Au, v, vscale, pd, D, G, eo, ne, N, s);
 }
+
+int fdd_multi_lincomb_scaled_dev(double *q, int q_is_zero, const double *c, const double *const *v, const double *vs, int m, int n, void *s)
+{
+    if (q_is_zero) memset(q, 0, sizeof(double) * (size_t)n); /* the caller promises 0 and does not clear it: the kernel never reads q */
+    return fdd_multi_axpy_scaled_dev(q, c, v, vs, m, n, s);
+}
+
+int fdd_xpby_ratio_dev(double *out, const double *x, const double *num, const double *den, const double *y, int n, void *s)
+{
+    (void)s;
+    double beta = *num / *den;
+    for (int i = 0; i < n; i++) out[i] = x[i] + beta * y[i];
+    return 0;
+}
