@@ -259,7 +259,7 @@ struct MultiDotWOp
 #pragma unroll
         for (int k = 0; k < M; k++)
         {
-            double2 bb = ld2(b[k], i);
+            double2 bb = (b[k] == a) ? aa : ld2(b[k], i); // <a, a>: one stream, not two
             if (bs)
             {
                 const double sk = bs[k];

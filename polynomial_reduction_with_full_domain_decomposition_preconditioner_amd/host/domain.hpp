@@ -98,6 +98,7 @@ class Domain
     bool nodes_ready = false;
     bool fcg_nodes_active = false;
     bool fcg_norm_pending = false;
+    int norm_parts = 1; // scalars[4..]: boundary-prefix and interior parts of the last enqueued residual norm
     fdd::memory point_node_dev;           // int[num_local_points]: Q as an index array
     fdd::memory node_mask;                // Dirichlet mask per node
     fdd::memory node_stitch;              // local multiplicity * assembled weight * mask
@@ -705,17 +706,19 @@ class Domain
         }
         else
         {
-            FDD_CALL(fdd_dom_residual_norm(out, reduce_ws.as<double>(), rn.as<double>(), rn.as<double>(), node_mask.as<double>(), nn, fdd::dev().stream));
-            FDD_CALL(fdd_set_to_value(out + 1, 0.0, 1, 0, fdd::dev().stream));
+            // sum r*r*mask with r read once (the arithmetic and the reduction tree of residual_norm_kernel, domain.okl:109-138)
+            const double *self[1] = {rn.as<double>()};
+            FDD_CALL(fdd_multi_weighted_inner_product(out, reduce_ws.as<double>(), rn.as<double>(), self, 1, node_mask.as<double>(), nn, fdd::dev().stream));
         }
-        if (fdd::comm().size > 1) fdd::comm().allreduce_sum(out, 2);
+        norm_parts = (nb > 0) ? 2 : 1;
+        if (fdd::comm().size > 1) fdd::comm().allreduce_sum(out, norm_parts);
     }
 
     DType node_norm_fetch()
     {
-        DType v[2];
+        DType v[2] = {0.0, 0.0};
         fdd::memory tail = scalars.slice(4, 2);
-        tail.copyTo(v, 2 * sizeof(DType));
+        tail.copyTo(v, norm_parts * sizeof(DType));
         return std::sqrt(v[0] + v[1]);
     }
 
