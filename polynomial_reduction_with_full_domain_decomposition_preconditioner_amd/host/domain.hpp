@@ -104,6 +104,7 @@ class Domain
     fdd::memory node_stitch;              // local multiplicity * assembled weight * mask
     fdd::memory node_of_dof, dof_of_node; // renumbering to / from the subdomain's dofs
     int nodes_sub_dofs = -1;
+    int dof_shift = -1; // >= 0: subdomain dof d is node d + dof_shift (the numbering makes it so), no renumbering pass
     fdd::memory nu, nr, nr1, nq, nz, np, nt, sub_f, sub_u;
     fdd::memory fcg_u_pts;
 
@@ -419,31 +420,30 @@ class Domain
         std::vector<long long> boundary_nodes;
         int count = 0;
 
-        // nodes whose local multiplicity differs from the global one come first
-        for (int p = 0; p < num_local_points; p++)
+        // Nodes whose local multiplicity differs from the global one (shared with other ranks) come first
+        // (domain.tpp:249-281), the rest after them by first appearance.  Within that, Dirichlet nodes are moved to
+        // the two ends -- shared Dirichlet | shared | interior | interior Dirichlet -- so that the Subdomain's dofs
+        // (the unmasked nodes, in this order) are one contiguous slice of every node vector and the outer solve hands
+        // its residual to the inner solve, and takes the correction back, without renumbering.  Nothing outside the
+        // class sees the order except through Q / Qt.
+        for (int pass = 0; pass < 4; pass++)
         {
-            const long long glo = mesh.glo_num[p];
-            if (local_node_degree[glo] != mesh.node_degree[p])
+            const bool want_shared = pass < 2;
+            const bool want_dirichlet = (pass == 0 or pass == 3);
+            for (int p = 0; p < num_local_points; p++)
             {
+                const long long glo = mesh.glo_num[p];
+                const bool shared = local_node_degree[glo] != mesh.node_degree[p];
+                const bool dirichlet = not(mesh.p_mask[p] > 0.0);
+                if (shared != want_shared or dirichlet != want_dirichlet) continue;
                 if (local_node_idx.find(glo) == local_node_idx.end())
                 {
-                    boundary_nodes.push_back(glo);
+                    if (shared) boundary_nodes.push_back(glo);
                     local_node_idx[glo] = count;
                     count++;
                 }
             }
-        }
-
-        num_bdary_nodes = count;
-
-        for (int p = 0; p < num_local_points; p++)
-        {
-            const long long glo = mesh.glo_num[p];
-            if (local_node_idx.find(glo) == local_node_idx.end())
-            {
-                local_node_idx[glo] = count;
-                count++;
-            }
+            if (pass == 1) num_bdary_nodes = count;
         }
 
         num_local_nodes = (int)local_node_degree.size();
@@ -661,6 +661,10 @@ class Domain
                 d_of_n[Q.col_hst[p]] = d;
             }
         }
+        dof_shift = (nd > 0) ? n_of_d[0] : -1;
+        for (int d = 0; d < nd and dof_shift >= 0; d++)
+            if (n_of_d[d] != d + dof_shift) dof_shift = -1;
+        if (dof_shift > 0 and (dof_shift & 1)) dof_shift = -1; // an odd shift would leave the slice 8-byte aligned only: the 16-byte kernels want more
         node_of_dof = fdd::dev().malloc<int>(std::max(nd, 1));
         node_of_dof.copyFrom(n_of_d.data(), (size_t)nd * sizeof(int));
         dof_of_node = fdd::dev().malloc<int>(std::max(num_local_nodes, 1));
@@ -736,12 +740,29 @@ class Domain
         if (use_preconditioner)
         {
             timer.start("subdomain.solver");
-            FDD_CALL(fdd_gather_indexed(sub_f.as<double>(), rn.as<double>(), node_of_dof.as<int>(), nullptr, nodes_sub_dofs, stream));
-            subdomain.gmres_dofs(sub_u, sub_f);
+            if (dof_shift >= 0)
+            {
+                // the dofs are the node slice [dof_shift, dof_shift + dofs): the inner solve reads r^ in place
+                fdd::memory f_slice = rn.slice(dof_shift, nodes_sub_dofs);
+                subdomain.gmres_dofs(sub_u, f_slice);
+            }
+            else
+            {
+                FDD_CALL(fdd_gather_indexed(sub_f.as<double>(), rn.as<double>(), node_of_dof.as<int>(), nullptr, nodes_sub_dofs, stream));
+                subdomain.gmres_dofs(sub_u, sub_f);
+            }
             timer.stop("subdomain.solver");
 
             timer.start("subdomain.stitching");
-            FDD_CALL(fdd_gather_indexed(zn.as<double>(), sub_u.as<double>(), dof_of_node.as<int>(), node_stitch.as<double>(), num_local_nodes, stream));
+            if (dof_shift >= 0)
+            {
+                const int tail = num_local_nodes - dof_shift - nodes_sub_dofs;
+                if (dof_shift > 0) FDD_CALL(fdd_set_to_value(zn.as<double>(), 0.0, dof_shift, 0, stream));
+                FDD_CALL(fdd_amg_vector_multiplication(zn.as<double>() + dof_shift, sub_u.as<double>(), node_stitch.as<double>() + dof_shift, nodes_sub_dofs, stream));
+                if (tail > 0) FDD_CALL(fdd_set_to_value(zn.as<double>(), 0.0, tail, dof_shift + nodes_sub_dofs, stream));
+            }
+            else
+                FDD_CALL(fdd_gather_indexed(zn.as<double>(), sub_u.as<double>(), dof_of_node.as<int>(), node_stitch.as<double>(), num_local_nodes, stream));
             gs_add_boundary(zn);
             timer.stop("subdomain.stitching");
         }

