@@ -561,3 +561,60 @@ def low_order_hierarchy(mesh, point_dof, num_dofs, min_size=30, max_levels=8):
         order = c_order
         cur_axes = [a[k] for a, k in zip(cur_axes, keeps)]
     return levels
+
+
+# --------------------------------------------------------------------------
+# A curved mesh: the unit cube pushed through a smooth map, so that all six
+# geometric factors are non-zero (the reference's Kershaw / pebble-bed inputs,
+# run.py:36-74, are such meshes; they are not available here).
+# --------------------------------------------------------------------------
+class DeformedMesh(BoxMesh):
+    """BoxMesh with x -> x + a*s(x,y,z)*(1, -0.7, 0.5), s = sin(pi x) sin(pi y) sin(pi z): the boundary stays put,
+    elements stay conforming (one global map), the Jacobian is full.  Geometric factors are the isoparametric ones
+    of degree N: G = w_i w_j w_k |J| J^-1 J^-T with J = dx/dr from the GLL differentiation matrix."""
+
+    def __init__(self, E, N, amplitude=0.06, P=(1, 1, 1), rank=0):
+        super().__init__(E, N, P, rank)
+        n = N + 1
+        _, w, D = gll(N)
+        D = np.asarray(D).reshape(n, n)  # D[i, p] = D_hat[p + i*n]
+        s = np.sin(np.pi * self.x) * np.sin(np.pi * self.y) * np.sin(np.pi * self.z)
+        X = [self.x + amplitude * s, self.y - 0.7 * amplitude * s, self.z + 0.5 * amplitude * s]
+        self.x, self.y, self.z = [np.ascontiguousarray(c) for c in X]
+        ne = self.num_local_elements
+        J = np.zeros((ne, n, n, n, 3, 3))
+        for a, c in enumerate(X):
+            c = c.reshape(ne, n, n, n)  # [e, k, j, i]
+            J[..., a, 0] = np.einsum("ip,ekjp->ekji", D, c)
+            J[..., a, 1] = np.einsum("jp,ekpi->ekji", D, c)
+            J[..., a, 2] = np.einsum("kp,epji->ekji", D, c)
+        det = np.linalg.det(J)
+        assert (det > 0).all()
+        Ji = np.linalg.inv(J)  # dr/dx
+        M = np.einsum("...ab,...cb->...ac", Ji, Ji)  # J^-1 J^-T
+        www = w[None, :, None, None] * w[None, None, :, None] * w[None, None, None, :]
+        sc = www * det
+        pairs = [(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]
+        self.g = [np.ascontiguousarray((sc * M[..., a, b]).reshape(-1)) for a, b in pairs]
+
+
+def write_mesh_files(directory, mesh, proc_id=0):
+    """The reference's per-rank input files (domain.tpp:45-224): lx1_<N+1>/{size,x,y,z,glo_num,node_degree,p_mask,g_1..g_6}_<rank>.<N>.dat"""
+    N = mesh.N
+    d = os.path.join(directory, "lx1_%d" % (N + 1))
+    os.makedirs(d, exist_ok=True)
+    n = N + 1
+    with open(os.path.join(d, "size_%d.%d.dat" % (proc_id, N)), "w") as fh:
+        fh.write("3 %d %d %d %d\n" % (n, n, n, mesh.num_local_elements))
+
+    def put(stem, arr, dtype):
+        np.ascontiguousarray(arr, dtype=dtype).tofile(os.path.join(d, "%s_%d.%d.dat" % (stem, proc_id, N)))
+
+    put("x", mesh.x, np.float64)
+    put("y", mesh.y, np.float64)
+    put("z", mesh.z, np.float64)
+    put("glo_num", mesh.glo_num, np.int64)
+    put("node_degree", mesh.node_degree, np.int32)
+    put("p_mask", mesh.p_mask, np.float64)
+    for g in range(6):
+        put("g_%d" % (g + 1), mesh.g[g], np.float64)

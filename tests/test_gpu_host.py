@@ -335,3 +335,46 @@ def test_inner_gmres_restarts_and_stops_inside_a_cycle(setup, nv, mi, device_boo
     finally:
         sd.close()
         p.close()
+
+
+def test_curved_mesh_from_files(setup, tmp_path):
+    """A deformed (non-affine) mesh read from the reference's file format: all six geometric factors
+    are non-zero in the whole solve.  Product vs oracle on the same arrays, and against the
+    manufactured solution."""
+    E, N, red = (3, 3, 2), 5, 2
+    d = str(tmp_path / "curved")
+    for deg in S.level_degrees(N, red):
+        S.write_mesh_files(d, S.DeformedMesh(E, deg))
+    p = H.Problem.from_directory(d, N, red)
+    for lvl in range(p.info["num_levels"]):
+        p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
+    meshes = [S.ArrayMesh.from_problem(p, lvl) for lvl in range(p.info["num_levels"])]
+    W = S.OracleWorld([meshes[0]], N)
+    sd = S.OracleSubdomain(None, N, red, meshes=meshes)
+    try:
+        for g in ("g_4", "g_5", "g_6"):
+            assert np.abs(p.mesh_array(g)).max() > 1e-4
+        u = S.seeded_uniform(p.n, 8)
+        assert np.array_equal(p.stiffness(u), W.stiffness([u])[0])
+        # the operator is symmetric positive on assembled data: <v, A u> = <u, A v>
+        us, vs = W.dssum([u], True, True)[0], W.dssum([S.seeded_uniform(p.n, 9)], True, True)[0]
+        Au, Av = p.stiffness(us, dssum=True), p.stiffness(vs, dssum=True)
+        wgt = 1.0 / meshes[0].node_degree
+        assert abs(np.dot(vs * wgt, Au) - np.dot(us * wgt, Av)) <= 1e-12 * abs(np.dot(us * wgt, Au))
+        assert np.dot(us * wgt, Au) > 0
+
+        u_star, f = p.make_rhs_from(S.seeded_uniform(p.n, 1234))
+        x, its, hist = p.solve(f, "fcg")
+
+        def pre(z, r):
+            out, _, _ = sd.solve(r[0], "gmres")
+            z[0][:] = out
+
+        ox, oits, ohist = W.solve([f], "fcg", precond=pre)
+        assert its == oits and np.abs(hist - ohist).max() <= 1e-8 * ohist[0]
+        assert np.abs(x - ox[0]).max() <= 1e-8 * np.abs(ox[0]).max()
+        assert np.abs(x - u_star).max() <= 1e-4 * np.abs(u_star).max()
+    finally:
+        sd.close()
+        W.close()
+        p.close()
