@@ -99,6 +99,9 @@ class Domain
     bool fcg_nodes_active = false;
     bool fcg_norm_pending = false;
     int norm_parts = 1; // scalars[4..]: boundary-prefix and interior parts of the last enqueued residual norm
+    bool norm_deferred = false;          // the saved prefix still waits for its exchange
+    const double *norm_source = nullptr; // the vector whose norm is being taken
+    fdd::memory nprefix;                 // its boundary prefix (exchanged copy)
     fdd::memory point_node_dev;           // int[num_local_points]: Q as an index array
     fdd::memory node_mask;                // Dirichlet mask per node
     fdd::memory node_stitch;              // local multiplicity * assembled weight * mask
@@ -119,6 +122,20 @@ class Domain
         FDD_CALL(fdd_interface_pack(interface_slots.as<double>(), bdary_slot.as<int>(), t.as<double>(), num_bdary_nodes, fdd::dev().stream));
         fdd::comm().allreduce_sum(interface_slots.as<double>(), num_interface_slots);
         FDD_CALL(fdd_interface_unpack(t.as<double>(), interface_slots.as<double>(), bdary_slot.as<int>(), num_bdary_nodes, fdd::dev().stream));
+    }
+
+    // two boundary prefixes in ONE exchange (one collective latency instead of two)
+    void gs_add_boundary_pair(fdd::memory &a, fdd::memory &b)
+    {
+        if (fdd::comm().size == 1 or num_interface_slots == 0) return;
+        const int S = num_interface_slots;
+        void *stream = fdd::dev().stream;
+        FDD_CALL(fdd_memset(interface_slots.ptr(), 0, 2 * (size_t)S * sizeof(double), stream));
+        FDD_CALL(fdd_interface_pack(interface_slots.as<double>(), bdary_slot.as<int>(), a.as<double>(), num_bdary_nodes, stream));
+        FDD_CALL(fdd_interface_pack(interface_slots.as<double>() + S, bdary_slot.as<int>(), b.as<double>(), num_bdary_nodes, stream));
+        fdd::comm().allreduce_sum(interface_slots.as<double>(), 2 * S);
+        FDD_CALL(fdd_interface_unpack(a.as<double>(), interface_slots.as<double>(), bdary_slot.as<int>(), num_bdary_nodes, stream));
+        FDD_CALL(fdd_interface_unpack(b.as<double>(), interface_slots.as<double>() + S, bdary_slot.as<int>(), num_bdary_nodes, stream));
     }
 
     // device scalars -> (all-reduce) -> host
@@ -463,7 +480,7 @@ class Domain
                 bdary_slot = fdd::dev().malloc<int>(num_bdary_nodes);
                 bdary_slot.copyFrom(slot.data(), (size_t)num_bdary_nodes * sizeof(int));
             }
-            if (num_interface_slots > 0) interface_slots = fdd::dev().malloc<double>(num_interface_slots);
+            if (num_interface_slots > 0) interface_slots = fdd::dev().malloc<double>(2 * (size_t)num_interface_slots); // room for two prefixes in one exchange
 
             // unique global nodes = sum of owned nodes: interior ones + shared ones counted once
             double owned = (double)(num_local_nodes - num_bdary_nodes);
@@ -696,17 +713,31 @@ class Domain
     // sqrt(<r, QQt r>) (domain.tpp:916-931) from r^ = Qt r: sum_n r^_n * gs(r^)_n * mask_n.
     // Two halves: the reductions (+ all-reduce) are enqueued into scalars[4..5]; the value is
     // fetched when the host wants it, which may be after more work has been enqueued.
-    void node_norm_enqueue(fdd::memory &rn)
+    // defer_exchange: the boundary prefix is only saved; its exchange rides with the stitching exchange of the
+    // preconditioner that follows (precondition_nodes), which then finishes the norm (node_norm_finish)
+    void node_norm_enqueue(fdd::memory &rn, bool defer_exchange = false)
     {
         const int nn = num_local_nodes;
-        const int nb = (fdd::comm().size > 1 and num_interface_slots > 0) ? num_bdary_nodes : 0;
+        // every rank of a multi-rank run takes the two-part path (a rank without shared nodes contributes an empty
+        // prefix), so that all of them issue the same collectives
+        const bool multi = fdd::comm().size > 1 and num_interface_slots > 0;
+        const int nb = multi ? num_bdary_nodes : 0;
         double *out = scalars.as<double>() + 4;
-        if (nb > 0)
+        if (multi)
         {
-            nt.copyFrom(rn, (size_t)nb * sizeof(DType));
-            gs_add_boundary(nt);
-            FDD_CALL(fdd_dom_residual_norm(out, reduce_ws.as<double>(), rn.as<double>(), nt.as<double>(), node_mask.as<double>(), nb, fdd::dev().stream));
+            if (not nprefix.ptr()) nprefix = fdd::dev().malloc<DType>(std::max(num_bdary_nodes, 1));
+            nprefix.copyFrom(rn, (size_t)nb * sizeof(DType));
             FDD_CALL(fdd_dom_residual_norm(out + 1, reduce_ws.as<double>(), rn.as<double>() + nb, rn.as<double>() + nb, node_mask.as<double>() + nb, nn - nb, fdd::dev().stream));
+            norm_parts = 2;
+            norm_source = rn.as<double>();
+            if (defer_exchange)
+            {
+                norm_deferred = true;
+                return;
+            }
+            gs_add_boundary(nprefix);
+            node_norm_finish();
+            return;
         }
         else
         {
@@ -714,8 +745,17 @@ class Domain
             const double *self[1] = {rn.as<double>()};
             FDD_CALL(fdd_multi_weighted_inner_product(out, reduce_ws.as<double>(), rn.as<double>(), self, 1, node_mask.as<double>(), nn, fdd::dev().stream));
         }
-        norm_parts = (nb > 0) ? 2 : 1;
+        norm_parts = 1;
         if (fdd::comm().size > 1) fdd::comm().allreduce_sum(out, norm_parts);
+    }
+
+    // the boundary part of the norm once the saved prefix has been exchanged, then the all-reduce of both parts
+    void node_norm_finish()
+    {
+        double *out = scalars.as<double>() + 4;
+        FDD_CALL(fdd_dom_residual_norm(out, reduce_ws.as<double>(), norm_source, nprefix.as<double>(), node_mask.as<double>(), num_bdary_nodes, fdd::dev().stream));
+        fdd::comm().allreduce_sum(out, 2);
+        norm_deferred = false;
     }
 
     DType node_norm_fetch()
@@ -763,13 +803,25 @@ class Domain
             }
             else
                 FDD_CALL(fdd_gather_indexed(zn.as<double>(), sub_u.as<double>(), dof_of_node.as<int>(), node_stitch.as<double>(), num_local_nodes, stream));
-            gs_add_boundary(zn);
+            if (norm_deferred)
+            {
+                gs_add_boundary_pair(zn, nprefix);
+                node_norm_finish();
+            }
+            else
+                gs_add_boundary(zn);
             timer.stop("subdomain.stitching");
         }
         else
         {
             nt.copyFrom(rn, (size_t)num_local_nodes * sizeof(DType));
-            gs_add_boundary(nt);
+            if (norm_deferred)
+            {
+                gs_add_boundary_pair(nt, nprefix);
+                node_norm_finish();
+            }
+            else
+                gs_add_boundary(nt);
             FDD_CALL(fdd_amg_vector_multiplication(zn.as<double>(), nt.as<double>(), node_mask.as<double>(), num_local_nodes, stream));
         }
     }
@@ -810,7 +862,7 @@ class Domain
             // gamma = scalars[0] (kept for beta), theta = scalars[1]: alpha never visits the host
             if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>(), 2);
             FDD_CALL(fdd_dom_solution_and_residual_update_dev(nu.as<double>(), nr1.as<double>(), nr.as<double>(), np.as<double>(), nq.as<double>(), scalars.as<double>(), scalars.as<double>() + 1, nn, stream));
-            node_norm_enqueue(nr1);
+            node_norm_enqueue(nr1, /*defer_exchange=*/true); // finished inside the preconditioner's exchange
             fcg_norm_pending = true;
             return std::numeric_limits<DType>::quiet_NaN(); // fcg_nodes_norm() has the value
         }
