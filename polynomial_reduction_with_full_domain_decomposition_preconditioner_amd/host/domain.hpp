@@ -100,6 +100,7 @@ class Domain
     bool fcg_norm_pending = false;
     int norm_parts = 1; // scalars[4..]: boundary-prefix and interior parts of the last enqueued residual norm
     bool norm_deferred = false;          // the saved prefix still waits for its exchange
+    bool norm_reduce_pending = false;    // scalars[4..5] still hold this rank's parts only
     const double *norm_source = nullptr; // the vector whose norm is being taken
     fdd::memory nprefix;                 // its boundary prefix (exchanged copy)
     fdd::memory point_node_dev;           // int[num_local_points]: Q as an index array
@@ -754,7 +755,10 @@ class Domain
     {
         double *out = scalars.as<double>() + 4;
         FDD_CALL(fdd_dom_residual_norm(out, reduce_ws.as<double>(), norm_source, nprefix.as<double>(), node_mask.as<double>(), num_bdary_nodes, fdd::dev().stream));
-        fdd::comm().allreduce_sum(out, 2);
+        if (norm_deferred and device_scalars)
+            norm_reduce_pending = true; // its two scalars join the all-reduce of the flexible dot (fcg_nodes_step_direction)
+        else
+            fdd::comm().allreduce_sum(out, 2);
         norm_deferred = false;
     }
 
@@ -896,11 +900,13 @@ class Domain
         precondition_nodes(nz, nr1, subdomain);
         if (device_scalars)
         {
-            // beta = scalars[2] / scalars[0] (theta / gamma), read by the update kernel
-            FDD_CALL(fdd_dom_inner_product_flexible(scalars.as<double>() + 2, reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
-            if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>() + 2, 1);
+            // beta = scalars[3] / scalars[0] (theta / gamma), read by the update kernel; the residual norm's two
+            // parts sit right behind it (scalars[4..5]) and are summed over the ranks in the same collective
+            FDD_CALL(fdd_dom_inner_product_flexible(scalars.as<double>() + 3, reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
+            if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>() + 3, norm_reduce_pending ? 3 : 1);
+            norm_reduce_pending = false;
             // p = z + beta p; "r = r+" (domain.okl:226-233) is a swap of the two node vectors, not a copy
-            FDD_CALL(fdd_xpby_ratio_dev(np.as<double>(), nz.as<double>(), scalars.as<double>() + 2, scalars.as<double>(), np.as<double>(), nn, fdd::dev().stream));
+            FDD_CALL(fdd_xpby_ratio_dev(np.as<double>(), nz.as<double>(), scalars.as<double>() + 3, scalars.as<double>(), np.as<double>(), nn, fdd::dev().stream));
             std::swap(nr, nr1);
         }
         else
