@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-precond", action="store_true")
     ap.add_argument("--amg", action="store_true", help="inner solve preconditioned by the low-order AMG V-cycle (config C5's preconditioner; hierarchy built by the host layer)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N>1 ranks all on cuda:0 with a gloo group staging device buffers over the host: exercises the multi-rank code path on a one-GPU box (not a measurement)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events around the kernels of the timed region (no roofline object): how much the instrumentation costs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-elements", type=int, default=20)
     ap.add_argument("--cpu-sample-steps", type=int, default=12)
@@ -181,7 +182,7 @@ def main():
     prob.pcg_begin(f)
     prob.pcg_steps(args.warmup)
 
-    lib.host().call("fddh_profile_enable", 1)
+    lib.host().call("fddh_profile_enable", 0 if args.no_kernel_timing else 1)
     H.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

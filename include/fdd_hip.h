@@ -239,6 +239,7 @@ int fdd_gmres_coefficients(void *state, const double **y_dev);
 /* the basis may stay unnormalised: inv[0] = 1/gamma_0, inv[j+1] = 1/||q_j|| are kept in the state (the factors
  * vector_scaling would have applied, subdomain.tpp:4358, 4457) for the *_scaled entries below to apply on load */
 int fdd_gmres_scales(void *state, const double **inv_dev);
+int fdd_gmres_last_column(void *state, const double **j_last_dev); /* device address of j_last (a double), for fdd_multi_lincomb_limited_dev */
 int fdd_sub_stiffness_matrix_gather_scaled(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
 /* in the multi-vector reductions below w == NULL means unit weights: nothing is read, and x * 1.0 is x bit for bit */
 int fdd_multi_weighted_inner_product_scaled(double *out, double *ws, const double *a, const double *const *b, const double *b_scale_dev, int m, const double *w, int n, void *stream);
@@ -246,6 +247,8 @@ int fdd_multi_axpy_norm2_scaled_dev(double *out, double *ws, double *dst, const 
 int fdd_multi_axpy_scaled_dev(double *q, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream);
 int fdd_vector_scaling_dev(double *au, const double *scale_dev, const double *u, int n, void *stream); /* au = (*scale_dev) * u */
 int fdd_multi_lincomb_scaled_dev(double *q, int q_is_zero, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream); /* fdd_multi_axpy_scaled_dev; q_is_zero: q is taken to be 0 and is not read (it need not have been cleared) */
+int fdd_multi_lincomb_limited_dev(double *q, int q_is_zero, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, const double *last_dev, int m, int n, void *stream); /* only vectors 0..(int)*last_dev enter (NULL: all m) */
+int fdd_sqrt_sum_dev(double *out, const double *parts_dev, int nparts, void *stream); /* out[0] = sqrt(sum parts): a residual norm appended to a device-side history */
 int fdd_xpby_ratio_dev(double *out, const double *x, const double *num_dev, const double *den_dev, const double *y, int n, void *stream); /* out = x + (*num / *den) * y (domain.okl:226: p = z + beta p; out may be y) */
 /* out[0] = sum_nodes s*s*w with s = (Qt u)[node]*w[node]: Subdomain::residual_norm
  * (subdomain.tpp:4491-4515: multiply_weight + weighted_inner_product) without the dof vector */

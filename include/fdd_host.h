@@ -100,6 +100,8 @@ int fddh_problem_set_options(fddh_problem *p, int max_iterations, double toleran
  *   "assembled_outer_solve"    1: flexible CG on node vectors (one value per assembled node): Q fused into the stiffness
  *                              load, no dssum pass, the inner solve entered and left in dof numbering (default when the
  *                              inner solve is the assembled GMRES or there is no preconditioner); 0: point vectors
+ *   "lazy_steps"               1: fddh_problem_pcg_steps(K) runs its K iterations with ONE host synchronisation, at the end
+ *                              (norms kept in a device-side history, inner solves without their end-of-cycle read; default)
  *   "device_bookkeeping"       1: Givens rotations / stopping tests of the inner GMRES in one-thread kernels and alpha, beta
  *                              of the node-space PCG read from device memory: two host synchronisations per PCG step
  *                              (default); 0: the host computes them between launches, as the reference does

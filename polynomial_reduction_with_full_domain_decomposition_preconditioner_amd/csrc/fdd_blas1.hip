@@ -141,6 +141,16 @@ struct XpbyRatioDevOp
     __device__ void one(long long i) const { out[i] = x[i] + (*num / *den) * y[i]; }
 };
 
+} // namespace
+__global__ void fdd_sqrt_sum_kernel(double *out, const double *parts, int nparts)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int k = 0; k < nparts; k++) s += parts[k];
+    *out = sqrt(s);
+}
+namespace
+{
 struct ScaleOp // math.okl:29-35
 {
     double *au;
@@ -323,12 +333,15 @@ struct MultiAxpyDevOp
     const double *c;
     const double *vs; // optional per-vector scales: v_k stands for vs[k] * v_k
     bool from_zero;   // q is known to be 0 (it was just cleared): it is not read, 1.0*0 + c*v is c*v all the same
+    const double *last; // optional: only vectors 0..(int)*last enter (a count that never left the device)
     __device__ void vec2(long long i) const
     {
         double2 x = from_zero ? make_double2(0.0, 0.0) : ld2(q, i);
+        const int kmax = last ? (int)*last : M - 1;
 #pragma unroll
         for (int k = 0; k < M; k++)
         {
+            if (k > kmax) break;
             const double ck = c[k];
             double2 b = ld2(v[k], i);
             if (vs)
@@ -345,20 +358,23 @@ struct MultiAxpyDevOp
     __device__ void one(long long i) const
     {
         double x = from_zero ? 0.0 : q[i];
+        const int kmax = last ? (int)*last : M - 1;
 #pragma unroll
-        for (int k = 0; k < M; k++) x = 1.0 * x + c[k] * (vs ? vs[k] * v[k][i] : v[k][i]);
+        for (int k = 0; k < M; k++)
+            if (k <= kmax) x = 1.0 * x + c[k] * (vs ? vs[k] * v[k][i] : v[k][i]);
         q[i] = x;
     }
 };
 
 template <int M>
-int launch_multi_axpy_dev(double *q, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, bool from_zero, int n, void *stream)
+int launch_multi_axpy_dev(double *q, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, bool from_zero, const double *last_dev, int n, void *stream)
 {
     MultiAxpyDevOp<M> op;
     op.q = q;
     op.c = coeffs_dev;
     op.vs = v_scale_dev;
     op.from_zero = from_zero;
+    op.last = last_dev;
     bool al = fdd_aligned16(q);
     for (int k = 0; k < M; k++)
     {
@@ -505,6 +521,14 @@ int fdd_vector_scaling(double *au, double alpha, const double *u, int n, void *s
     return launch_ew(ScaleOp{au, u, alpha}, n, fdd_aligned16(au) && fdd_aligned16(u), stream);
 }
 
+int fdd_sqrt_sum_dev(double *out, const double *parts_dev, int nparts, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && parts_dev != nullptr && nparts >= 1);
+    hipLaunchKernelGGL(fdd_sqrt_sum_kernel, dim3(1), dim3(64), 0, fdd_stream(stream), out, parts_dev, nparts);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
 int fdd_xpby_ratio_dev(double *out, const double *x, const double *num_dev, const double *den_dev, const double *y, int n, void *stream)
 {
     FDD_REQUIRE(n >= 0);
@@ -628,6 +652,11 @@ int fdd_multi_axpy_scaled_dev(double *q, const double *coeffs_dev, const double 
 
 int fdd_multi_lincomb_scaled_dev(double *q, int q_is_zero, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream)
 {
+    return fdd_multi_lincomb_limited_dev(q, q_is_zero, coeffs_dev, v, v_scale_dev, nullptr, m, n, stream);
+}
+
+int fdd_multi_lincomb_limited_dev(double *q, int q_is_zero, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, const double *last_dev, int m, int n, void *stream)
+{
     const bool from_zero = q_is_zero != 0;
     FDD_REQUIRE(n >= 0 && m >= 1 && m <= FDD_MULTI_MAX);
     if (n == 0) return 0;
@@ -635,14 +664,14 @@ int fdd_multi_lincomb_scaled_dev(double *q, int q_is_zero, const double *coeffs_
     for (int k = 0; k < m; k++) FDD_REQUIRE(v[k] != nullptr && v[k] != q);
     switch (m)
     {
-    case 1: return launch_multi_axpy_dev<1>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
-    case 2: return launch_multi_axpy_dev<2>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
-    case 3: return launch_multi_axpy_dev<3>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
-    case 4: return launch_multi_axpy_dev<4>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
-    case 5: return launch_multi_axpy_dev<5>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
-    case 6: return launch_multi_axpy_dev<6>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
-    case 7: return launch_multi_axpy_dev<7>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
-    default: return launch_multi_axpy_dev<8>(q, coeffs_dev, v, v_scale_dev, from_zero, n, stream);
+    case 1: return launch_multi_axpy_dev<1>(q, coeffs_dev, v, v_scale_dev, from_zero, last_dev, n, stream);
+    case 2: return launch_multi_axpy_dev<2>(q, coeffs_dev, v, v_scale_dev, from_zero, last_dev, n, stream);
+    case 3: return launch_multi_axpy_dev<3>(q, coeffs_dev, v, v_scale_dev, from_zero, last_dev, n, stream);
+    case 4: return launch_multi_axpy_dev<4>(q, coeffs_dev, v, v_scale_dev, from_zero, last_dev, n, stream);
+    case 5: return launch_multi_axpy_dev<5>(q, coeffs_dev, v, v_scale_dev, from_zero, last_dev, n, stream);
+    case 6: return launch_multi_axpy_dev<6>(q, coeffs_dev, v, v_scale_dev, from_zero, last_dev, n, stream);
+    case 7: return launch_multi_axpy_dev<7>(q, coeffs_dev, v, v_scale_dev, from_zero, last_dev, n, stream);
+    default: return launch_multi_axpy_dev<8>(q, coeffs_dev, v, v_scale_dev, from_zero, last_dev, n, stream);
     }
 }
 

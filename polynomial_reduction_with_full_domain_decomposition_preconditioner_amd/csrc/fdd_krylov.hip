@@ -159,6 +159,13 @@ int fdd_gmres_scales(void *state, const double **inv_dev)
     return 0;
 }
 
+int fdd_gmres_last_column(void *state, const double **j_last_dev)
+{
+    FDD_REQUIRE(state != nullptr && j_last_dev != nullptr);
+    *j_last_dev = &static_cast<GmresState *>(state)->j_last;
+    return 0;
+}
+
 int fdd_gmres_coefficients(void *state, const double **y_dev)
 {
     FDD_REQUIRE(state != nullptr && y_dev != nullptr);

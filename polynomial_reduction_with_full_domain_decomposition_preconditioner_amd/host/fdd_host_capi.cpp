@@ -430,6 +430,10 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
     {
         for (auto &kv : p->domains) kv.second.assembled_outer = value != 0;
     }
+    else if (s == "lazy_steps")
+    {
+        for (auto &kv : p->domains) kv.second.lazy_steps = value != 0;
+    }
     else if (s == "device_bookkeeping")
     {
         if (p->subdomain) p->subdomain->device_bookkeeping = value != 0;
@@ -665,6 +669,7 @@ int fddh_problem_precond_apply(fddh_problem *p, int type, const double *r, doubl
     else
         p->subdomain->generalized_minimum_residual(p->b, p->a);
     p->b.copyTo(z, bytes);
+    p->subdomain->finish_history();
     const int nh = (int)p->subdomain->residual_history.size();
     if (history)
         for (int i = 0; i < nh && i < history_cap; i++) history[i] = p->subdomain->residual_history[i];
@@ -724,13 +729,10 @@ int fddh_problem_pcg_steps(fddh_problem *p, int steps, double *last_residual)
     if (!p || steps < 0) return fail("bad argument");
     Domain<SType> &d = p->fine();
     double r = std::numeric_limits<double>::quiet_NaN();
-    for (int s = 0; s < steps; s++)
-    {
-        if (p->subdomain && d.use_preconditioner)
-            r = d.fcg_step(*p->subdomain);
-        else
-            r = d.fcg_step(p->none);
-    }
+    if (p->subdomain && d.use_preconditioner)
+        r = d.fcg_steps(*p->subdomain, steps);
+    else
+        r = d.fcg_steps(p->none, steps);
     if (last_residual) *last_residual = r;
     return 0;
 }

@@ -378,6 +378,19 @@ class Subdomain
     bool restructured = true;             // inner GMRES with cached assembled basis, multi-dot / multi-axpy
     bool assembled_inner = true;          // inner GMRES on vectors over the dofs: Q fused into the stiffness load, no point-space Krylov basis
     bool device_bookkeeping = true;       // assembled inner GMRES: Givens / stopping tests in one-thread kernels, one host sync per cycle
+    bool lazy_history = false;            // single-cycle inner solves do not synchronise at all; finish_history() fetches on demand
+    bool history_pending = false;
+
+    // residual_history of the last lazy solve (one blocking read of the device state)
+    void finish_history()
+    {
+        if (not history_pending or not gmres_state.ptr()) return;
+        std::vector<double> hist(FDD_MULTI_MAX + 1);
+        int nh = 0, j_last = -1, steps = 0, converged = 0;
+        FDD_CALL(fdd_gmres_fetch(gmres_state.ptr(), nullptr, hist.data(), &nh, &j_last, &steps, &converged, fdd::dev().stream));
+        residual_history.assign(hist.begin(), hist.begin() + nh);
+        history_pending = false;
+    }
     bool mfma_stiffness = true;           // N >= 11 element lists on the fp64 matrix cores
     std::vector<DType> residual_history;  // inner history of the last application
 
@@ -1078,6 +1091,8 @@ class Subdomain
         // u~ starts at 0 (subdomain.tpp:4270-4275); the first update writes it without reading it
         int iter = 0;
         bool first_cycle = true;
+        history_pending = false;
+        const bool lazy = lazy_history and max_iterations <= m and fdd::globals().pstdout_file == nullptr;
         std::vector<const double *> W(m + 1), ptrs(m + 1);
         std::vector<fdd::memory *> Wm(m + 1);
         std::vector<double> hist(FDD_MULTI_MAX + 1);
@@ -1129,6 +1144,25 @@ class Subdomain
                 FDD_CALL(fdd_gmres_step_dev(st, slot, j, iter, max_iterations, tolerance, use_relative ? 1 : 0, stream));
             }
             FDD_CALL(fdd_gmres_finish_dev(st, m, stream));
+
+            if (lazy)
+            {
+                // single cycle, nobody is waiting for the history: the update takes its column count from the
+                // device state and the host does not synchronise at all (finish_history() reads the state later)
+                const double *last_dev = nullptr;
+                FDD_CALL(fdd_gmres_last_column(st, &last_dev));
+                fdd::ProfileScope prof("ew_vec2_kernel<MultiAxpy>", 8.0 * nd * (m + 2));
+                if (use_preconditioner)
+                {
+                    for (int i = 0; i < m; i++) ptrs[i] = ZA[i].template as<double>();
+                    FDD_CALL(fdd_multi_lincomb_limited_dev(ua.as<double>(), 1, y_dev, ptrs.data(), nullptr, last_dev, m, nd, stream));
+                }
+                else
+                    FDD_CALL(fdd_multi_lincomb_limited_dev(ua.as<double>(), 1, y_dev, W.data(), inv_dev, last_dev, m, nd, stream));
+                history_pending = true;
+                iter = std::min(m, max_iterations); // the steps enqueued; an early stop is only known to the device
+                break;
+            }
 
             // the one synchronisation of the cycle
             int nh = 0, j_last = -1, steps = 0, converged = 0;

@@ -545,3 +545,30 @@ int fdd_xpby_ratio_dev(double *out, const double *x, const double *num, const do
     for (int i = 0; i < n; i++) out[i] = x[i] + beta * y[i];
     return 0;
 }
+
+int fdd_multi_lincomb_limited_dev(double *q, int q_is_zero, const double *c, const double *const *v, const double *vs, const double *last, int m, int n, void *s)
+{
+    int use = last ? (int)*last + 1 : m;
+    if (use > m) use = m;
+    if (use <= 0)
+    {
+        if (q_is_zero) memset(q, 0, sizeof(double) * (size_t)n);
+        return 0;
+    }
+    return fdd_multi_lincomb_scaled_dev(q, q_is_zero, c, v, vs, use, n, s);
+}
+
+int fdd_sqrt_sum_dev(double *out, const double *parts, int nparts, void *s)
+{
+    (void)s;
+    double t = 0.0;
+    for (int k = 0; k < nparts; k++) t += parts[k];
+    *out = sqrt(t);
+    return 0;
+}
+
+int fdd_gmres_last_column(void *state, const double **j_last_dev)
+{
+    *j_last_dev = &((shim_gmres_state *)state)->j_last;
+    return 0;
+}
