@@ -167,6 +167,7 @@ int fddh_problem_pcg_solution(fddh_problem *p, double *u);
  * object).  collect() synchronises and writes a JSON object
  * {"<kernel family>": {"count": n, "ms": total, "bytes": algorithmic total}}. */
 int fddh_profile_enable(int on);
+int fddh_profile_only(const char *kernel_key); /* after enable: time only this kernel family (NULL / "": all); two event records per launch cost a few microseconds */
 int fddh_profile_collect(char *json, size_t json_len);
 
 int fddh_sync(void);   /* stream synchronise */

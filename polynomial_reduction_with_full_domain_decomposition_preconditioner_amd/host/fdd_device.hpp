@@ -153,12 +153,18 @@ class KernelProfiler
         return (int)keys_.size() - 1;
     }
 
+    std::vector<char> open_; // per open scope: was it recorded
+
   public:
     bool enabled = false;
+    std::string only; // when set, only this kernel family is timed (two event records cost a few microseconds each)
 
     void begin(const char *key, double bytes)
     {
         if (!enabled) return;
+        const bool take = only.empty() or only == key;
+        open_.push_back(take ? 1 : 0);
+        if (!take) return;
         Rec r{key_id(key), bytes, event(), event()};
         FDD_CALL(fdd_event_record(r.e0, dev().stream));
         recs_.push_back(r);
@@ -166,13 +172,16 @@ class KernelProfiler
 
     void end()
     {
-        if (!enabled) return;
-        FDD_CALL(fdd_event_record(recs_.back().e1, dev().stream));
+        if (!enabled or open_.empty()) return;
+        const bool took = open_.back() != 0;
+        open_.pop_back();
+        if (took) FDD_CALL(fdd_event_record(recs_.back().e1, dev().stream));
     }
 
     void reset()
     {
         recs_.clear();
+        open_.clear();
         used_ = 0;
     }
 

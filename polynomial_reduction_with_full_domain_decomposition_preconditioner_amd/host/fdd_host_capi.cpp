@@ -778,6 +778,13 @@ int fddh_profile_enable(int on)
 {
     fdd::profiler().reset();
     fdd::profiler().enabled = on != 0;
+    fdd::profiler().only.clear();
+    return 0;
+}
+
+int fddh_profile_only(const char *kernel_key)
+{
+    fdd::profiler().only = kernel_key ? kernel_key : "";
     return 0;
 }
 
