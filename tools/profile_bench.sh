@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- pyt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o run -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o run -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $out/pmc_write.log 2>&1
 cd $root
-python3 tools/rocprof_summary.py stats $out/stats $out/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
+python3 tools/rocprof_summary.py stats $out/stats $out/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --kernel-table $*"
 python3 tools/rocprof_summary.py pmc $out/pmc_fetch $out/pmc_write $out/pmc_traffic.json
 # keep only the small summaries (the traces hold torch's kilobyte-long kernel names)
 cp $out/stats/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null || cp $(find $out/stats -name '*kernel_stats.csv' | head -n 1) $out/kernel_stats.csv
