@@ -804,10 +804,9 @@ class Domain
             timer.start("subdomain.stitching");
             if (dof_shift >= 0)
             {
-                const int tail = num_local_nodes - dof_shift - nodes_sub_dofs;
-                if (dof_shift > 0) FDD_CALL(fdd_set_to_value(zn.as<double>(), 0.0, dof_shift, 0, stream));
+                // the Dirichlet ends of z~ were cleared once (fcg_nodes_begin) and nothing writes them: the shared ones
+                // see only zeros in the exchange (every rank masks them)
                 FDD_CALL(fdd_amg_vector_multiplication(zn.as<double>() + dof_shift, sub_u.as<double>(), node_stitch.as<double>() + dof_shift, nodes_sub_dofs, stream));
-                if (tail > 0) FDD_CALL(fdd_set_to_value(zn.as<double>(), 0.0, tail, dof_shift + nodes_sub_dofs, stream));
             }
             else
                 FDD_CALL(fdd_gather_indexed(zn.as<double>(), sub_u.as<double>(), dof_of_node.as<int>(), node_stitch.as<double>(), num_local_nodes, stream));
@@ -844,6 +843,7 @@ class Domain
 
         gather_nodes(nr, f);
         FDD_CALL(fdd_set_to_value(nu.as<double>(), 0.0, num_local_nodes, 0, fdd::dev().stream));
+        FDD_CALL(fdd_set_to_value(nz.as<double>(), 0.0, num_local_nodes, 0, fdd::dev().stream));
 
         node_norm(fcg_r_0_norm, nr);
         residual_history.push_back(fcg_r_0_norm);
