@@ -29,8 +29,11 @@ namespace
 {
 
 constexpr int kBlock = 256;
-constexpr int kBlockNnz = FDD_CSR_BLOCK_NNZ;
-constexpr int kBlockRowsMax = 2048;
+// Non-zeros per row block: the kernels are compiled for two sizes and the plan picks one per matrix.  Boolean
+// gather / scatter matrices (under 4 non-zeros per row) run best on 1024 (more workgroups in flight: Qt gather
+// 89 -> 77 us at C2), wider rows on 2048 (27-point stencil 838 -> 803 us).  A block holds at most as many rows.
+constexpr int kBlockNnzMax = FDD_CSR_BLOCK_NNZ;
+constexpr int kBlockNnzSmall = FDD_CSR_BLOCK_NNZ / 2;
 
 struct EpiPlain
 {
@@ -80,7 +83,7 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-template <typename Epi, bool UNIT>
+template <typename Epi, bool UNIT, int kBlockNnz>
 __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ Au, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const double *__restrict__ A_val, const double *__restrict__ u, Epi epi, const int *__restrict__ row_blocks)
 {
     __shared__ double prod[kBlockNnz];
@@ -183,10 +186,11 @@ int launch_rows(double *Au, const int *A_ptr, const int *A_col, const double *A_
 // the boundary prefix of a multi-rank Domain is gathered / scattered apart.
 // MODE 0: gather + scatter, 1: gather only, 2: scatter only (s read from t).
 // ---------------------------------------------------------------------------
-template <int MODE, bool WEIGHT, bool MASK>
+template <int MODE, bool WEIGHT, bool MASK, int kBlockNnz>
 __global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double *__restrict__ t, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const double *u, const double *__restrict__ node_weight, const double *__restrict__ point_mask, const int *__restrict__ row_blocks, int block_first, int row_lo, int row_hi)
 {
     __shared__ double x[kBlockNnz];
+    constexpr int kBlockRowsMax = kBlockNnz;
     __shared__ int sp[kBlockRowsMax + 1]; // the block's row pointers, relative to its first non-zero
     constexpr int kIts = kBlockNnz / kBlock;
     constexpr int kRowIts = kBlockRowsMax / kBlock;
@@ -286,6 +290,7 @@ __global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double
 
 // sum_nodes s*s*w with s = (Qt u)[node]*w[node], on the same row blocks; a
 // capped grid strides over the blocks, one partial per workgroup
+template <int kBlockNnz>
 __global__ __launch_bounds__(kBlock) void gather_norm2_block_kernel(double *__restrict__ ws, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const double *__restrict__ u, const double *__restrict__ w, const int *__restrict__ row_blocks, int num_blocks)
 {
     __shared__ double x[kBlockNnz];
@@ -366,6 +371,7 @@ struct fdd_csr_plan
     int kind; // 0: thread-per-row, 1: LDS-staged row blocks
     int unit_values; // every stored value is exactly 1.0: val need not be read
     int has_long_rows; // some row exceeds a block (workgroup-reduced in SpMV)
+    int block_nnz;     // kBlockNnzSmall or kBlockNnzMax: non-zeros (and rows) per row block
     int num_blocks;
     int *row_blocks_dev; // num_blocks + 1
     std::vector<int> row_blocks_host;
@@ -418,6 +424,8 @@ int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows
     p->kind = 0;
     p->unit_values = 0;
     p->has_long_rows = 0;
+    p->block_nnz = ((double)num_nnz < 4.0 * (double)num_rows) ? kBlockNnzSmall : kBlockNnzMax;
+    if (const char *e = getenv("FDD_TUNE_CSR_BLOCK_NNZ")) p->block_nnz = (atoi(e) <= kBlockNnzSmall) ? kBlockNnzSmall : kBlockNnzMax;
     p->num_blocks = 0;
     p->row_blocks_dev = nullptr;
 
@@ -440,7 +448,7 @@ int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows
     {
         const int base = A_ptr_host[r];
         int e = r;
-        while (e < num_rows && (e - r) < kBlockRowsMax && A_ptr_host[e + 1] - base <= kBlockNnz) e++;
+        while (e < num_rows && (e - r) < p->block_nnz && A_ptr_host[e + 1] - base <= p->block_nnz) e++;
         if (e == r)
         {
             e = r + 1; // one row longer than a block: workgroup-reduced
@@ -515,7 +523,14 @@ int fdd_csr_plan_dssum(const fdd_csr_plan *plan, double *QQtu, double *t, const 
     const dim3 grid(last - first), block(kBlock);
     hipStream_t s = fdd_stream(stream);
     const bool W = node_weight != nullptr && mode != 2, M = point_mask != nullptr && mode != 1;
-#define FDD_DSB(MODE, WW, MM) hipLaunchKernelGGL((dssum_block_kernel<MODE, WW, MM>), grid, block, 0, s, QQtu, t, Qt_ptr, Qt_col, u, node_weight, point_mask, plan->row_blocks_dev, first, row_lo, row_hi)
+#define FDD_DSB(MODE, WW, MM)                                                                                                                                                                    \
+    do                                                                                                                                                                                          \
+    {                                                                                                                                                                                           \
+        if (plan->block_nnz == kBlockNnzSmall)                                                                                                                                                  \
+            hipLaunchKernelGGL((dssum_block_kernel<MODE, WW, MM, kBlockNnzSmall>), grid, block, 0, s, QQtu, t, Qt_ptr, Qt_col, u, node_weight, point_mask, plan->row_blocks_dev, first, row_lo, row_hi); \
+        else                                                                                                                                                                                    \
+            hipLaunchKernelGGL((dssum_block_kernel<MODE, WW, MM, kBlockNnzMax>), grid, block, 0, s, QQtu, t, Qt_ptr, Qt_col, u, node_weight, point_mask, plan->row_blocks_dev, first, row_lo, row_hi);   \
+    } while (0)
     if (mode == 0)
     {
         if (W && M) FDD_DSB(0, true, true);
@@ -547,7 +562,10 @@ int fdd_csr_plan_gather_weighted_norm2(const fdd_csr_plan *plan, double *out, do
     FDD_REQUIRE(plan->unit_values != 0 && Qt_ptr != nullptr && Qt_col != nullptr && u != nullptr && node_weight != nullptr);
     if (plan->kind == 0 || plan->has_long_rows) return fdd_gather_weighted_norm2(out, ws, Qt_ptr, Qt_col, u, node_weight, plan->num_rows, stream);
     const int grid = plan->num_blocks < FDD_REDUCE_MAX_BLOCKS ? plan->num_blocks : FDD_REDUCE_MAX_BLOCKS;
-    hipLaunchKernelGGL(gather_norm2_block_kernel, dim3(grid), dim3(kBlock), 0, s, ws, Qt_ptr, Qt_col, u, node_weight, plan->row_blocks_dev, plan->num_blocks);
+    if (plan->block_nnz == kBlockNnzSmall)
+        hipLaunchKernelGGL(gather_norm2_block_kernel<kBlockNnzSmall>, dim3(grid), dim3(kBlock), 0, s, ws, Qt_ptr, Qt_col, u, node_weight, plan->row_blocks_dev, plan->num_blocks);
+    else
+        hipLaunchKernelGGL(gather_norm2_block_kernel<kBlockNnzMax>, dim3(grid), dim3(kBlock), 0, s, ws, Qt_ptr, Qt_col, u, node_weight, plan->row_blocks_dev, plan->num_blocks);
     FDD_LAUNCH_CHECK();
     hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(kBlock), 0, s, out, ws, grid);
     FDD_LAUNCH_CHECK();
@@ -568,6 +586,16 @@ int fdd_csr_plan_kind(const fdd_csr_plan *plan, int *kind)
     return 0;
 }
 
+// launch csr_block_kernel for the plan's block size
+#define FDD_CSR_BLOCK(EPI, UNIT, ...)                                                          \
+    do                                                                                         \
+    {                                                                                          \
+        if (plan->block_nnz == kBlockNnzSmall)                                                 \
+            hipLaunchKernelGGL((csr_block_kernel<EPI, UNIT, kBlockNnzSmall>), __VA_ARGS__);    \
+        else                                                                                   \
+            hipLaunchKernelGGL((csr_block_kernel<EPI, UNIT, kBlockNnzMax>), __VA_ARGS__);      \
+    } while (0)
+
 int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const double *weight, void *stream)
 {
     FDD_REQUIRE(plan != nullptr);
@@ -585,16 +613,16 @@ int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr
     if (plan->unit_values)
     {
         if (weight)
-            hipLaunchKernelGGL((csr_block_kernel<EpiWeight, true>), grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev);
+            FDD_CSR_BLOCK(EpiWeight, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev);
         else
-            hipLaunchKernelGGL((csr_block_kernel<EpiPlain, true>), grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev);
+            FDD_CSR_BLOCK(EpiPlain, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev);
     }
     else
     {
         if (weight)
-            hipLaunchKernelGGL((csr_block_kernel<EpiWeight, false>), grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev);
+            FDD_CSR_BLOCK(EpiWeight, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev);
         else
-            hipLaunchKernelGGL((csr_block_kernel<EpiPlain, false>), grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev);
+            FDD_CSR_BLOCK(EpiPlain, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev);
     }
     FDD_LAUNCH_CHECK();
     return 0;
@@ -610,9 +638,9 @@ int fdd_csr_plan_matvec(const fdd_csr_plan *plan, double *y, const int *A_ptr, c
     if (plan->kind == 0) return launch_rows(y, A_ptr, A_col, A_val, x, epi, 0, plan->num_rows, stream, plan->unit_values != 0);
     const dim3 grid(plan->num_blocks), block(kBlock);
     if (plan->unit_values)
-        hipLaunchKernelGGL((csr_block_kernel<EpiAxpby, true>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev);
+        FDD_CSR_BLOCK(EpiAxpby, true, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev);
     else
-        hipLaunchKernelGGL((csr_block_kernel<EpiAxpby, false>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev);
+        FDD_CSR_BLOCK(EpiAxpby, false, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev);
     FDD_LAUNCH_CHECK();
     return 0;
 }
