@@ -264,7 +264,7 @@ class ArrayMesh(BoxMesh):
 
 def rank_grid(num_ranks):
     """Rank blocks for a cube: 1->(1,1,1), 2->(2,1,1), 4->(2,2,1), 8->(2,2,2)."""
-    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[num_ranks]
+    return {1: (1, 1, 1), 2: (2, 1, 1), 3: (3, 1, 1), 4: (2, 2, 1), 6: (6, 1, 1), 8: (2, 2, 2)}[num_ranks]  # as host_api.rank_grid
 
 
 # --------------------------------------------------------------------------

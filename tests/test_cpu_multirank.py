@@ -113,11 +113,11 @@ def cpu_host_lib():
     return HOST_CPU_SO
 
 
-@pytest.mark.parametrize("world,with_sub", [(2, False), (2, True), (4, False)])
+@pytest.mark.parametrize("world,with_sub", [(2, False), (2, True), (3, True), (4, False)])
 def test_host_layer_multirank_gloo(cpu_host_lib, world, with_sub):
     import torch.multiprocessing as mp
 
-    E, N, red = (4, 4, 4), 3, 2
+    E, N, red = ((6, 4, 4) if world == 3 else (4, 4, 4)), 3, 2  # 3 ranks: the middle one has two interfaces (unequal boundary counts)
     mp.spawn(_worker, args=(world, _free_port(), E, N, red, with_sub), nprocs=world, join=True)
 
 
