@@ -35,19 +35,27 @@ constexpr int kBlock = 256;
 constexpr int kBlockNnzMax = FDD_CSR_BLOCK_NNZ;
 constexpr int kBlockNnzSmall = FDD_CSR_BLOCK_NNZ / 2;
 
+// Row epilogues.  apply() = operand() + finish(): the block kernel loads the operands of all its rows up front
+// (unconditionally, with its other loads) and finishes once the row sums are known.
 struct EpiPlain
 {
+    __device__ double operand(int, const double *) const { return 0.0; }
+    __device__ double finish(double s, double) const { return s; }
     __device__ double apply(double s, int row, const double *y_old) const { return s; }
 };
 struct EpiWeight
 {
     const double *weight;
+    __device__ double operand(int row, const double *) const { return weight[row]; }
+    __device__ double finish(double s, double w) const { return s * w; }
     __device__ double apply(double s, int row, const double *y_old) const { return s * weight[row]; }
 };
 struct EpiAxpby // AMG/csr_matrix.cpp:112-134
 {
     double alpha, beta;
     // beta == 0: y is output only (cusparseSpMV semantics), whatever it held is not read
+    __device__ double operand(int row, const double *y_old) const { return (beta == 0.0) ? 0.0 : y_old[row]; }
+    __device__ double finish(double s, double y) const { return (beta == 0.0) ? alpha * s : alpha * s + beta * y; }
     __device__ double apply(double s, int row, const double *y_old) const { return (beta == 0.0) ? alpha * s : alpha * s + beta * y_old[row]; }
 };
 
@@ -87,6 +95,12 @@ template <typename Epi, bool UNIT, int kBlockNnz>
 __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ Au, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const double *__restrict__ A_val, const double *__restrict__ u, Epi epi, const int *__restrict__ row_blocks)
 {
     __shared__ double prod[kBlockNnz];
+    // Matrices with short rows (the small block size) have hundreds of rows per block: their row pointers and
+    // epilogue operands are loaded up front with everything else and staged in LDS.  With wide rows a block has
+    // few rows and the extra LDS would only cost occupancy (27-point stencil: 757 -> 905 us): those read them
+    // in the row loop.
+    constexpr bool kStageRows = (kBlockNnz == kBlockNnzSmall);
+    __shared__ int sp[kStageRows ? kBlockNnz + 1 : 1];
     __shared__ double wsum[kBlock / FDD_WAVE];
 
     // Row blocks in plain dispatch order: the val/col streams of the 8 XCDs then
@@ -104,16 +118,30 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
         // value) loads first, then all x gathers, flat over the non-zeros --
         // no dependence on row lengths, every lane has 8 loads in flight
         constexpr int kIts = kBlockNnz / kBlock;
-        int c[kIts];
-        double a[kIts];
+        constexpr int kRowIts = kBlockNnz / kBlock; // a block has at most as many rows as non-zeros (the plan)
+        const int nrows = r1 - r0;
+        int c[kIts], rp[kRowIts];
+        double a[kIts], opnd[kRowIts];
 #pragma unroll
         for (int it = 0; it < kIts; it++)
         {
-            // unconditional loads on a selected index (see fdd_multi_row_sum): 8 loads per lane in flight
+            // unconditional loads on a selected index (see fdd_multi_row_sum): all of a lane's loads in flight
             const int k = threadIdx.x + it * kBlock;
             const int ks = (k < nnz) ? k : 0;
             c[it] = A_col[base + ks];
             a[it] = UNIT ? 1.0 : A_val[base + ks];
+        }
+        if (kStageRows)
+        {
+#pragma unroll
+            for (int it = 0; it < kRowIts; it++)
+            {
+                // row pointers and epilogue operands of this lane's rows, with the same trick
+                const int r = threadIdx.x + it * kBlock;
+                const int rs = (r < nrows) ? r : 0;
+                rp[it] = A_ptr[r0 + rs + 1];
+                opnd[it] = epi.operand(r0 + rs, Au);
+            }
         }
 #pragma unroll
         for (int it = 0; it < kIts; it++)
@@ -122,16 +150,44 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
             const double x = u[c[it]];
             if (k < nnz) prod[k] = a[it] * x;
         }
+        if (kStageRows)
+        {
+            if (threadIdx.x == 0) sp[0] = 0;
+#pragma unroll
+            for (int it = 0; it < kRowIts; it++)
+            {
+                const int r = threadIdx.x + it * kBlock;
+                if (r < nrows) sp[r + 1] = rp[it] - base;
+            }
+        }
         __syncthreads();
 
         // phase 2: one lane per row, products added in column order
-        for (int row = r0 + threadIdx.x; row < r1; row += kBlock)
+        if (kStageRows)
         {
-            const int j0 = A_ptr[row] - base;
-            const int j1 = A_ptr[row + 1] - base;
-            double Au_i = 0.0;
-            for (int j = j0; j < j1; j++) Au_i += prod[j];
-            Au[row] = epi.apply(Au_i, row, Au);
+#pragma unroll
+            for (int it = 0; it < kRowIts; it++)
+            {
+                const int r = threadIdx.x + it * kBlock;
+                if (r < nrows)
+                {
+                    const int j0 = sp[r], j1 = sp[r + 1];
+                    double Au_i = 0.0;
+                    for (int j = j0; j < j1; j++) Au_i += prod[j];
+                    Au[r0 + r] = epi.finish(Au_i, opnd[it]);
+                }
+            }
+        }
+        else
+        {
+            for (int row = r0 + threadIdx.x; row < r1; row += kBlock)
+            {
+                const int j0 = A_ptr[row] - base;
+                const int j1 = A_ptr[row + 1] - base;
+                double Au_i = 0.0;
+                for (int j = j0; j < j1; j++) Au_i += prod[j];
+                Au[row] = epi.apply(Au_i, row, Au);
+            }
         }
     }
     else
