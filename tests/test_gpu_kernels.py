@@ -940,6 +940,41 @@ def test_scaled_forms_equal_scaling_first(gpu):
     assert np.array_equal(host(A1), host(A2))
 
 
+def test_limited_linear_combination_and_small_device_ops(gpu):
+    """fdd_multi_lincomb_limited_dev (solution update whose column count never left the device; q taken as 0
+    without being read), fdd_xpby_ratio_dev (p = z + (num/den) p), fdd_sqrt_sum_dev."""
+    L = S.oracle()
+    m, n = 5, 200003
+    V = [rnd(n, 300 + i) for i in range(m)]
+    c, inv = rnd(m, 310), np.abs(rnd(m, 311)) + 0.5
+    dV, dc, dinv = [dev(v, gpu) for v in V], dev(c, gpu), dev(inv, gpu)
+    for last in (0, 2, 4):
+        ref = np.zeros(n)
+        for i in range(last + 1):
+            t = np.zeros(n)
+            L.orc_vector_scaling(P(t), ctypes.c_double(inv[i]), P(V[i]), n)
+            L.orc_vector_vector_addition(P(ref), ctypes.c_double(1.0), P(ref), ctypes.c_double(c[i]), P(t), n)
+        q = torch.full((n,), float("nan"), dtype=torch.float64, device=gpu)  # garbage in: must not be read
+        k("fdd_multi_lincomb_limited_dev", q, 1, dc, dV, dinv, dev(np.array([float(last)]), gpu), m, n)
+        assert np.array_equal(host(q), ref), last
+        # accumulate on top of an existing q, no limit
+        q2 = dev(rnd(n, 320), gpu)
+        ref2 = rnd(n, 320)
+        for i in range(m):
+            L.orc_vector_vector_addition(P(ref2), ctypes.c_double(1.0), P(ref2), ctypes.c_double(c[i]), P(V[i]), n)
+        k("fdd_multi_lincomb_limited_dev", q2, 0, dc, dV, None, None, m, n)
+        assert np.array_equal(host(q2), ref2)
+    z, p = rnd(n, 330), rnd(n, 331)
+    num, den = np.array([0.37]), np.array([-1.9])
+    dp = dev(p, gpu)
+    k("fdd_xpby_ratio_dev", dp, dev(z, gpu), dev(num, gpu), dev(den, gpu), dp, n)
+    assert np.array_equal(host(dp), z + (num[0] / den[0]) * p)
+    parts = np.array([2.25, 4.0])
+    out = torch.zeros(1, dtype=torch.float64, device=gpu)
+    k("fdd_sqrt_sum_dev", out, dev(parts, gpu), 2)
+    assert host(out)[0] == 2.5
+
+
 def test_gather_indexed(gpu):
     n_in, n_out = 5000, 7001
     x, sc = rnd(n_in, 70), rnd(n_out, 71)
