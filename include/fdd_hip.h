@@ -198,6 +198,7 @@ int fdd_amg_vector_multiplication(double *uv, const double *u, const double *v, 
 int fdd_amg_matvec(double *y, const int *ptr, const int *col, const double *val, const double *x, double alpha, double beta, int num_rows, void *stream);
 /* the same on a plan (LDS row staging for the ~27 non-zeros per row of the AMG levels) */
 int fdd_csr_plan_matvec(const fdd_csr_plan *plan, double *y, const int *A_ptr, const int *A_col, const double *A_val, const double *x, double alpha, double beta, void *stream);
+int fdd_csr_plan_matvec_to(const fdd_csr_plan *plan, double *y, const double *y_in, const int *A_ptr, const int *A_col, const double *A_val, const double *x, double alpha, double beta, void *stream); /* y = alpha*A*x + beta*y_in (y_in NULL: y itself): f - A u without first copying f */
 /* cublasDdot replacement (AMG/vector.cpp:100,129): out[0] = sum x*y */
 int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int size, void *stream);
 

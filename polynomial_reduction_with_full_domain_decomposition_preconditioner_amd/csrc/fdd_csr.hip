@@ -53,10 +53,11 @@ struct EpiWeight
 struct EpiAxpby // AMG/csr_matrix.cpp:112-134
 {
     double alpha, beta;
+    const double *y_in; // optional: y = alpha*A*x + beta*y_in with y_in another vector (f - A u without copying f first)
     // beta == 0: y is output only (cusparseSpMV semantics), whatever it held is not read
-    __device__ double operand(int row, const double *y_old) const { return (beta == 0.0) ? 0.0 : y_old[row]; }
+    __device__ double operand(int row, const double *y_old) const { return (beta == 0.0) ? 0.0 : (y_in ? y_in[row] : y_old[row]); }
     __device__ double finish(double s, double y) const { return (beta == 0.0) ? alpha * s : alpha * s + beta * y; }
-    __device__ double apply(double s, int row, const double *y_old) const { return (beta == 0.0) ? alpha * s : alpha * s + beta * y_old[row]; }
+    __device__ double apply(double s, int row, const double *y_old) const { return (beta == 0.0) ? alpha * s : alpha * s + beta * (y_in ? y_in[row] : y_old[row]); }
 };
 
 // Lane-per-row SpMV.  Each lane owns NPT rows (strided by the workgroup size,
@@ -464,7 +465,7 @@ int fdd_amg_matvec(double *y, const int *ptr, const int *col, const double *val,
     FDD_REQUIRE(num_rows >= 0);
     if (num_rows == 0) return 0;
     FDD_REQUIRE(y != nullptr && ptr != nullptr && x != nullptr && y != x);
-    return launch_rows(y, ptr, col, val, x, EpiAxpby{alpha, beta}, 0, num_rows, stream);
+    return launch_rows(y, ptr, col, val, x, EpiAxpby{alpha, beta, nullptr}, 0, num_rows, stream);
 }
 
 int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows, int num_cols, int num_nnz)
@@ -687,10 +688,15 @@ int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr
 // y = alpha*A*x + beta*y on a plan (the cusparseSpMV of AMG/csr_matrix.cpp:129-131); y must not alias x
 int fdd_csr_plan_matvec(const fdd_csr_plan *plan, double *y, const int *A_ptr, const int *A_col, const double *A_val, const double *x, double alpha, double beta, void *stream)
 {
+    return fdd_csr_plan_matvec_to(plan, y, nullptr, A_ptr, A_col, A_val, x, alpha, beta, stream);
+}
+
+int fdd_csr_plan_matvec_to(const fdd_csr_plan *plan, double *y, const double *y_in, const int *A_ptr, const int *A_col, const double *A_val, const double *x, double alpha, double beta, void *stream)
+{
     FDD_REQUIRE(plan != nullptr);
     if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
     FDD_REQUIRE(y != nullptr && A_ptr != nullptr && x != nullptr && y != x);
-    const EpiAxpby epi{alpha, beta};
+    const EpiAxpby epi{alpha, beta, y_in};
     if (plan->kind == 0) return launch_rows(y, A_ptr, A_col, A_val, x, epi, 0, plan->num_rows, stream, plan->unit_values != 0);
     const dim3 grid(plan->num_blocks), block(kBlock);
     if (plan->unit_values)

@@ -55,10 +55,9 @@ class Hierarchy
     {
         Level &L = levels[l];
         void *s = fdd::dev().stream;
-        // scaled_residual (:34-39)
-        copy(L.work, L.f, L.n);
-        if (not u_is_zero) L.A.matvec(L.work, L.u, -1.0, 1.0);
-        FDD_CALL(fdd_amg_main_scaled_residual(L.r.as<double>(), L.w.as<double>(), L.work.as<double>(), L.D_val.as<double>(), L.coefs[cheby_order - 1], L.n, s));
+        // scaled_residual (:34-39): work = f - A u without the copy "work = f" in front of the SpMV; from u = 0 it is f
+        if (not u_is_zero) L.A.matvec_to(L.work, L.f, L.u, -1.0, 1.0);
+        FDD_CALL(fdd_amg_main_scaled_residual(L.r.as<double>(), L.w.as<double>(), (u_is_zero ? L.f : L.work).as<double>(), L.D_val.as<double>(), L.coefs[cheby_order - 1], L.n, s));
         // polynomial_evaluation (:62-67)
         for (int p = cheby_order - 2; p >= 0; p--)
         {
@@ -83,8 +82,7 @@ class Hierarchy
                 Level &L = levels[l];
                 if (l > 0) FDD_CALL(fdd_amg_vector_set_to_value(L.u.as<double>(), 0.0, L.n, s));
                 smooth(l, l > 0 or iter == 0);
-                copy(L.v, L.f, L.n);             // v = f
-                L.A.matvec(L.v, L.u, -1.0, 1.0); // v = f - A u
+                L.A.matvec_to(L.v, L.f, L.u, -1.0, 1.0); // v = f - A u
                 L.R.matvec(levels[l + 1].f, L.v, 1.0, 0.0);
             }
             Level &C = levels[nl - 1];

@@ -149,6 +149,15 @@ class CSR_Matrix
         FDD_CALL(fdd_csr_plan_matvec(plan, y.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), x.as<double>(), alpha, beta, fdd::dev().stream));
     }
 
+    // y = alpha*A*x + beta*y_in: the copy "y = y_in" that precedes the SpMV in the reference (subdomain.tpp:34-36) folded in
+    void matvec_to(fdd::memory &y, fdd::memory &y_in, fdd::memory &x, double alpha, double beta)
+    {
+        if ((num_rows == 0) or (num_cols == 0)) return;
+        initialization_check();
+        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiAxpby>" : "csr_block_kernel<EpiAxpby>", algorithmic_bytes(beta != 0.0));
+        FDD_CALL(fdd_csr_plan_matvec_to(plan, y.as<double>(), y_in.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), x.as<double>(), alpha, beta, fdd::dev().stream));
+    }
+
   private:
     // host mirrors -> HBM + the SpMV plan
     void upload()

@@ -572,3 +572,9 @@ int fdd_gmres_last_column(void *state, const double **j_last_dev)
     *j_last_dev = &((shim_gmres_state *)state)->j_last;
     return 0;
 }
+
+int fdd_csr_plan_matvec_to(const fdd_csr_plan *plan, double *y, const double *y_in, const int *p, const int *c, const double *v, const double *x, double a, double b, void *s)
+{
+    if (y_in && y_in != y && b != 0.0) memcpy(y, y_in, sizeof(double) * (size_t)plan->num_rows);
+    return fdd_csr_plan_matvec(plan, y, p, c, v, x, a, b, s);
+}
