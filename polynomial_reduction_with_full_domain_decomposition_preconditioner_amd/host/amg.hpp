@@ -46,8 +46,6 @@ class Hierarchy
     bool graph_failed = false;
     CSR_Matrix<double> coarse_inverse;
 
-    static void copy(fdd::memory &dst, const fdd::memory &src, int n) { dst.copyFrom(src, (size_t)n * sizeof(double)); }
-
     // Chebyshev smoother, device branches of subdomain.tpp:19-83
     // u_is_zero: the level's u was just set to 0 (every pre-smoothing), so f - A u is f itself
     // bit for bit and the SpMV of scaled_residual is skipped (the reference multiplies by the zero vector)
