@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
     const double uscale = (kGather && u_scale) ? *u_scale : 1.0;
     // kGather: the dof indices run one element ahead of the values they address (rd), so that the value
     // loads of the prefetch never wait on an index load issued in the same phase
-    auto load_idx = [&](size_t p, bool ok) -> int { return ok ? point_dof[p] : -1; };
+    auto load_idx = [&](size_t p, bool ok) -> int { return ok ? __builtin_nontemporal_load(point_dof + p) : -1; }; // the index stream is read once
     auto load_val = [&](int d) -> double { // unconditional load on a selected index, then the select
         const double v = u[d < 0 ? 0 : d];
         return (d < 0) ? 0.0 : (u_scale ? uscale * v : v);
