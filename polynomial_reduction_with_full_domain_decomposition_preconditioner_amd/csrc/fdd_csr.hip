@@ -93,7 +93,7 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 template <typename Epi, bool UNIT, int kBlockNnz>
-__global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ Au, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const double *__restrict__ A_val, const double *__restrict__ u, Epi epi, const int *__restrict__ row_blocks)
+__global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ Au, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const double *__restrict__ A_val, const double *__restrict__ u, Epi epi, const int *__restrict__ row_blocks, int xcd_chunked)
 {
     __shared__ double prod[kBlockNnz];
     // Matrices with short rows (the small block size) have hundreds of rows per block: their row pointers and
@@ -104,10 +104,11 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
     __shared__ int sp[kStageRows ? kBlockNnz + 1 : 1];
     __shared__ double wsum[kBlock / FDD_WAVE];
 
-    // Row blocks in plain dispatch order: the val/col streams of the 8 XCDs then
-    // advance through adjacent memory (XCD-chunked order measured 9 % slower on
-    // the 27-point stencil; the x window fits every XCD's L2 either way).
-    const int b = blockIdx.x;
+    // Row blocks in plain dispatch order by default: the val/col streams of the 8 XCDs then advance through
+    // adjacent memory.  XCD-chunked order (FDD_TUNE_CSR_XCD=1) does cut the 27-point stencil's L2 fetch traffic
+    // from 4.58 to 4.00 GB per launch (x is no longer pulled through all eight L2s; algorithmic 3.80 GB) but
+    // runs 3 % slower (785 vs 762 us): the re-fetches are Infinity Cache hits, the eight far-apart streams cost more.
+    const int b = xcd_chunked ? fdd_xcd_chunked_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int r0 = row_blocks[b];
     const int r1 = row_blocks[b + 1];
     const int base = A_ptr[r0];
@@ -129,8 +130,10 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
             // unconditional loads on a selected index (see fdd_multi_row_sum): all of a lane's loads in flight
             const int k = threadIdx.x + it * kBlock;
             const int ks = (k < nnz) ? k : 0;
-            c[it] = A_col[base + ks];
-            a[it] = UNIT ? 1.0 : A_val[base + ks];
+            // short-row matrices: the matrix streams are read once per launch and x keeps the L2 (Qt at C2: 91 -> 79 us);
+            // the 27-point stencil measured 2 % slower that way
+            c[it] = kStageRows ? __builtin_nontemporal_load(A_col + base + ks) : A_col[base + ks];
+            a[it] = UNIT ? 1.0 : (kStageRows ? __builtin_nontemporal_load(A_val + base + ks) : A_val[base + ks]);
         }
         if (kStageRows)
         {
@@ -144,6 +147,12 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
                 opnd[it] = epi.operand(r0 + rs, Au);
             }
         }
+        // wide rows: the lane's first row (the only one, unless the block is full of short rows) has its
+        // pointers and epilogue operand requested here, so that nothing is loaded from HBM after the barrier
+        const int rs0 = (threadIdx.x < nrows) ? threadIdx.x : 0;
+        const int first_j0 = kStageRows ? 0 : A_ptr[r0 + rs0] - base;
+        const int first_j1 = kStageRows ? 0 : A_ptr[r0 + rs0 + 1] - base;
+        const double first_opnd = kStageRows ? 0.0 : epi.operand(r0 + rs0, Au);
 #pragma unroll
         for (int it = 0; it < kIts; it++)
         {
@@ -183,11 +192,25 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
         {
             for (int row = r0 + threadIdx.x; row < r1; row += kBlock)
             {
-                const int j0 = A_ptr[row] - base;
-                const int j1 = A_ptr[row + 1] - base;
+                const bool first = (row == r0 + (int)threadIdx.x);
+                const int j0 = first ? first_j0 : A_ptr[row] - base;
+                const int j1 = first ? first_j1 : A_ptr[row + 1] - base;
+                const double y = first ? first_opnd : epi.operand(row, Au);
+                // four LDS reads in flight per lane; the sum stays in column order (slots past the row add +0.0,
+                // which leaves a sum that started from +0.0 unchanged bit for bit)
                 double Au_i = 0.0;
-                for (int j = j0; j < j1; j++) Au_i += prod[j];
-                Au[row] = epi.apply(Au_i, row, Au);
+                for (int j = j0; j < j1; j += 4)
+                {
+                    const double p0 = prod[j];
+                    const double p1 = prod[(j + 1 < kBlockNnz) ? j + 1 : j];
+                    const double p2 = prod[(j + 2 < kBlockNnz) ? j + 2 : j];
+                    const double p3 = prod[(j + 3 < kBlockNnz) ? j + 3 : j];
+                    Au_i += p0;
+                    Au_i += (j + 1 < j1) ? p1 : 0.0;
+                    Au_i += (j + 2 < j1) ? p2 : 0.0;
+                    Au_i += (j + 3 < j1) ? p3 : 0.0;
+                }
+                Au[row] = epi.finish(Au_i, y);
             }
         }
     }
@@ -429,6 +452,7 @@ struct fdd_csr_plan
     int unit_values; // every stored value is exactly 1.0: val need not be read
     int has_long_rows; // some row exceeds a block (workgroup-reduced in SpMV)
     int block_nnz;     // kBlockNnzSmall or kBlockNnzMax: non-zeros (and rows) per row block
+    int xcd_chunked;   // SpMV row blocks in XCD-chunked order
     int num_blocks;
     int *row_blocks_dev; // num_blocks + 1
     std::vector<int> row_blocks_host;
@@ -483,6 +507,7 @@ int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows
     p->has_long_rows = 0;
     p->block_nnz = ((double)num_nnz < 4.0 * (double)num_rows) ? kBlockNnzSmall : kBlockNnzMax;
     if (const char *e = getenv("FDD_TUNE_CSR_BLOCK_NNZ")) p->block_nnz = (atoi(e) <= kBlockNnzSmall) ? kBlockNnzSmall : kBlockNnzMax;
+    p->xcd_chunked = fdd_env_int("FDD_TUNE_CSR_XCD", 0);
     p->num_blocks = 0;
     p->row_blocks_dev = nullptr;
 
@@ -670,16 +695,16 @@ int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr
     if (plan->unit_values)
     {
         if (weight)
-            FDD_CSR_BLOCK(EpiWeight, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev);
+            FDD_CSR_BLOCK(EpiWeight, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev, plan->xcd_chunked);
         else
-            FDD_CSR_BLOCK(EpiPlain, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev);
+            FDD_CSR_BLOCK(EpiPlain, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev, plan->xcd_chunked);
     }
     else
     {
         if (weight)
-            FDD_CSR_BLOCK(EpiWeight, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev);
+            FDD_CSR_BLOCK(EpiWeight, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev, plan->xcd_chunked);
         else
-            FDD_CSR_BLOCK(EpiPlain, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev);
+            FDD_CSR_BLOCK(EpiPlain, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev, plan->xcd_chunked);
     }
     FDD_LAUNCH_CHECK();
     return 0;
@@ -700,9 +725,9 @@ int fdd_csr_plan_matvec_to(const fdd_csr_plan *plan, double *y, const double *y_
     if (plan->kind == 0) return launch_rows(y, A_ptr, A_col, A_val, x, epi, 0, plan->num_rows, stream, plan->unit_values != 0);
     const dim3 grid(plan->num_blocks), block(kBlock);
     if (plan->unit_values)
-        FDD_CSR_BLOCK(EpiAxpby, true, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev);
+        FDD_CSR_BLOCK(EpiAxpby, true, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
     else
-        FDD_CSR_BLOCK(EpiAxpby, false, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev);
+        FDD_CSR_BLOCK(EpiAxpby, false, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
     FDD_LAUNCH_CHECK();
     return 0;
 }
