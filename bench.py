@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--comm", choices=["torch", "rccl"], default="torch", help="N>1: torch.distributed(nccl=RCCL) callbacks, or RCCL called directly")
     ap.add_argument("--no-precond", action="store_true")
     ap.add_argument("--amg", action="store_true", help="inner solve preconditioned by the low-order AMG V-cycle (config C5's preconditioner; hierarchy built by the host layer)")
+    ap.add_argument("--no-amg-fusion", action="store_true", help="with --amg: the smoother's element-wise kernels as separate launches (the reference's sequence) instead of SpMV epilogues")
     ap.add_argument("--no-amg-graph", action="store_true", help="with --amg: launch the V-cycle kernel by kernel (so that --kernel-table shows them) instead of replaying its hipGraph")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N>1 ranks all on cuda:0 with a gloo group staging device buffers over the host: exercises the multi-rank code path on a one-GPU box (not a measurement)")
     ap.add_argument("--kernel-table", action="store_true", help="time every instrumented kernel family in the timed region (fills `kernels`; costs ~8 %% of a step)")
@@ -174,6 +175,8 @@ def main():
         prob.set_flag("sub_use_preconditioner", 1)
         if args.no_amg_graph:
             prob.set_flag("amg_graph", 0)
+        if args.no_amg_fusion:
+            prob.set_flag("amg_fused_smoother", 0)
     t_setup = time.perf_counter() - t_setup
 
     def max_over_ranks(x):

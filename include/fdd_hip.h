@@ -199,6 +199,16 @@ int fdd_amg_matvec(double *y, const int *ptr, const int *col, const double *val,
 /* the same on a plan (LDS row staging for the ~27 non-zeros per row of the AMG levels) */
 int fdd_csr_plan_matvec(const fdd_csr_plan *plan, double *y, const int *A_ptr, const int *A_col, const double *A_val, const double *x, double alpha, double beta, void *stream);
 int fdd_csr_plan_matvec_to(const fdd_csr_plan *plan, double *y, const double *y_in, const int *A_ptr, const int *A_col, const double *A_val, const double *x, double alpha, double beta, void *stream); /* y = alpha*A*x + beta*y_in (y_in NULL: y itself): f - A u without first copying f */
+/* The Chebyshev smoother (subdomain.tpp:19-83) with its element-wise kernels (AMG/kernels.cu:25-94) fused into the
+ * SpMV in front of them, statement for statement the same arithmetic:
+ *   residual:    Sr = D*(f - A u);  work = D*(coef*Sr)          [matvec(-1,1) + scaled_residual + vector_multiplication]
+ *   polynomial:  work_out = D*(coef*Sr + D*(A work_in))         [matvec(1,0) + polynomial_evaluation + vector_multiplication]
+ *   update:      u += D*(coef*Sr + D*(A work_in))               [matvec(1,0) + polynomial_evaluation + update_field]
+ *   start:       Sr = D*f;  work = D*(coef*Sr)                  [scaled_residual from u = 0 + vector_multiplication] */
+int fdd_amg_smooth_residual_matvec(const fdd_csr_plan *plan, double *work, double *Sr, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const double *f, const double *D_val, double coef, void *stream);
+int fdd_amg_smooth_polynomial_matvec(const fdd_csr_plan *plan, double *work_out, const int *A_ptr, const int *A_col, const double *A_val, const double *work_in, const double *Sr, const double *D_val, double coef, void *stream);
+int fdd_amg_smooth_update_matvec(const fdd_csr_plan *plan, double *u, const int *A_ptr, const int *A_col, const double *A_val, const double *work_in, const double *Sr, const double *D_val, double coef, void *stream);
+int fdd_amg_smooth_start(double *work, double *Sr, const double *f, const double *D_val, double coef, int size, void *stream);
 /* cublasDdot replacement (AMG/vector.cpp:100,129): out[0] = sum x*y */
 int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int size, void *stream);
 

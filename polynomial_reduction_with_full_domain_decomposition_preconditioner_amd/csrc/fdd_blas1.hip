@@ -406,6 +406,28 @@ struct ScaledResidualOp // AMG/kernels.cu:25-41
     }
 };
 
+struct SmoothStartOp // scaled_residual from u = 0 (f - A u is f) followed by vector_multiplication: Sr = S*f, work = D*(alpha*Sr)
+{
+    double *work;
+    double *Sr;
+    const double *f;
+    const double *S;
+    double alpha;
+    __device__ void vec2(long long i) const
+    {
+        double2 s = ld2(S, i), r = ld2(f, i);
+        double2 sr = make_double2(s.x * r.x, s.y * r.y);
+        st2(Sr, i, sr);
+        st2(work, i, make_double2(s.x * (alpha * sr.x), s.y * (alpha * sr.y)));
+    }
+    __device__ void one(long long i) const
+    {
+        const double sr = S[i] * f[i];
+        Sr[i] = sr;
+        work[i] = S[i] * (alpha * sr);
+    }
+};
+
 struct PolyEvalOp // AMG/kernels.cu:43-59
 {
     double *w;
@@ -687,6 +709,15 @@ int fdd_amg_main_scaled_residual(double *Sr, double *w, const double *f_m_Au, co
     FDD_REQUIRE(Sr != nullptr && w != nullptr && f_m_Au != nullptr && S != nullptr);
     bool al = fdd_aligned16(Sr) && fdd_aligned16(w) && fdd_aligned16(f_m_Au) && fdd_aligned16(S);
     return launch_ew(ScaledResidualOp{Sr, w, f_m_Au, S, alpha}, size, al, stream);
+}
+
+int fdd_amg_smooth_start(double *work, double *Sr, const double *f, const double *D_val, double coef, int size, void *stream)
+{
+    FDD_REQUIRE(size >= 0);
+    if (size == 0) return 0;
+    FDD_REQUIRE(work != nullptr && Sr != nullptr && f != nullptr && D_val != nullptr);
+    bool al = fdd_aligned16(work) && fdd_aligned16(Sr) && fdd_aligned16(f) && fdd_aligned16(D_val);
+    return launch_ew(SmoothStartOp{work, Sr, f, D_val, coef}, size, al, stream);
 }
 
 int fdd_amg_main_polynomial_evaluation(double *w, double *v, const double *r, const double *D_val, double alpha, int size, void *stream)

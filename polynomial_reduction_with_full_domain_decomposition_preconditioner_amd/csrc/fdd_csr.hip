@@ -39,25 +39,82 @@ constexpr int kBlockNnzSmall = FDD_CSR_BLOCK_NNZ / 2;
 // (unconditionally, with its other loads) and finishes once the row sums are known.
 struct EpiPlain
 {
+    typedef double Opnd;
     __device__ double operand(int, const double *) const { return 0.0; }
-    __device__ double finish(double s, double) const { return s; }
-    __device__ double apply(double s, int row, const double *y_old) const { return s; }
+    __device__ double finish(double s, double, int) const { return s; }
 };
 struct EpiWeight
 {
+    typedef double Opnd;
     const double *weight;
     __device__ double operand(int row, const double *) const { return weight[row]; }
-    __device__ double finish(double s, double w) const { return s * w; }
-    __device__ double apply(double s, int row, const double *y_old) const { return s * weight[row]; }
+    __device__ double finish(double s, double w, int) const { return s * w; }
 };
 struct EpiAxpby // AMG/csr_matrix.cpp:112-134
 {
+    typedef double Opnd;
     double alpha, beta;
     const double *y_in; // optional: y = alpha*A*x + beta*y_in with y_in another vector (f - A u without copying f first)
     // beta == 0: y is output only (cusparseSpMV semantics), whatever it held is not read
     __device__ double operand(int row, const double *y_old) const { return (beta == 0.0) ? 0.0 : (y_in ? y_in[row] : y_old[row]); }
-    __device__ double finish(double s, double y) const { return (beta == 0.0) ? alpha * s : alpha * s + beta * y; }
-    __device__ double apply(double s, int row, const double *y_old) const { return (beta == 0.0) ? alpha * s : alpha * s + beta * (y_in ? y_in[row] : y_old[row]); }
+    __device__ double finish(double s, double y, int) const { return (beta == 0.0) ? alpha * s : alpha * s + beta * y; }
+};
+
+// The Chebyshev smoother's element-wise kernels (subdomain.tpp:19-83, AMG/kernels.cu:25-94) as epilogues of the
+// SpMV in front of them: the same products and sums in the same order (the statements of the unfused kernels are
+// quoted), without the vectors in between going through HBM.
+struct Opnd2
+{
+    double a, b;
+};
+struct Opnd3
+{
+    double a, b, c;
+};
+// work = f - A u (matvec -1, 1) | Sr = S*work; w = alpha*Sr (scaled_residual) | out = D*w (vector_multiplication)
+struct EpiSmoothResidual
+{
+    typedef Opnd2 Opnd;
+    const double *f, *D;
+    double *r; // Sr
+    double coef;
+    __device__ Opnd2 operand(int row, const double *) const { return Opnd2{f[row], D[row]}; }
+    __device__ double finish(double s, Opnd2 o, int row) const
+    {
+        const double work = -1.0 * s + 1.0 * o.a;
+        const double sr = o.b * work;
+        r[row] = sr;
+        const double w = coef * sr;
+        return w * o.b;
+    }
+};
+// v = A work (matvec 1, 0) | v *= D; w = alpha*r + v (polynomial_evaluation) | out = D*w (vector_multiplication)
+struct EpiSmoothPoly
+{
+    typedef Opnd2 Opnd;
+    const double *r, *D;
+    double coef;
+    __device__ Opnd2 operand(int row, const double *) const { return Opnd2{r[row], D[row]}; }
+    __device__ double finish(double s, Opnd2 o, int) const
+    {
+        const double v = (1.0 * s) * o.b;
+        const double w = coef * o.a + v;
+        return w * o.b;
+    }
+};
+// v = A work | v *= D; w = alpha*r + v (polynomial_evaluation) | u += D*w (update_field): the output vector is u
+struct EpiSmoothUpdate
+{
+    typedef Opnd3 Opnd;
+    const double *r, *D;
+    double coef;
+    __device__ Opnd3 operand(int row, const double *u_old) const { return Opnd3{r[row], D[row], u_old[row]}; }
+    __device__ double finish(double s, Opnd3 o, int) const
+    {
+        const double v = (1.0 * s) * o.b;
+        const double w = coef * o.a + v;
+        return o.c + o.b * w;
+    }
 };
 
 // Lane-per-row SpMV.  Each lane owns NPT rows (strided by the workgroup size,
@@ -82,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void csr_row_kernel(double *__restrict__ Au
     fdd_multi_row_sum<NPT, 4, UNIT>(A_col, A_val, u, j0, j1, s);
 #pragma unroll
     for (int r = 0; r < NPT; r++)
-        if (row[r] < row_end) Au[row[r]] = epi.apply(s[r], row[r], Au);
+        if (row[r] < row_end) Au[row[r]] = epi.finish(s[r], epi.operand(row[r], Au), row[r]);
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -123,7 +180,8 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
         constexpr int kRowIts = kBlockNnz / kBlock; // a block has at most as many rows as non-zeros (the plan)
         const int nrows = r1 - r0;
         int c[kIts], rp[kRowIts];
-        double a[kIts], opnd[kRowIts];
+        double a[kIts];
+        typename Epi::Opnd opnd[kRowIts];
 #pragma unroll
         for (int it = 0; it < kIts; it++)
         {
@@ -152,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
         const int rs0 = (threadIdx.x < nrows) ? threadIdx.x : 0;
         const int first_j0 = kStageRows ? 0 : A_ptr[r0 + rs0] - base;
         const int first_j1 = kStageRows ? 0 : A_ptr[r0 + rs0 + 1] - base;
-        const double first_opnd = kStageRows ? 0.0 : epi.operand(r0 + rs0, Au);
+        const typename Epi::Opnd first_opnd = epi.operand(r0 + rs0, Au); // unused (and dropped) when the rows are staged
 #pragma unroll
         for (int it = 0; it < kIts; it++)
         {
@@ -184,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
                     const int j0 = sp[r], j1 = sp[r + 1];
                     double Au_i = 0.0;
                     for (int j = j0; j < j1; j++) Au_i += prod[j];
-                    Au[r0 + r] = epi.finish(Au_i, opnd[it]);
+                    Au[r0 + r] = epi.finish(Au_i, opnd[it], r0 + r);
                 }
             }
         }
@@ -195,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
                 const bool first = (row == r0 + (int)threadIdx.x);
                 const int j0 = first ? first_j0 : A_ptr[row] - base;
                 const int j1 = first ? first_j1 : A_ptr[row + 1] - base;
-                const double y = first ? first_opnd : epi.operand(row, Au);
+                const typename Epi::Opnd y = first ? first_opnd : epi.operand(row, Au);
                 // four LDS reads in flight per lane; the sum stays in column order (slots past the row add +0.0,
                 // which leaves a sum that started from +0.0 unchanged bit for bit)
                 double Au_i = 0.0;
@@ -210,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
                     Au_i += (j + 2 < j1) ? p2 : 0.0;
                     Au_i += (j + 3 < j1) ? p3 : 0.0;
                 }
-                Au[row] = epi.finish(Au_i, y);
+                Au[row] = epi.finish(Au_i, y, row);
             }
         }
     }
@@ -227,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
             double t = wsum[0];
 #pragma unroll
             for (int w = 1; w < kBlock / FDD_WAVE; w++) t += wsum[w];
-            Au[r0] = epi.apply(t, r0, Au);
+            Au[r0] = epi.finish(t, epi.operand(r0, Au), r0);
         }
     }
 }
@@ -458,6 +516,28 @@ struct fdd_csr_plan
     std::vector<int> row_blocks_host;
 };
 
+#define FDD_CSR_BLOCK(EPI, UNIT, ...)                                                          \
+    do                                                                                         \
+    {                                                                                          \
+        if (plan->block_nnz == kBlockNnzSmall)                                                 \
+            hipLaunchKernelGGL((csr_block_kernel<EPI, UNIT, kBlockNnzSmall>), __VA_ARGS__);    \
+        else                                                                                   \
+            hipLaunchKernelGGL((csr_block_kernel<EPI, UNIT, kBlockNnzMax>), __VA_ARGS__);      \
+    } while (0)
+
+template <typename Epi>
+static int plan_launch(const fdd_csr_plan *plan, double *y, const int *A_ptr, const int *A_col, const double *A_val, const double *x, const Epi &epi, void *stream)
+{
+    if (plan->kind == 0) return launch_rows(y, A_ptr, A_col, A_val, x, epi, 0, plan->num_rows, stream, plan->unit_values != 0);
+    const dim3 grid(plan->num_blocks), block(kBlock);
+    if (plan->unit_values)
+        FDD_CSR_BLOCK(Epi, true, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
+    else
+        FDD_CSR_BLOCK(Epi, false, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" {
 
 int fdd_csr_multiply(double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, int n, void *stream)
@@ -669,14 +749,6 @@ int fdd_csr_plan_kind(const fdd_csr_plan *plan, int *kind)
 }
 
 // launch csr_block_kernel for the plan's block size
-#define FDD_CSR_BLOCK(EPI, UNIT, ...)                                                          \
-    do                                                                                         \
-    {                                                                                          \
-        if (plan->block_nnz == kBlockNnzSmall)                                                 \
-            hipLaunchKernelGGL((csr_block_kernel<EPI, UNIT, kBlockNnzSmall>), __VA_ARGS__);    \
-        else                                                                                   \
-            hipLaunchKernelGGL((csr_block_kernel<EPI, UNIT, kBlockNnzMax>), __VA_ARGS__);      \
-    } while (0)
 
 int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const double *weight, void *stream)
 {
@@ -721,15 +793,36 @@ int fdd_csr_plan_matvec_to(const fdd_csr_plan *plan, double *y, const double *y_
     FDD_REQUIRE(plan != nullptr);
     if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
     FDD_REQUIRE(y != nullptr && A_ptr != nullptr && x != nullptr && y != x);
-    const EpiAxpby epi{alpha, beta, y_in};
-    if (plan->kind == 0) return launch_rows(y, A_ptr, A_col, A_val, x, epi, 0, plan->num_rows, stream, plan->unit_values != 0);
-    const dim3 grid(plan->num_blocks), block(kBlock);
-    if (plan->unit_values)
-        FDD_CSR_BLOCK(EpiAxpby, true, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
-    else
-        FDD_CSR_BLOCK(EpiAxpby, false, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
-    FDD_LAUNCH_CHECK();
-    return 0;
+    return plan_launch(plan, y, A_ptr, A_col, A_val, x, EpiAxpby{alpha, beta, y_in}, stream);
+}
+
+// The Chebyshev smoother with its element-wise kernels as SpMV epilogues (same arithmetic, statement for
+// statement, as scaled_residual / polynomial_evaluation / update_field around matvec: subdomain.tpp:19-83).
+// Sr = D*(f - A u), work = D*(coef*Sr)
+int fdd_amg_smooth_residual_matvec(const fdd_csr_plan *plan, double *work, double *Sr, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const double *f, const double *D_val, double coef, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr);
+    if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
+    FDD_REQUIRE(work != nullptr && Sr != nullptr && A_ptr != nullptr && u != nullptr && f != nullptr && D_val != nullptr && work != u && Sr != u);
+    return plan_launch(plan, work, A_ptr, A_col, A_val, u, EpiSmoothResidual{f, D_val, Sr, coef}, stream);
+}
+
+// work_out = D*(coef*Sr + D*(A work_in))
+int fdd_amg_smooth_polynomial_matvec(const fdd_csr_plan *plan, double *work_out, const int *A_ptr, const int *A_col, const double *A_val, const double *work_in, const double *Sr, const double *D_val, double coef, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr);
+    if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
+    FDD_REQUIRE(work_out != nullptr && A_ptr != nullptr && work_in != nullptr && Sr != nullptr && D_val != nullptr && work_out != work_in);
+    return plan_launch(plan, work_out, A_ptr, A_col, A_val, work_in, EpiSmoothPoly{Sr, D_val, coef}, stream);
+}
+
+// u += D*(coef*Sr + D*(A work_in))
+int fdd_amg_smooth_update_matvec(const fdd_csr_plan *plan, double *u, const int *A_ptr, const int *A_col, const double *A_val, const double *work_in, const double *Sr, const double *D_val, double coef, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr);
+    if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
+    FDD_REQUIRE(u != nullptr && A_ptr != nullptr && work_in != nullptr && Sr != nullptr && D_val != nullptr && u != work_in);
+    return plan_launch(plan, u, A_ptr, A_col, A_val, work_in, EpiSmoothUpdate{Sr, D_val, coef}, stream);
 }
 
 } // extern "C"

@@ -19,6 +19,7 @@
 #ifndef FDD_AMG_HPP
 #define FDD_AMG_HPP
 
+#include <utility>
 #include <vector>
 
 #include "config.hpp"
@@ -53,6 +54,24 @@ class Hierarchy
     {
         Level &L = levels[l];
         void *s = fdd::dev().stream;
+        if (fused_smoother and cheby_order >= 2)
+        {
+            // the same statements as below, with the element-wise kernels running as epilogues of the SpMV in front
+            // of them (bit-identical): cheby_order SpMV launches (one fewer, plus one element-wise, from u = 0) and
+            // no vector in between goes through HBM.  work and v alternate as the SpMV operand.
+            fdd::memory *in = &L.work, *out = &L.v;
+            if (u_is_zero)
+                FDD_CALL(fdd_amg_smooth_start(in->as<double>(), L.r.as<double>(), L.f.as<double>(), L.D_val.as<double>(), L.coefs[cheby_order - 1], L.n, s));
+            else
+                L.A.smooth_residual(*in, L.r, L.u, L.f, L.D_val, L.coefs[cheby_order - 1]);
+            for (int p = cheby_order - 2; p >= 1; p--)
+            {
+                L.A.smooth_polynomial(*out, *in, L.r, L.D_val, L.coefs[p]);
+                std::swap(in, out);
+            }
+            L.A.smooth_update(L.u, *in, L.r, L.D_val, L.coefs[0]);
+            return;
+        }
         // scaled_residual (:34-39): work = f - A u without the copy "work = f" in front of the SpMV; from u = 0 it is f
         if (not u_is_zero) L.A.matvec_to(L.work, L.f, L.u, -1.0, 1.0);
         FDD_CALL(fdd_amg_main_scaled_residual(L.r.as<double>(), L.w.as<double>(), (u_is_zero ? L.f : L.work).as<double>(), L.D_val.as<double>(), L.coefs[cheby_order - 1], L.n, s));
@@ -97,6 +116,7 @@ class Hierarchy
     int cheby_order = 2; // subdomain.hpp:237
     int num_vcycles = 1; // subdomain.hpp:236
     bool use_graph = true; // AMG/config.hpp:6 USE_CUDA_GRAPH
+    bool fused_smoother = true; // element-wise smoother kernels as SpMV epilogues (false: the reference's launch sequence)
     std::vector<Level> levels;
 
     bool ready() const { return finalized; }

@@ -158,6 +158,34 @@ class CSR_Matrix
         FDD_CALL(fdd_csr_plan_matvec_to(plan, y.as<double>(), y_in.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), x.as<double>(), alpha, beta, fdd::dev().stream));
     }
 
+    // --- the Chebyshev smoother's element-wise kernels as epilogues of this SpMV (subdomain.tpp:19-83) ---
+    // Sr = D*(f - A u), work = D*(coef*Sr)
+    void smooth_residual(fdd::memory &work, fdd::memory &Sr, fdd::memory &u, fdd::memory &f, fdd::memory &D, double coef)
+    {
+        if ((num_rows == 0) or (num_cols == 0)) return;
+        initialization_check();
+        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiSmoothResidual>" : "csr_block_kernel<EpiSmoothResidual>", algorithmic_bytes(true) + 16.0 * num_rows);
+        FDD_CALL(fdd_amg_smooth_residual_matvec(plan, work.as<double>(), Sr.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), u.as<double>(), f.as<double>(), D.as<double>(), coef, fdd::dev().stream));
+    }
+
+    // work_out = D*(coef*Sr + D*(A work_in))
+    void smooth_polynomial(fdd::memory &work_out, fdd::memory &work_in, fdd::memory &Sr, fdd::memory &D, double coef)
+    {
+        if ((num_rows == 0) or (num_cols == 0)) return;
+        initialization_check();
+        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiSmoothPoly>" : "csr_block_kernel<EpiSmoothPoly>", algorithmic_bytes(true) + 8.0 * num_rows);
+        FDD_CALL(fdd_amg_smooth_polynomial_matvec(plan, work_out.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), work_in.as<double>(), Sr.as<double>(), D.as<double>(), coef, fdd::dev().stream));
+    }
+
+    // u += D*(coef*Sr + D*(A work_in))
+    void smooth_update(fdd::memory &u, fdd::memory &work_in, fdd::memory &Sr, fdd::memory &D, double coef)
+    {
+        if ((num_rows == 0) or (num_cols == 0)) return;
+        initialization_check();
+        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiSmoothUpdate>" : "csr_block_kernel<EpiSmoothUpdate>", algorithmic_bytes(true) + 16.0 * num_rows);
+        FDD_CALL(fdd_amg_smooth_update_matvec(plan, u.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), work_in.as<double>(), Sr.as<double>(), D.as<double>(), coef, fdd::dev().stream));
+    }
+
   private:
     // host mirrors -> HBM + the SpMV plan
     void upload()

@@ -457,6 +457,10 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
     {
         if (p->subdomain) p->subdomain->amg_hierarchy.use_graph = value != 0;
     }
+    else if (s == "amg_fused_smoother")
+    {
+        if (p->subdomain) p->subdomain->amg_hierarchy.fused_smoother = value != 0;
+    }
     else
         return fail("unknown flag '%s'", name);
     return 0;

@@ -578,3 +578,55 @@ int fdd_csr_plan_matvec_to(const fdd_csr_plan *plan, double *y, const double *y_
     if (y_in && y_in != y && b != 0.0) memcpy(y, y_in, sizeof(double) * (size_t)plan->num_rows);
     return fdd_csr_plan_matvec(plan, y, p, c, v, x, a, b, s);
 }
+
+/* fused smoother entries: the unfused oracle pieces in sequence */
+int fdd_amg_smooth_start(double *work, double *Sr, const double *f, const double *D, double coef, int n, void *s)
+{
+    (void)s;
+    double *w = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    orc_amg_main_scaled_residual(Sr, w, f, D, coef, n);
+    orc_amg_vector_multiplication(work, D, w, n);
+    free(w);
+    return 0;
+}
+
+int fdd_amg_smooth_residual_matvec(const fdd_csr_plan *plan, double *work, double *Sr, const int *p, const int *c, const double *v, const double *u, const double *f, const double *D, double coef, void *s)
+{
+    int n = plan->num_rows;
+    double *w = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    int rc = fdd_csr_plan_matvec_to(plan, work, f, p, c, v, u, -1.0, 1.0, s);
+    orc_amg_main_scaled_residual(Sr, w, work, D, coef, n);
+    orc_amg_vector_multiplication(work, D, w, n);
+    free(w);
+    return rc;
+}
+
+static int shim_smooth_poly(const fdd_csr_plan *plan, double *w, const int *p, const int *c, const double *v, const double *work_in, const double *Sr, const double *D, double coef, void *s)
+{
+    int n = plan->num_rows;
+    double *t = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    int rc = fdd_csr_plan_matvec(plan, t, p, c, v, work_in, 1.0, 0.0, s);
+    orc_amg_main_polynomial_evaluation(w, t, Sr, D, coef, n);
+    free(t);
+    return rc;
+}
+
+int fdd_amg_smooth_polynomial_matvec(const fdd_csr_plan *plan, double *work_out, const int *p, const int *c, const double *v, const double *work_in, const double *Sr, const double *D, double coef, void *s)
+{
+    int n = plan->num_rows;
+    double *w = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    int rc = shim_smooth_poly(plan, w, p, c, v, work_in, Sr, D, coef, s);
+    orc_amg_vector_multiplication(work_out, D, w, n);
+    free(w);
+    return rc;
+}
+
+int fdd_amg_smooth_update_matvec(const fdd_csr_plan *plan, double *u, const int *p, const int *c, const double *v, const double *work_in, const double *Sr, const double *D, double coef, void *s)
+{
+    int n = plan->num_rows;
+    double *w = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    int rc = shim_smooth_poly(plan, w, p, c, v, work_in, Sr, D, coef, s);
+    orc_amg_main_update_field(u, w, D, n);
+    free(w);
+    return rc;
+}

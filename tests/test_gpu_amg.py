@@ -60,6 +60,25 @@ def test_graph_replay_equals_eager_launches(own_stream):
         assert np.array_equal(z, out[0][0])
 
 
+def test_fused_smoother_equals_reference_launch_sequence(own_stream):
+    """"amg_fused_smoother" only moves the element-wise smoother kernels into the SpMV
+    epilogues: the V-cycle result must not change in any bit."""
+    E, N, red = (4, 4, 4), 3, 2
+    out = []
+    for fused in (1, 0):
+        p = make_problem(E, N, red)
+        try:
+            p.set_flag("amg_fused_smoother", fused)
+            m = S.ArrayMesh.from_problem(p)
+            dof = p.sub_point_dofs()
+            p.amg_attach(S.low_order_hierarchy(m, dof, p.info["sub_num_dofs"]))
+            r = S.seeded_uniform(p.n, 9) - 0.5
+            out.append(p.amg_apply(r))
+        finally:
+            p.close()
+    assert np.array_equal(out[0], out[1])
+
+
 def test_errors(own_stream):
     p = make_problem((2, 2, 2), 3, 2)
     try:

@@ -1026,6 +1026,87 @@ def test_csr_plan_matvec_axpby(gpu, shape):
         lib.hip().call("fdd_csr_plan_destroy", plan)
 
 
+@pytest.mark.parametrize("shape", ["boolean", "stencil", "dense", "long_row"])
+def test_amg_smoother_fused_into_spmv(gpu, shape):
+    """The Chebyshev smoother's element-wise kernels as SpMV epilogues: bit-identical to
+    the oracle's unfused sequence matvec -> scaled_residual / polynomial_evaluation /
+    update_field -> vector_multiplication (subdomain.tpp:19-83), on every plan kind."""
+    L = S.oracle()
+    rng = np.random.default_rng(90)
+    if shape == "boolean":
+        n = 3000
+        ptr, col, _ = boolean_gather(n, n, 91)
+        val = rng.uniform(-1, 1, len(col))
+    elif shape == "stencil":
+        import scipy.sparse as sp
+
+        m = 15
+        T = sp.diags([1.0, -2.0, 1.0], [-1, 0, 1], shape=(m, m))
+        A = (sp.kron(sp.kron(T, sp.eye(m)), sp.eye(m)) + sp.kron(sp.kron(sp.eye(m), T), sp.eye(m)) + sp.kron(sp.eye(m), sp.kron(sp.eye(m), T))).tocsr()
+        A.sort_indices()
+        ptr, col, val = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+        n = m**3
+    elif shape == "dense":
+        n = 41
+        ptr = (np.arange(n + 1) * n).astype(np.int32)
+        col = np.tile(np.arange(n), n).astype(np.int32)
+        val = rng.uniform(-1, 1, n * n)
+    else:  # one row longer than a row block among short ones
+        n = 3000
+        lens = np.full(n, 3)
+        lens[1234] = 2500
+        ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        col = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for k in lens]).astype(np.int32)
+        val = rng.uniform(-1, 1, len(col))
+    u, f, D, w_in = rnd(n, 92), rnd(n, 93), rnd(n, 94) + 1.5, rnd(n, 95)
+    coef = -0.37
+    # a row longer than a block is summed by the whole workgroup (shuffle tree): same values, other order
+    same = (lambda a, b: np.allclose(a, b, rtol=1e-12, atol=1e-13)) if shape == "long_row" else np.array_equal
+    c = ctypes.c_double
+    plan = vp()
+    lib.hip().call("fdd_csr_plan_create", ctypes.byref(plan), vp(ptr.ctypes.data), n, n, len(col))
+    dp, dc, dv, dD = dev(ptr, gpu), dev(col, gpu), dev(val, gpu), dev(D, gpu)
+    try:
+        # residual: work = f - A u; Sr = D*work, w = coef*Sr; out = D*w
+        work = f.copy()
+        L.orc_amg_matvec(P(work), P(ptr), P(col), P(val), P(u), c(-1.0), c(1.0), n)
+        Sr, w, out = np.zeros(n), np.zeros(n), np.zeros(n)
+        L.orc_amg_main_scaled_residual(P(Sr), P(w), P(work), P(D), c(coef), n)
+        L.orc_amg_vector_multiplication(P(out), P(D), P(w), n)
+        dwork = torch.full((n,), float("nan"), dtype=torch.float64, device=gpu)
+        dSr = torch.full((n,), float("nan"), dtype=torch.float64, device=gpu)
+        k("fdd_amg_smooth_residual_matvec", plan, dwork, dSr, dp, dc, dv, dev(u, gpu), dev(f, gpu), dD, coef)
+        assert same(host(dSr), Sr) and same(host(dwork), out), shape
+
+        # start (u = 0): Sr = D*f, out = D*(coef*Sr)
+        Sr0, w0, out0 = np.zeros(n), np.zeros(n), np.zeros(n)
+        L.orc_amg_main_scaled_residual(P(Sr0), P(w0), P(f), P(D), c(coef), n)
+        L.orc_amg_vector_multiplication(P(out0), P(D), P(w0), n)
+        dwork0 = torch.zeros(n, dtype=torch.float64, device=gpu)
+        dSr0 = torch.zeros(n, dtype=torch.float64, device=gpu)
+        k("fdd_amg_smooth_start", dwork0, dSr0, dev(f, gpu), dD, coef, n)
+        assert same(host(dSr0), Sr0) and same(host(dwork0), out0), shape
+
+        # polynomial: v = A work_in; v *= D; w = coef*Sr + v; out = D*w
+        v = np.zeros(n)
+        L.orc_amg_matvec(P(v), P(ptr), P(col), P(val), P(w_in), c(1.0), c(0.0), n)
+        w1, out1 = np.zeros(n), np.zeros(n)
+        L.orc_amg_main_polynomial_evaluation(P(w1), P(v), P(Sr), P(D), c(coef), n)
+        L.orc_amg_vector_multiplication(P(out1), P(D), P(w1), n)
+        dout = torch.full((n,), float("nan"), dtype=torch.float64, device=gpu)
+        k("fdd_amg_smooth_polynomial_matvec", plan, dout, dp, dc, dv, dev(w_in, gpu), dev(Sr, gpu), dD, coef)
+        assert same(host(dout), out1), shape
+
+        # update: the same w, then u += D*w
+        u2 = u.copy()
+        L.orc_amg_main_update_field(P(u2), P(w1), P(D), n)
+        du = dev(u, gpu)
+        k("fdd_amg_smooth_update_matvec", plan, du, dp, dc, dv, dev(w_in, gpu), dev(Sr, gpu), dD, coef)
+        assert same(host(du), u2), shape
+    finally:
+        lib.hip().call("fdd_csr_plan_destroy", plan)
+
+
 def test_graph_capture_and_replay(gpu):
     """fdd_graph_*: a captured launch sequence replays with the same result;
     the default stream is refused (it cannot be captured)."""
