@@ -70,6 +70,7 @@ enum
     FDDH_INFO_SUB_NUM_VALUES,
     FDDH_INFO_SUB_NUM_DOFS,
     FDDH_INFO_NUM_ITERATIONS,
+    FDDH_INFO_DIM, /* 2 or 3: set by the mesh (domain.tpp:47) */
     FDDH_INFO_COUNT
 };
 int fddh_problem_info(const fddh_problem *p, long long *info, int n);

@@ -319,6 +319,7 @@ int fddh_problem_info(const fddh_problem *p, long long *info, int n)
     v[FDDH_INFO_SUB_NUM_VALUES] = p->subdomain ? p->subdomain->num_values : 0;
     v[FDDH_INFO_SUB_NUM_DOFS] = p->subdomain ? p->subdomain->dofs() : 0;
     v[FDDH_INFO_NUM_ITERATIONS] = d.num_iterations;
+    v[FDDH_INFO_DIM] = d.mesh.dim;
     for (int i = 0; i < n && i < FDDH_INFO_COUNT; i++) info[i] = v[i];
     return 0;
 }

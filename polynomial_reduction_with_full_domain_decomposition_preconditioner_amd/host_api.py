@@ -25,6 +25,7 @@ INFO_NAMES = [
     "sub_num_values",
     "sub_num_dofs",
     "num_iterations",
+    "dim",
 ]
 
 _ALLREDUCE = ctypes.CFUNCTYPE(ctypes.c_int, vp, vp, ctypes.c_longlong)
@@ -212,7 +213,9 @@ class Problem:
 
     def mesh_array(self, name, level=0):
         deg = self.level_degree(level)
-        npts = self.info["num_local_elements"] * (deg + 1) ** 3
+        npts = self.info["num_local_elements"] * (deg + 1) ** self.info["dim"]
+        if name == "z" and self.info["dim"] == 2:
+            return np.zeros(npts)  # a 2-D mesh has no z file (domain.tpp:121-138)
         dtype = {"glo_num": np.int64, "node_degree": np.int32}.get(name, np.float64)
         out = np.zeros(npts, dtype)
         _H().call("fddh_problem_mesh_array", self.h, level, name.encode(), _dp(out), out.nbytes)

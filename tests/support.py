@@ -228,7 +228,7 @@ class BoxMesh:
 
     def orc_mesh(self):
         m = OrcMesh()
-        m.dim = 3
+        m.dim = getattr(self, "dim", 3)
         m.poly_degree = self.N
         m.num_local_elements = self.num_local_elements
         m.x, m.y, m.z = _p(self.x), _p(self.y), _p(self.z)
@@ -244,10 +244,11 @@ class ArrayMesh(BoxMesh):
     """A mesh given by its arrays (e.g. the ones the C++ host layer generated,
     so that oracle and product see bit-identical geometric factors)."""
 
-    def __init__(self, N, num_local_elements, arrays):
+    def __init__(self, N, num_local_elements, arrays, dim=3):
         self.N = N
+        self.dim = dim
         self.num_local_elements = num_local_elements
-        self.num_elem_points = (N + 1) ** 3
+        self.num_elem_points = (N + 1) ** dim
         self.num_local_points = num_local_elements * self.num_elem_points
         self.x, self.y, self.z = arrays["x"], arrays["y"], arrays["z"]
         self.glo_num = arrays["glo_num"]
@@ -259,7 +260,7 @@ class ArrayMesh(BoxMesh):
     def from_problem(cls, problem, level=0):
         names = ["x", "y", "z", "glo_num", "node_degree", "p_mask"] + [f"g_{k + 1}" for k in range(6)]
         arrays = {n: problem.mesh_array(n, level) for n in names}
-        return cls(problem.level_degree(level), problem.info["num_local_elements"], arrays)
+        return cls(problem.level_degree(level), problem.info["num_local_elements"], arrays, problem.info.get("dim", 3))
 
 
 def rank_grid(num_ranks):
@@ -598,21 +599,82 @@ class DeformedMesh(BoxMesh):
         self.g = [np.ascontiguousarray((sc * M[..., a, b]).reshape(-1)) for a, b in pairs]
 
 
+class QuadMesh(BoxMesh):
+    """2-D counterpart of BoxMesh / DeformedMesh (the reference's `dim == 2` branches): unit square, E = (Ex, Ey)
+    quadrilaterals of degree N, optionally deformed by x -> x + a*s*(1, -0.7), s = sin(pi x) sin(pi y).  Geometric
+    factors in the 2-D layout of domain.okl:29-30, g_1 = G_rr, g_2 = G_ss, g_3 = G_rs (g_4..g_6 are read by
+    Domain::initialize but unused), G = w_i w_j |J| J^-1 J^-T with J from the GLL differentiation matrix."""
+
+    dim = 2
+
+    def __init__(self, E, N, amplitude=0.0):
+        Ex, Ey = E
+        self.E, self.N, self.P, self.rank = (Ex, Ey, 1), N, (1, 1, 1), 0
+        n = N + 1
+        z, w, D = gll(N)
+        D = np.asarray(D).reshape(n, n)
+        ne = Ex * Ey
+        self.local_E = (Ex, Ey, 1)
+        self.origin = (0, 0, 0)
+        self.num_local_elements = ne
+        self.num_elem_points = n * n
+        self.num_local_points = ne * n * n
+        Gx, Gy = Ex * N + 1, Ey * N + 1
+        self.global_nodes = Gx * Gy
+        EY, EX = np.meshgrid(np.arange(Ey), np.arange(Ex), indexing="ij")
+        EX, EY = EX.reshape(-1), EY.reshape(-1)
+        j, i = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+        i, j = i.reshape(-1), j.reshape(-1)  # x fastest
+        gi = EX[:, None] * N + i[None, :]
+        gj = EY[:, None] * N + j[None, :]
+        self.glo_num = (1 + gi + Gx * gj).astype(np.int64).reshape(-1)
+
+        def mult(g, G):
+            m = np.ones_like(g)
+            m[(g % N == 0) & (g > 0) & (g < G - 1)] = 2
+            return m
+
+        self.node_degree = (mult(gi, Gx) * mult(gj, Gy)).astype(np.int32).reshape(-1)
+        on_bdry = (gi == 0) | (gi == Gx - 1) | (gj == 0) | (gj == Gy - 1)
+        self.p_mask = np.where(on_bdry, 0.0, 1.0).reshape(-1)
+        xi = 0.5 * (z + 1.0)
+        x = ((EX[:, None] + xi[i][None, :]) / Ex).reshape(-1)
+        y = ((EY[:, None] + xi[j][None, :]) / Ey).reshape(-1)
+        s_ = np.sin(np.pi * x) * np.sin(np.pi * y)
+        X = [x + amplitude * s_, y - 0.7 * amplitude * s_]
+        self.x, self.y = [np.ascontiguousarray(c) for c in X]
+        self.z = np.zeros_like(self.x)
+        J = np.zeros((ne, n, n, 2, 2))
+        for a, c in enumerate(X):
+            c = c.reshape(ne, n, n)  # [e, j, i]
+            J[..., a, 0] = np.einsum("ip,ejp->eji", D, c)
+            J[..., a, 1] = np.einsum("jp,epi->eji", D, c)
+        det = np.linalg.det(J)
+        assert (det > 0).all()
+        Ji = np.linalg.inv(J)
+        M = np.einsum("...ab,...cb->...ac", Ji, Ji)
+        sc = (w[None, :, None] * w[None, None, :]) * det
+        zero = np.zeros(self.num_local_points)
+        self.g = [np.ascontiguousarray((sc * M[..., a, b]).reshape(-1)) for a, b in ((0, 0), (1, 1), (0, 1))] + [zero, zero.copy(), zero.copy()]
+
+
 def write_mesh_files(directory, mesh, proc_id=0):
     """The reference's per-rank input files (domain.tpp:45-224): lx1_<N+1>/{size,x,y,z,glo_num,node_degree,p_mask,g_1..g_6}_<rank>.<N>.dat"""
     N = mesh.N
     d = os.path.join(directory, "lx1_%d" % (N + 1))
     os.makedirs(d, exist_ok=True)
     n = N + 1
+    dim = getattr(mesh, "dim", 3)
     with open(os.path.join(d, "size_%d.%d.dat" % (proc_id, N)), "w") as fh:
-        fh.write("3 %d %d %d %d\n" % (n, n, n, mesh.num_local_elements))
+        fh.write("%d %d %d %d %d\n" % (dim, n, n, n if dim == 3 else 1, mesh.num_local_elements))
 
     def put(stem, arr, dtype):
         np.ascontiguousarray(arr, dtype=dtype).tofile(os.path.join(d, "%s_%d.%d.dat" % (stem, proc_id, N)))
 
     put("x", mesh.x, np.float64)
     put("y", mesh.y, np.float64)
-    put("z", mesh.z, np.float64)
+    if dim == 3:
+        put("z", mesh.z, np.float64)  # domain.tpp:121-138: no z file in 2-D
     put("glo_num", mesh.glo_num, np.int64)
     put("node_degree", mesh.node_degree, np.int32)
     put("p_mask", mesh.p_mask, np.float64)

@@ -149,3 +149,21 @@ print("ok", its)
 """ % (S.ROOT, S.HERE, HOST_CPU_SO)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_host_layer_two_dimensional_solve_on_cpu_shim(tmp_path):
+    """Domain / Subdomain host logic on a 2-D mesh read from the reference's files (dim2_checks.py)."""
+    subprocess.check_call(["make", "-C", S.ORACLE_DIR, "-s"])
+    subprocess.check_call(["make", "-C", SHIM_DIR, "-s"])
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import support as S, dim2_checks
+from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H, lib
+lib._host = lib._Lib(%r, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
+H.init(0, use_torch_stream=False); H.comm_single(); H.set_print(False)
+its = dim2_checks.check_two_dimensional_solve(H, %r)
+print("ok", its)
+""" % (S.ROOT, S.HERE, HOST_CPU_SO, str(tmp_path / "quad"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

@@ -378,3 +378,11 @@ def test_curved_mesh_from_files(setup, tmp_path):
         sd.close()
         W.close()
         p.close()
+
+
+def test_two_dimensional_mesh_from_files(setup, tmp_path):
+    """The `dim == 2` branches of Domain / Subdomain and their kernels, end to end (dim2_checks.py)."""
+    import dim2_checks
+
+    its = dim2_checks.check_two_dimensional_solve(H, str(tmp_path / "quad"))
+    assert 0 < its < 40
