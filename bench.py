@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-precond", action="store_true")
     ap.add_argument("--amg", action="store_true", help="inner solve preconditioned by the low-order AMG V-cycle (config C5's preconditioner; hierarchy built by the host layer)")
     ap.add_argument("--no-amg-fusion", action="store_true", help="with --amg: the smoother's element-wise kernels as separate launches (the reference's sequence) instead of SpMV epilogues")
+    ap.add_argument("--amg-precision", type=int, choices=[64, 32], default=64, help="with --amg: the reference's `Float` (AMG/config.hpp:4): V-cycle in double (default) or float")
     ap.add_argument("--no-amg-graph", action="store_true", help="with --amg: launch the V-cycle kernel by kernel (so that --kernel-table shows them) instead of replaying its hipGraph")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N>1 ranks all on cuda:0 with a gloo group staging device buffers over the host: exercises the multi-rank code path on a one-GPU box (not a measurement)")
     ap.add_argument("--kernel-table", action="store_true", help="time every instrumented kernel family in the timed region (fills `kernels`; costs ~8 %% of a step)")
@@ -177,6 +178,8 @@ def main():
             prob.set_flag("amg_graph", 0)
         if args.no_amg_fusion:
             prob.set_flag("amg_fused_smoother", 0)
+        if args.amg_precision != 64:
+            prob.set_flag("amg_precision", args.amg_precision)
     t_setup = time.perf_counter() - t_setup
 
     def max_over_ranks(x):
@@ -272,7 +275,7 @@ def main():
             "poly_degree": N,
             "points_per_gpu": info["num_local_points"],
             "unique_nodes": nodes,
-            "preconditioner": "none" if args.no_precond else ("fdd_gmres4+amg_vcycle(%d levels)" % amg_levels if amg_levels else "fdd_gmres4"),
+            "preconditioner": "none" if args.no_precond else ("fdd_gmres4+amg_vcycle(%d levels, f%d)" % (amg_levels, args.amg_precision) if amg_levels else "fdd_gmres4"),
             "comm": "single" if world == 1 else ("gloo-staged rehearsal on one GPU" if args.rehearse_on_one_gpu else args.comm),
         },
         "points_updates_per_s": info["num_local_points"] * world * args.steps / dt,

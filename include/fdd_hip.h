@@ -209,6 +209,17 @@ int fdd_amg_smooth_residual_matvec(const fdd_csr_plan *plan, double *work, doubl
 int fdd_amg_smooth_polynomial_matvec(const fdd_csr_plan *plan, double *work_out, const int *A_ptr, const int *A_col, const double *A_val, const double *work_in, const double *Sr, const double *D_val, double coef, void *stream);
 int fdd_amg_smooth_update_matvec(const fdd_csr_plan *plan, double *u, const int *A_ptr, const int *A_col, const double *A_val, const double *work_in, const double *Sr, const double *D_val, double coef, void *stream);
 int fdd_amg_smooth_start(double *work, double *Sr, const double *f, const double *D_val, double coef, int size, void *stream);
+/* Float = float (AMG/config.hpp:4, run.py:157): the V-cycle on f32 values and vectors.  Only the fused sequence is
+ * provided (SpMV + fused smoother + set/start); casts at the V-cycle's ends: fdd_sub_copy_f32_f64 / _f64_f32.
+ * Plans for these entries come from fdd_csr_plan_create_f32 (row blocks whatever the row lengths); the fp64
+ * entries refuse such a plan and these refuse an fp64 one. */
+int fdd_csr_plan_create_f32(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows, int num_cols, int num_nnz);
+int fdd_csr_plan_matvec_to_f32(const fdd_csr_plan *plan, float *y, const float *y_in, const int *A_ptr, const int *A_col, const float *A_val, const float *x, float alpha, float beta, void *stream);
+int fdd_amg_smooth_residual_matvec_f32(const fdd_csr_plan *plan, float *work, float *Sr, const int *A_ptr, const int *A_col, const float *A_val, const float *u, const float *f, const float *D_val, float coef, void *stream);
+int fdd_amg_smooth_polynomial_matvec_f32(const fdd_csr_plan *plan, float *work_out, const int *A_ptr, const int *A_col, const float *A_val, const float *work_in, const float *Sr, const float *D_val, float coef, void *stream);
+int fdd_amg_smooth_update_matvec_f32(const fdd_csr_plan *plan, float *u, const int *A_ptr, const int *A_col, const float *A_val, const float *work_in, const float *Sr, const float *D_val, float coef, void *stream);
+int fdd_amg_smooth_start_f32(float *work, float *Sr, const float *f, const float *D_val, float coef, int size, void *stream);
+int fdd_amg_vector_set_to_value_f32(float *data, float value, int size, void *stream);
 /* cublasDdot replacement (AMG/vector.cpp:100,129): out[0] = sum x*y */
 int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int size, void *stream);
 

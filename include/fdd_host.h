@@ -113,7 +113,8 @@ int fddh_problem_set_options(fddh_problem *p, int max_iterations, double toleran
  *   "sub_use_preconditioner"   1: the inner solver preconditions with the low-order AMG V-cycle
  *                              (Subdomain::use_preconditioner, subdomain.hpp:231; needs fddh_problem_amg_*), 0: dssum (default)
  *   "amg_graph"                1: the V-cycle is replayed as one hipGraph when the stream allows capture (default)
- *   "amg_fused_smoother"       1: the smoother's element-wise kernels run as SpMV epilogues, bit-identical (default); 0: the reference's launch sequence */
+ *   "amg_fused_smoother"       1: the smoother's element-wise kernels run as SpMV epilogues, bit-identical (default); 0: the reference's launch sequence 
+ *   "amg_precision"            64 (default) or 32: the reference's `Float` (AMG/config.hpp:4): the V-cycle in double or in float */
 int fddh_problem_set_flag(fddh_problem *p, const char *name, int value);
 
 /* Low-order AMG preconditioner of the inner solve (Subdomain::low_order_preconditioner,

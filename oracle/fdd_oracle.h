@@ -229,6 +229,13 @@ void orc_subdomain_attach_amg(orc_subdomain *s, orc_amg *amg);
 void orc_subdomain_point_dofs(const orc_subdomain *s, int *dof);
 void orc_subdomain_low_order_preconditioner(orc_subdomain *s, double *z, const double *r);
 
+/* the same V-cycle with Float = float (AMG/config.hpp:4; fdd_oracle_amg_f32.c): arrays given in double are rounded */
+typedef struct orc_amg32 orc_amg32;
+orc_amg32 *orc_amg32_create(int num_levels, int cheby_order, int num_vcycles);
+void orc_amg32_set_level(orc_amg32 *a, int l, int n, const int *A_ptr, const int *A_col, const double *A_val, const double *D_val, const double *coefs, int n_coarse, const int *P_ptr, const int *P_col, const double *P_val);
+void orc_amg32_destroy(orc_amg32 *a);
+void orc_amg32_vcycle(orc_amg32 *a, double *u0, const double *f0);
+
 #ifdef __cplusplus
 }
 #endif

@@ -428,6 +428,37 @@ struct SmoothStartOp // scaled_residual from u = 0 (f - A u is f) followed by ve
     }
 };
 
+// ---- Float = float (AMG/config.hpp:4): the two element-wise kernels the fused f32 V-cycle launches ----
+struct SetF32Op // AMG/kernels.cu:11-23
+{
+    float *data;
+    float value;
+    __device__ void vec2(long long i) const { reinterpret_cast<float2 *>(data)[i] = make_float2(value, value); }
+    __device__ void one(long long i) const { data[i] = value; }
+};
+
+struct SmoothStartF32Op // SmoothStartOp in f32
+{
+    float *work;
+    float *Sr;
+    const float *f;
+    const float *S;
+    float alpha;
+    __device__ void vec2(long long i) const
+    {
+        const float2 s = reinterpret_cast<const float2 *>(S)[i], r = reinterpret_cast<const float2 *>(f)[i];
+        const float2 sr = make_float2(s.x * r.x, s.y * r.y);
+        reinterpret_cast<float2 *>(Sr)[i] = sr;
+        reinterpret_cast<float2 *>(work)[i] = make_float2(s.x * (alpha * sr.x), s.y * (alpha * sr.y));
+    }
+    __device__ void one(long long i) const
+    {
+        const float sr = S[i] * f[i];
+        Sr[i] = sr;
+        work[i] = S[i] * (alpha * sr);
+    }
+};
+
 struct PolyEvalOp // AMG/kernels.cu:43-59
 {
     double *w;
@@ -718,6 +749,23 @@ int fdd_amg_smooth_start(double *work, double *Sr, const double *f, const double
     FDD_REQUIRE(work != nullptr && Sr != nullptr && f != nullptr && D_val != nullptr);
     bool al = fdd_aligned16(work) && fdd_aligned16(Sr) && fdd_aligned16(f) && fdd_aligned16(D_val);
     return launch_ew(SmoothStartOp{work, Sr, f, D_val, coef}, size, al, stream);
+}
+
+int fdd_amg_vector_set_to_value_f32(float *data, float value, int size, void *stream)
+{
+    FDD_REQUIRE(size >= 0);
+    if (size == 0) return 0;
+    FDD_REQUIRE(data != nullptr);
+    return launch_ew(SetF32Op{data, value}, size, fdd_aligned16(data), stream);
+}
+
+int fdd_amg_smooth_start_f32(float *work, float *Sr, const float *f, const float *D_val, float coef, int size, void *stream)
+{
+    FDD_REQUIRE(size >= 0);
+    if (size == 0) return 0;
+    FDD_REQUIRE(work != nullptr && Sr != nullptr && f != nullptr && D_val != nullptr);
+    bool al = fdd_aligned16(work) && fdd_aligned16(Sr) && fdd_aligned16(f) && fdd_aligned16(D_val);
+    return launch_ew(SmoothStartF32Op{work, Sr, f, D_val, coef}, size, al, stream);
 }
 
 int fdd_amg_main_polynomial_evaluation(double *w, double *v, const double *r, const double *D_val, double alpha, int size, void *stream)

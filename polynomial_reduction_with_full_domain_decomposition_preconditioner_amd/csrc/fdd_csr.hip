@@ -50,72 +50,82 @@ struct EpiWeight
     __device__ double operand(int row, const double *) const { return weight[row]; }
     __device__ double finish(double s, double w, int) const { return s * w; }
 };
-struct EpiAxpby // AMG/csr_matrix.cpp:112-134
+template <typename T>
+struct EpiAxpbyT // AMG/csr_matrix.cpp:112-134
 {
-    typedef double Opnd;
-    double alpha, beta;
-    const double *y_in; // optional: y = alpha*A*x + beta*y_in with y_in another vector (f - A u without copying f first)
+    typedef T Opnd;
+    T alpha, beta;
+    const T *y_in; // optional: y = alpha*A*x + beta*y_in with y_in another vector (f - A u without copying f first)
     // beta == 0: y is output only (cusparseSpMV semantics), whatever it held is not read
-    __device__ double operand(int row, const double *y_old) const { return (beta == 0.0) ? 0.0 : (y_in ? y_in[row] : y_old[row]); }
-    __device__ double finish(double s, double y, int) const { return (beta == 0.0) ? alpha * s : alpha * s + beta * y; }
+    __device__ T operand(int row, const T *y_old) const { return (beta == T(0)) ? T(0) : (y_in ? y_in[row] : y_old[row]); }
+    __device__ T finish(T s, T y, int) const { return (beta == T(0)) ? alpha * s : alpha * s + beta * y; }
 };
+typedef EpiAxpbyT<double> EpiAxpby;
 
 // The Chebyshev smoother's element-wise kernels (subdomain.tpp:19-83, AMG/kernels.cu:25-94) as epilogues of the
 // SpMV in front of them: the same products and sums in the same order (the statements of the unfused kernels are
 // quoted), without the vectors in between going through HBM.
+template <typename T>
 struct Opnd2
 {
-    double a, b;
+    T a, b;
 };
+template <typename T>
 struct Opnd3
 {
-    double a, b, c;
+    T a, b, c;
 };
 // work = f - A u (matvec -1, 1) | Sr = S*work; w = alpha*Sr (scaled_residual) | out = D*w (vector_multiplication)
-struct EpiSmoothResidual
+template <typename T>
+struct EpiSmoothResidualT
 {
-    typedef Opnd2 Opnd;
-    const double *f, *D;
-    double *r; // Sr
-    double coef;
-    __device__ Opnd2 operand(int row, const double *) const { return Opnd2{f[row], D[row]}; }
-    __device__ double finish(double s, Opnd2 o, int row) const
+    typedef Opnd2<T> Opnd;
+    const T *f, *D;
+    T *r; // Sr
+    T coef;
+    __device__ Opnd operand(int row, const T *) const { return Opnd{f[row], D[row]}; }
+    __device__ T finish(T s, Opnd o, int row) const
     {
-        const double work = -1.0 * s + 1.0 * o.a;
-        const double sr = o.b * work;
+        const T work = T(-1) * s + T(1) * o.a;
+        const T sr = o.b * work;
         r[row] = sr;
-        const double w = coef * sr;
+        const T w = coef * sr;
         return w * o.b;
     }
 };
 // v = A work (matvec 1, 0) | v *= D; w = alpha*r + v (polynomial_evaluation) | out = D*w (vector_multiplication)
-struct EpiSmoothPoly
+template <typename T>
+struct EpiSmoothPolyT
 {
-    typedef Opnd2 Opnd;
-    const double *r, *D;
-    double coef;
-    __device__ Opnd2 operand(int row, const double *) const { return Opnd2{r[row], D[row]}; }
-    __device__ double finish(double s, Opnd2 o, int) const
+    typedef Opnd2<T> Opnd;
+    const T *r, *D;
+    T coef;
+    __device__ Opnd operand(int row, const T *) const { return Opnd{r[row], D[row]}; }
+    __device__ T finish(T s, Opnd o, int) const
     {
-        const double v = (1.0 * s) * o.b;
-        const double w = coef * o.a + v;
+        const T v = (T(1) * s) * o.b;
+        const T w = coef * o.a + v;
         return w * o.b;
     }
 };
 // v = A work | v *= D; w = alpha*r + v (polynomial_evaluation) | u += D*w (update_field): the output vector is u
-struct EpiSmoothUpdate
+template <typename T>
+struct EpiSmoothUpdateT
 {
-    typedef Opnd3 Opnd;
-    const double *r, *D;
-    double coef;
-    __device__ Opnd3 operand(int row, const double *u_old) const { return Opnd3{r[row], D[row], u_old[row]}; }
-    __device__ double finish(double s, Opnd3 o, int) const
+    typedef Opnd3<T> Opnd;
+    const T *r, *D;
+    T coef;
+    __device__ Opnd operand(int row, const T *u_old) const { return Opnd{r[row], D[row], u_old[row]}; }
+    __device__ T finish(T s, Opnd o, int) const
     {
-        const double v = (1.0 * s) * o.b;
-        const double w = coef * o.a + v;
+        const T v = (T(1) * s) * o.b;
+        const T w = coef * o.a + v;
         return o.c + o.b * w;
     }
 };
+typedef EpiSmoothResidualT<double> EpiSmoothResidual;
+typedef EpiSmoothPolyT<double> EpiSmoothPoly;
+typedef EpiSmoothUpdateT<double> EpiSmoothUpdate;
 
 // Lane-per-row SpMV.  Each lane owns NPT rows (strided by the workgroup size,
 // so every access stays coalesced across lanes) and keeps the column loads,
@@ -149,17 +159,25 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-template <typename Epi, bool UNIT, int kBlockNnz>
-__global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ Au, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const double *__restrict__ A_val, const double *__restrict__ u, Epi epi, const int *__restrict__ row_blocks, int xcd_chunked)
+__device__ __forceinline__ float wave_sum(float v)
 {
-    __shared__ double prod[kBlockNnz];
+#pragma unroll
+    for (int off = FDD_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, FDD_WAVE);
+    return v;
+}
+
+// T: the value type of the matrix and of both vectors (double everywhere except the Float = float V-cycle, AMG/config.hpp:4)
+template <typename T, typename Epi, bool UNIT, int kBlockNnz>
+__global__ __launch_bounds__(kBlock) void csr_block_kernel(T *__restrict__ Au, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const T *__restrict__ A_val, const T *__restrict__ u, Epi epi, const int *__restrict__ row_blocks, int xcd_chunked)
+{
+    __shared__ T prod[kBlockNnz];
     // Matrices with short rows (the small block size) have hundreds of rows per block: their row pointers and
     // epilogue operands are loaded up front with everything else and staged in LDS.  With wide rows a block has
     // few rows and the extra LDS would only cost occupancy (27-point stencil: 757 -> 905 us): those read them
     // in the row loop.
     constexpr bool kStageRows = (kBlockNnz == kBlockNnzSmall);
     __shared__ int sp[kStageRows ? kBlockNnz + 1 : 1];
-    __shared__ double wsum[kBlock / FDD_WAVE];
+    __shared__ T wsum[kBlock / FDD_WAVE];
 
     // Row blocks in plain dispatch order by default: the val/col streams of the 8 XCDs then advance through
     // adjacent memory.  XCD-chunked order (FDD_TUNE_CSR_XCD=1) does cut the 27-point stencil's L2 fetch traffic
@@ -180,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
         constexpr int kRowIts = kBlockNnz / kBlock; // a block has at most as many rows as non-zeros (the plan)
         const int nrows = r1 - r0;
         int c[kIts], rp[kRowIts];
-        double a[kIts];
+        T a[kIts];
         typename Epi::Opnd opnd[kRowIts];
 #pragma unroll
         for (int it = 0; it < kIts; it++)
@@ -191,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
             // short-row matrices: the matrix streams are read once per launch and x keeps the L2 (Qt at C2: 91 -> 79 us);
             // the 27-point stencil measured 2 % slower that way
             c[it] = kStageRows ? __builtin_nontemporal_load(A_col + base + ks) : A_col[base + ks];
-            a[it] = UNIT ? 1.0 : (kStageRows ? __builtin_nontemporal_load(A_val + base + ks) : A_val[base + ks]);
+            a[it] = UNIT ? T(1) : (kStageRows ? __builtin_nontemporal_load(A_val + base + ks) : A_val[base + ks]);
         }
         if (kStageRows)
         {
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
         for (int it = 0; it < kIts; it++)
         {
             const int k = threadIdx.x + it * kBlock;
-            const double x = u[c[it]];
+            const T x = u[c[it]];
             if (k < nnz) prod[k] = a[it] * x;
         }
         if (kStageRows)
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
                 if (r < nrows)
                 {
                     const int j0 = sp[r], j1 = sp[r + 1];
-                    double Au_i = 0.0;
+                    T Au_i = T(0);
                     for (int j = j0; j < j1; j++) Au_i += prod[j];
                     Au[r0 + r] = epi.finish(Au_i, opnd[it], r0 + r);
                 }
@@ -256,17 +274,17 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
                 const typename Epi::Opnd y = first ? first_opnd : epi.operand(row, Au);
                 // four LDS reads in flight per lane; the sum stays in column order (slots past the row add +0.0,
                 // which leaves a sum that started from +0.0 unchanged bit for bit)
-                double Au_i = 0.0;
+                T Au_i = T(0);
                 for (int j = j0; j < j1; j += 4)
                 {
-                    const double p0 = prod[j];
-                    const double p1 = prod[(j + 1 < kBlockNnz) ? j + 1 : j];
-                    const double p2 = prod[(j + 2 < kBlockNnz) ? j + 2 : j];
-                    const double p3 = prod[(j + 3 < kBlockNnz) ? j + 3 : j];
+                    const T p0 = prod[j];
+                    const T p1 = prod[(j + 1 < kBlockNnz) ? j + 1 : j];
+                    const T p2 = prod[(j + 2 < kBlockNnz) ? j + 2 : j];
+                    const T p3 = prod[(j + 3 < kBlockNnz) ? j + 3 : j];
                     Au_i += p0;
-                    Au_i += (j + 1 < j1) ? p1 : 0.0;
-                    Au_i += (j + 2 < j1) ? p2 : 0.0;
-                    Au_i += (j + 3 < j1) ? p3 : 0.0;
+                    Au_i += (j + 1 < j1) ? p1 : T(0);
+                    Au_i += (j + 2 < j1) ? p2 : T(0);
+                    Au_i += (j + 3 < j1) ? p3 : T(0);
                 }
                 Au[row] = epi.finish(Au_i, y, row);
             }
@@ -275,14 +293,14 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(double *__restrict__ 
     else
     {
         // a single long row (the plan guarantees r1 == r0 + 1)
-        double s = 0.0;
-        for (int k = threadIdx.x; k < nnz; k += kBlock) s += (UNIT ? 1.0 : A_val[base + k]) * u[A_col[base + k]];
+        T s = T(0);
+        for (int k = threadIdx.x; k < nnz; k += kBlock) s += (UNIT ? T(1) : A_val[base + k]) * u[A_col[base + k]];
         s = wave_sum(s);
         if ((threadIdx.x & (FDD_WAVE - 1)) == 0) wsum[threadIdx.x / FDD_WAVE] = s;
         __syncthreads();
         if (threadIdx.x == 0)
         {
-            double t = wsum[0];
+            T t = wsum[0];
 #pragma unroll
             for (int w = 1; w < kBlock / FDD_WAVE; w++) t += wsum[w];
             Au[r0] = epi.finish(t, epi.operand(r0, Au), r0);
@@ -511,6 +529,7 @@ struct fdd_csr_plan
     int has_long_rows; // some row exceeds a block (workgroup-reduced in SpMV)
     int block_nnz;     // kBlockNnzSmall or kBlockNnzMax: non-zeros (and rows) per row block
     int xcd_chunked;   // SpMV row blocks in XCD-chunked order
+    int value_bytes;   // 8: the fp64 entries; 4: a plan of the f32 entries (always row blocks; twice the non-zeros per block measured no faster)
     int num_blocks;
     int *row_blocks_dev; // num_blocks + 1
     std::vector<int> row_blocks_host;
@@ -520,14 +539,19 @@ struct fdd_csr_plan
     do                                                                                         \
     {                                                                                          \
         if (plan->block_nnz == kBlockNnzSmall)                                                 \
-            hipLaunchKernelGGL((csr_block_kernel<EPI, UNIT, kBlockNnzSmall>), __VA_ARGS__);    \
+            hipLaunchKernelGGL((csr_block_kernel<double, EPI, UNIT, kBlockNnzSmall>), __VA_ARGS__);    \
         else                                                                                   \
-            hipLaunchKernelGGL((csr_block_kernel<EPI, UNIT, kBlockNnzMax>), __VA_ARGS__);      \
+            hipLaunchKernelGGL((csr_block_kernel<double, EPI, UNIT, kBlockNnzMax>), __VA_ARGS__);      \
     } while (0)
 
 template <typename Epi>
 static int plan_launch(const fdd_csr_plan *plan, double *y, const int *A_ptr, const int *A_col, const double *A_val, const double *x, const Epi &epi, void *stream)
 {
+    if (plan->value_bytes != 8)
+    {
+        fdd_set_error("fp64 SpMV on a plan of fdd_csr_plan_create_f32");
+        return 1;
+    }
     if (plan->kind == 0) return launch_rows(y, A_ptr, A_col, A_val, x, epi, 0, plan->num_rows, stream, plan->unit_values != 0);
     const dim3 grid(plan->num_blocks), block(kBlock);
     if (plan->unit_values)
@@ -537,6 +561,26 @@ static int plan_launch(const fdd_csr_plan *plan, double *y, const int *A_ptr, co
     FDD_LAUNCH_CHECK();
     return 0;
 }
+
+// the Float = float V-cycle (AMG/config.hpp:4): row-block plans only (fdd_csr_plan_create_blocked)
+template <typename Epi>
+static int plan_launch_f32(const fdd_csr_plan *plan, float *y, const int *A_ptr, const int *A_col, const float *A_val, const float *x, const Epi &epi, void *stream)
+{
+    if (plan->kind != 1 || plan->value_bytes != 4)
+    {
+        fdd_set_error("f32 SpMV: not a plan of fdd_csr_plan_create_f32");
+        return 1;
+    }
+    const dim3 grid(plan->num_blocks), block(kBlock);
+    if (plan->block_nnz == kBlockNnzSmall)
+        hipLaunchKernelGGL((csr_block_kernel<float, Epi, false, kBlockNnzSmall>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
+    else
+        hipLaunchKernelGGL((csr_block_kernel<float, Epi, false, kBlockNnzMax>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+static int plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows, int num_cols, int num_nnz, bool f32);
 
 extern "C" {
 
@@ -572,7 +616,14 @@ int fdd_amg_matvec(double *y, const int *ptr, const int *col, const double *val,
     return launch_rows(y, ptr, col, val, x, EpiAxpby{alpha, beta, nullptr}, 0, num_rows, stream);
 }
 
-int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows, int num_cols, int num_nnz)
+int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows, int num_cols, int num_nnz) { return plan_create(plan, A_ptr_host, num_rows, num_cols, num_nnz, false); }
+
+/* a plan for the f32 entries: row blocks whatever the row lengths (no lane-per-row form there) */
+int fdd_csr_plan_create_f32(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows, int num_cols, int num_nnz) { return plan_create(plan, A_ptr_host, num_rows, num_cols, num_nnz, true); }
+
+} // extern "C"
+
+static int plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows, int num_cols, int num_nnz, bool f32)
 {
     FDD_REQUIRE(plan != nullptr && num_rows >= 0 && num_cols >= 0 && num_nnz >= 0);
     FDD_REQUIRE(num_rows == 0 || A_ptr_host != nullptr);
@@ -587,6 +638,7 @@ int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows
     p->has_long_rows = 0;
     p->block_nnz = ((double)num_nnz < 4.0 * (double)num_rows) ? kBlockNnzSmall : kBlockNnzMax;
     if (const char *e = getenv("FDD_TUNE_CSR_BLOCK_NNZ")) p->block_nnz = (atoi(e) <= kBlockNnzSmall) ? kBlockNnzSmall : kBlockNnzMax;
+    p->value_bytes = f32 ? 4 : 8;
     p->xcd_chunked = fdd_env_int("FDD_TUNE_CSR_XCD", 0);
     p->num_blocks = 0;
     p->row_blocks_dev = nullptr;
@@ -597,7 +649,7 @@ int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows
     // through LDS row staging.  FDD_TUNE_CSR_ROW_BLOCK_THRESHOLD overrides (development).
     double threshold = 1.0;
     if (const char *e = getenv("FDD_TUNE_CSR_ROW_BLOCK_THRESHOLD")) threshold = atof(e);
-    if (num_rows == 0 || (double)num_nnz <= threshold * (double)num_rows)
+    if (num_rows == 0 || (not f32 and (double)num_nnz <= threshold * (double)num_rows))
     {
         *plan = p;
         return 0;
@@ -637,6 +689,8 @@ int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows
     *plan = p;
     return 0;
 }
+
+extern "C" {
 
 int fdd_csr_plan_destroy(fdd_csr_plan *plan)
 {
@@ -737,6 +791,8 @@ int fdd_csr_plan_gather_weighted_norm2(const fdd_csr_plan *plan, double *out, do
 int fdd_csr_plan_set_unit_values(fdd_csr_plan *plan, int unit_values)
 {
     FDD_REQUIRE(plan != nullptr);
+    FDD_REQUIRE(plan->value_bytes == 8);
+    FDD_REQUIRE(plan->value_bytes == 8);
     plan->unit_values = unit_values != 0;
     return 0;
 }
@@ -753,6 +809,7 @@ int fdd_csr_plan_kind(const fdd_csr_plan *plan, int *kind)
 int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const double *weight, void *stream)
 {
     FDD_REQUIRE(plan != nullptr);
+    FDD_REQUIRE(plan->value_bytes == 8);
     if (plan->num_rows == 0 || plan->num_cols == 0) return 0; // csr_matrix.tpp:304,334
     FDD_REQUIRE(Au != nullptr && A_ptr != nullptr && u != nullptr);
 
@@ -823,6 +880,39 @@ int fdd_amg_smooth_update_matvec(const fdd_csr_plan *plan, double *u, const int 
     if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
     FDD_REQUIRE(u != nullptr && A_ptr != nullptr && work_in != nullptr && Sr != nullptr && D_val != nullptr && u != work_in);
     return plan_launch(plan, u, A_ptr, A_col, A_val, work_in, EpiSmoothUpdate{Sr, D_val, coef}, stream);
+}
+
+// ---- Float = float (AMG/config.hpp:4): the V-cycle's SpMV and fused smoother on f32 values and vectors ----
+int fdd_csr_plan_matvec_to_f32(const fdd_csr_plan *plan, float *y, const float *y_in, const int *A_ptr, const int *A_col, const float *A_val, const float *x, float alpha, float beta, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr);
+    if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
+    FDD_REQUIRE(y != nullptr && A_ptr != nullptr && A_val != nullptr && x != nullptr && y != x);
+    return plan_launch_f32(plan, y, A_ptr, A_col, A_val, x, EpiAxpbyT<float>{alpha, beta, y_in}, stream);
+}
+
+int fdd_amg_smooth_residual_matvec_f32(const fdd_csr_plan *plan, float *work, float *Sr, const int *A_ptr, const int *A_col, const float *A_val, const float *u, const float *f, const float *D_val, float coef, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr);
+    if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
+    FDD_REQUIRE(work != nullptr && Sr != nullptr && A_ptr != nullptr && A_val != nullptr && u != nullptr && f != nullptr && D_val != nullptr && work != u && Sr != u);
+    return plan_launch_f32(plan, work, A_ptr, A_col, A_val, u, EpiSmoothResidualT<float>{f, D_val, Sr, coef}, stream);
+}
+
+int fdd_amg_smooth_polynomial_matvec_f32(const fdd_csr_plan *plan, float *work_out, const int *A_ptr, const int *A_col, const float *A_val, const float *work_in, const float *Sr, const float *D_val, float coef, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr);
+    if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
+    FDD_REQUIRE(work_out != nullptr && A_ptr != nullptr && A_val != nullptr && work_in != nullptr && Sr != nullptr && D_val != nullptr && work_out != work_in);
+    return plan_launch_f32(plan, work_out, A_ptr, A_col, A_val, work_in, EpiSmoothPolyT<float>{Sr, D_val, coef}, stream);
+}
+
+int fdd_amg_smooth_update_matvec_f32(const fdd_csr_plan *plan, float *u, const int *A_ptr, const int *A_col, const float *A_val, const float *work_in, const float *Sr, const float *D_val, float coef, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr);
+    if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
+    FDD_REQUIRE(u != nullptr && A_ptr != nullptr && A_val != nullptr && work_in != nullptr && Sr != nullptr && D_val != nullptr && u != work_in);
+    return plan_launch_f32(plan, u, A_ptr, A_col, A_val, work_in, EpiSmoothUpdateT<float>{Sr, D_val, coef}, stream);
 }
 
 } // extern "C"

@@ -37,6 +37,11 @@ struct Level
     fdd::memory D_val;
     std::vector<double> coefs; // Chebyshev coefficients, coefs[p] multiplies (DAD)^p
     fdd::memory f, u, r, v, w, work;
+    // Float = float (AMG/config.hpp:4): f32 copies of the values and vectors, row-block plans for the f32 SpMV
+    std::vector<double> D_hst;
+    fdd::memory A_val32, P_val32, R_val32, D_val32;
+    fdd::memory f32, u32, r32, v32, work32;
+    fdd_csr_plan *A_plan32 = nullptr, *P_plan32 = nullptr, *R_plan32 = nullptr;
 };
 
 class Hierarchy
@@ -112,11 +117,124 @@ class Hierarchy
         }
     }
 
+    // ---------------------------------------------------------------------------------------------
+    // Float = float (AMG/config.hpp:4, swept by run.py:157): the same cycle on f32 values and vectors.
+    // The residual is cast down on entry and the correction cast up on exit (the reference copies Float
+    // data at subdomain.tpp:4008,4142); fused smoother sequence only.
+    // ---------------------------------------------------------------------------------------------
+    bool ready32 = false;
+    fdd::memory coarse_inverse_val32;
+    fdd_csr_plan *coarse_plan32 = nullptr;
+
+    static fdd::memory to_f32(const std::vector<double> &v)
+    {
+        std::vector<float> t(v.begin(), v.end());
+        fdd::memory m = fdd::dev().malloc<float>(std::max<size_t>(t.size(), 1));
+        if (not t.empty()) m.copyFrom(t.data(), t.size() * sizeof(float));
+        return m;
+    }
+
+    static void blocked_plan(fdd_csr_plan **plan, CSR_Matrix<double> &M)
+    {
+        if (M.num_rows == 0 or M.num_cols == 0 or M.ptr_hst.empty()) return;
+        FDD_CALL(fdd_csr_plan_create_f32(plan, M.ptr_hst.data(), M.num_rows, M.num_cols, M.num_nnz));
+    }
+
+    void prepare32()
+    {
+        if (ready32) return;
+        for (Level &L : levels)
+        {
+            L.A_val32 = to_f32(L.A.val_hst);
+            blocked_plan(&L.A_plan32, L.A);
+            if (L.P.num_rows > 0 and not L.P.ptr_hst.empty())
+            {
+                L.P_val32 = to_f32(L.P.val_hst);
+                L.R_val32 = to_f32(L.R.val_hst);
+                blocked_plan(&L.P_plan32, L.P);
+                blocked_plan(&L.R_plan32, L.R);
+            }
+            L.D_val32 = to_f32(L.D_hst);
+            for (fdd::memory *m : {&L.f32, &L.u32, &L.r32, &L.v32, &L.work32}) *m = fdd::dev().malloc<float>(L.n);
+        }
+        coarse_inverse_val32 = to_f32(coarse_inverse.val_hst);
+        blocked_plan(&coarse_plan32, coarse_inverse);
+        ready32 = true;
+    }
+
+    // y = alpha*A*x + beta*y_in on f32 data
+    static void matvec32(fdd_csr_plan *plan, CSR_Matrix<double> &M, fdd::memory &val32, fdd::memory &y, fdd::memory *y_in, fdd::memory &x, float alpha, float beta)
+    {
+        fdd::ProfileScope prof("csr_block_kernel<f32>", 8.0 * M.num_nnz + 8.0 * M.num_rows + 4.0 * M.num_cols + (beta != 0.0f ? 4.0 * M.num_rows : 0.0));
+        FDD_CALL(fdd_csr_plan_matvec_to_f32(plan, y.as<float>(), y_in ? y_in->as<float>() : nullptr, M.ptr.as<int>(), M.col.as<int>(), val32.as<float>(), x.as<float>(), alpha, beta, fdd::dev().stream));
+    }
+
+    void smooth32(int l, bool u_is_zero)
+    {
+        Level &L = levels[l];
+        void *s = fdd::dev().stream;
+        const int *ptr = L.A.ptr.as<int>(), *col = L.A.col.as<int>();
+        const float *val = L.A_val32.as<float>(), *D = L.D_val32.as<float>();
+        fdd::memory *in = &L.work32, *out = &L.v32;
+        if (u_is_zero)
+            FDD_CALL(fdd_amg_smooth_start_f32(in->as<float>(), L.r32.as<float>(), L.f32.as<float>(), D, (float)L.coefs[cheby_order - 1], L.n, s));
+        else
+            FDD_CALL(fdd_amg_smooth_residual_matvec_f32(L.A_plan32, in->as<float>(), L.r32.as<float>(), ptr, col, val, L.u32.as<float>(), L.f32.as<float>(), D, (float)L.coefs[cheby_order - 1], s));
+        for (int p = cheby_order - 2; p >= 1; p--)
+        {
+            FDD_CALL(fdd_amg_smooth_polynomial_matvec_f32(L.A_plan32, out->as<float>(), ptr, col, val, in->as<float>(), L.r32.as<float>(), D, (float)L.coefs[p], s));
+            std::swap(in, out);
+        }
+        FDD_CALL(fdd_amg_smooth_update_matvec_f32(L.A_plan32, L.u32.as<float>(), ptr, col, val, in->as<float>(), L.r32.as<float>(), D, (float)L.coefs[0], s));
+    }
+
+    void vcycle_launches32()
+    {
+        const int nl = (int)levels.size();
+        void *s = fdd::dev().stream;
+        FDD_CALL(fdd_sub_copy_f32_f64(levels[0].f32.as<float>(), levels[0].f.as<double>(), levels[0].n, s));
+        FDD_CALL(fdd_amg_vector_set_to_value_f32(levels[0].u32.as<float>(), 0.0f, levels[0].n, s));
+        for (int iter = 0; iter < num_vcycles; iter++)
+        {
+            for (int l = 0; l < nl - 1; l++)
+            {
+                Level &L = levels[l];
+                if (l > 0) FDD_CALL(fdd_amg_vector_set_to_value_f32(L.u32.as<float>(), 0.0f, L.n, s));
+                smooth32(l, l > 0 or iter == 0);
+                matvec32(L.A_plan32, L.A, L.A_val32, L.v32, &L.f32, L.u32, -1.0f, 1.0f);
+                matvec32(L.R_plan32, L.R, L.R_val32, levels[l + 1].f32, nullptr, L.v32, 1.0f, 0.0f);
+            }
+            Level &C = levels[nl - 1];
+            matvec32(coarse_plan32, coarse_inverse, coarse_inverse_val32, C.u32, nullptr, C.f32, 1.0f, 0.0f);
+            for (int l = nl - 1; l > 0; l--)
+            {
+                matvec32(levels[l - 1].P_plan32, levels[l - 1].P, levels[l - 1].P_val32, levels[l - 1].u32, nullptr, levels[l].u32, 1.0f, 1.0f);
+                smooth32(l - 1, false);
+            }
+        }
+        FDD_CALL(fdd_sub_copy_f64_f32(levels[0].u.as<double>(), levels[0].u32.as<float>(), levels[0].n, s));
+    }
+
   public:
     int cheby_order = 2; // subdomain.hpp:237
     int num_vcycles = 1; // subdomain.hpp:236
     bool use_graph = true; // AMG/config.hpp:6 USE_CUDA_GRAPH
     bool fused_smoother = true; // element-wise smoother kernels as SpMV epilogues (false: the reference's launch sequence)
+    int precision = 64;         // AMG/config.hpp:4 `Float`: 64 = double, 32 = float (set_precision)
+
+    // 32 needs the fused sequence with a Chebyshev order of at least 2; a captured graph belongs to one precision
+    bool set_precision(int bits)
+    {
+        if (bits != 64 and bits != 32) return false;
+        if (bits == 32 and cheby_order < 2) return false;
+        if (bits != precision and graph != nullptr)
+        {
+            (void)fdd_graph_destroy(graph);
+            graph = nullptr;
+        }
+        precision = bits;
+        return true;
+    }
     std::vector<Level> levels;
 
     bool ready() const { return finalized; }
@@ -136,6 +254,7 @@ class Hierarchy
         }
         L.D_val = fdd::dev().malloc<double>(n);
         L.D_val.copyFrom(D_val, (size_t)n * sizeof(double));
+        L.D_hst.assign(D_val, D_val + n);
         L.coefs.assign(coefs_, coefs_ + cheby_order);
         for (fdd::memory *m : {&L.f, &L.u, &L.r, &L.v, &L.w, &L.work}) *m = fdd::dev().malloc<double>(n);
     }
@@ -173,23 +292,27 @@ class Hierarchy
     }
 
     // algorithmic bytes of the SpMVs of one application (the element-wise kernels between them are not counted)
-    double spmv_bytes() const
+    double spmv_bytes(bool f32 = false) const
     {
+        // f32: 4-byte values and vector entries, the same 4-byte indices
+        auto bytes = [f32](const CSR_Matrix<double> &M, bool weighted) { return f32 ? 8.0 * M.num_nnz + 8.0 * M.num_rows + 4.0 * M.num_cols + (weighted ? 4.0 * M.num_rows : 0.0) : M.algorithmic_bytes(weighted); };
         double b = 0.0;
         const int nl = (int)levels.size();
         for (int iter = 0; iter < num_vcycles; iter++)
             for (int l = 0; l < nl - 1; l++)
             {
                 const int with_A = 2 * cheby_order + ((l > 0 or iter == 0) ? 0 : 1); // pre-smoothing (no residual SpMV from u = 0), residual, post-smoothing
-                b += with_A * levels[l].A.algorithmic_bytes(true) + levels[l].R.algorithmic_bytes(false) + levels[l].P.algorithmic_bytes(true);
+                b += with_A * bytes(levels[l].A, true) + bytes(levels[l].R, false) + bytes(levels[l].P, true);
             }
-        return b + num_vcycles * coarse_inverse.algorithmic_bytes(false);
+        return b + num_vcycles * bytes(coarse_inverse, false);
     }
 
     // u_fem[0] = V-cycle applied to f_fem[0] from u = 0; both live in levels[0]
     void vcycle()
     {
         void *s = fdd::dev().stream;
+        const bool f32 = (precision == 32);
+        if (f32) prepare32();
         if (use_graph and not graph_failed)
         {
             if (graph == nullptr)
@@ -204,7 +327,10 @@ class Hierarchy
                         const bool profiling = fdd::profiler().enabled; // no event records inside a capture
                         fdd::profiler().enabled = false;
                         fdd::dev().stream = cs;
-                        vcycle_launches();
+                        if (f32)
+                            vcycle_launches32();
+                        else
+                            vcycle_launches();
                         fdd::dev().stream = s;
                         fdd::profiler().enabled = profiling;
                         if (fdd_graph_end_capture(cs, &graph) != 0) graph = nullptr;
@@ -215,12 +341,15 @@ class Hierarchy
             }
             if (graph != nullptr)
             {
-                fdd::ProfileScope prof("amg_vcycle<hipGraph>", spmv_bytes());
+                fdd::ProfileScope prof(f32 ? "amg_vcycle<hipGraph,f32>" : "amg_vcycle<hipGraph>", spmv_bytes(f32));
                 FDD_CALL(fdd_graph_launch(graph, s));
                 return;
             }
         }
-        vcycle_launches();
+        if (f32)
+            vcycle_launches32();
+        else
+            vcycle_launches();
     }
 };
 

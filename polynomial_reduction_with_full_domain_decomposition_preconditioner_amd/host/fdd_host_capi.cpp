@@ -462,6 +462,11 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
     {
         if (p->subdomain) p->subdomain->amg_hierarchy.fused_smoother = value != 0;
     }
+    else if (s == "amg_precision")
+    {
+        // AMG/config.hpp:4 `Float`: 64 (double) or 32 (float)
+        if (p->subdomain and not p->subdomain->amg_hierarchy.set_precision(value)) return fail("amg_precision is 64 or 32 (32 needs a Chebyshev order of at least 2)");
+    }
     else
         return fail("unknown flag '%s'", name);
     return 0;

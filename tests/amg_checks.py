@@ -17,6 +17,55 @@ import numpy as np
 import support as S
 
 
+def check_amg_f32(p, N, red):
+    """`Float = float` (AMG/config.hpp:4): the V-cycle on f32 values and vectors against the oracle's float
+    cycle (fdd_oracle_amg_f32.c, same statement order; the coarsest level is a precomputed inverse here and an
+    elimination there), against the double cycle, and as the preconditioner of the solves.
+    Tolerances are single-precision ones: 2e-5 of the result's max norm between the two float cycles,
+    1e-4 between float and double."""
+    meshes = [S.ArrayMesh.from_problem(p, lvl) for lvl in range(p.info["num_levels"])]
+    dof, nd = p.sub_point_dofs(), p.info["sub_num_dofs"]
+    levels = S.low_order_hierarchy(meshes[0], dof, nd)
+    p.amg_attach(levels)
+    o32 = S.OracleAmgF32(levels)
+    try:
+        r = S.seeded_uniform(p.n, 5) - 0.5
+        z64 = p.amg_apply(r)
+        p.set_flag("amg_precision", 32)
+        z32 = p.amg_apply(r)
+        # Qt r on the dofs (sum over a dof's points), the float cycle, Q back to the points
+        has = dof >= 0
+        f = np.zeros(nd)
+        np.add.at(f, dof[has], r[has])
+        u = o32.vcycle(f)
+        ref = np.where(has, u[np.maximum(dof, 0)], 0.0)
+        scale = np.abs(ref).max()
+        assert scale > 0
+        assert np.abs(z32 - ref).max() <= 2e-5 * scale, np.abs(z32 - ref).max() / scale
+        assert np.abs(z32 - z64).max() <= 1e-4 * np.abs(z64).max()
+        assert not np.array_equal(z32, z64)  # it really ran in float
+        assert np.array_equal(z32.astype(np.float32).astype(np.float64), z32)  # the correction is float data cast up
+        assert np.all(z32[~has] == 0.0)
+        assert np.array_equal(p.amg_apply(r), z32)  # replay
+        # switching back gives the double cycle again, bit for bit
+        p.set_flag("amg_precision", 64)
+        assert np.array_equal(p.amg_apply(r), z64)
+
+        # the float cycle as preconditioner: the flexible solves converge as with the double one
+        _, rhs = p.make_rhs_from(S.seeded_uniform(p.n, 1234))
+        p.set_flag("sub_use_preconditioner", 1)
+        p.set_options(preconditioner_type=1)
+        u64, its64, h64 = p.solve(rhs, "fcg")
+        p.set_flag("amg_precision", 32)
+        u32, its32, h32 = p.solve(rhs, "fcg")
+        assert abs(its32 - its64) <= 1, (its32, its64)
+        assert h32[-1] <= 1e-7 * h32[0] * 1.0001
+        assert np.abs(u32 - u64).max() <= 1e-5 * np.abs(u64).max()
+        return its32
+    finally:
+        o32.close()
+
+
 def check_amg(p, N, red, outer_solve=True, builder="scipy"):
     meshes = [S.ArrayMesh.from_problem(p, lvl) for lvl in range(p.info["num_levels"])]
     sd = S.OracleSubdomain(None, N, red, meshes=meshes)

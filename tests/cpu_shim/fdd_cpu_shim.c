@@ -630,3 +630,84 @@ int fdd_amg_smooth_update_matvec(const fdd_csr_plan *plan, double *u, const int 
     free(w);
     return rc;
 }
+
+/* ---- Float = float V-cycle entries: plain float loops in the device statement order ---- */
+int fdd_csr_plan_create_f32(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows, int num_cols, int num_nnz) { return fdd_csr_plan_create(plan, A_ptr_host, num_rows, num_cols, num_nnz); }
+
+static float shim_rowsum32(const int *p, const int *c, const float *v, const float *x, int row)
+{
+    float s = 0.0f;
+    for (int i = p[row]; i < p[row + 1]; i++) s += v[i] * x[c[i]];
+    return s;
+}
+
+int fdd_csr_plan_matvec_to_f32(const fdd_csr_plan *plan, float *y, const float *y_in, const int *p, const int *c, const float *v, const float *x, float a, float b, void *s)
+{
+    (void)s;
+    for (int row = 0; row < plan->num_rows; row++)
+    {
+        float t = shim_rowsum32(p, c, v, x, row);
+        y[row] = (b == 0.0f) ? a * t : a * t + b * (y_in ? y_in[row] : y[row]);
+    }
+    return 0;
+}
+
+int fdd_amg_smooth_residual_matvec_f32(const fdd_csr_plan *plan, float *work, float *Sr, const int *p, const int *c, const float *v, const float *u, const float *f, const float *D, float coef, void *s)
+{
+    (void)s;
+    for (int row = 0; row < plan->num_rows; row++)
+    {
+        float t = shim_rowsum32(p, c, v, u, row);
+        float wk = -1.0f * t + 1.0f * f[row];
+        float sr = D[row] * wk;
+        Sr[row] = sr;
+        float w = coef * sr;
+        work[row] = w * D[row];
+    }
+    return 0;
+}
+
+int fdd_amg_smooth_polynomial_matvec_f32(const fdd_csr_plan *plan, float *work_out, const int *p, const int *c, const float *v, const float *work_in, const float *Sr, const float *D, float coef, void *s)
+{
+    (void)s;
+    for (int row = 0; row < plan->num_rows; row++)
+    {
+        float t = shim_rowsum32(p, c, v, work_in, row);
+        float vv = (1.0f * t) * D[row];
+        float w = coef * Sr[row] + vv;
+        work_out[row] = w * D[row];
+    }
+    return 0;
+}
+
+int fdd_amg_smooth_update_matvec_f32(const fdd_csr_plan *plan, float *u, const int *p, const int *c, const float *v, const float *work_in, const float *Sr, const float *D, float coef, void *s)
+{
+    (void)s;
+    for (int row = 0; row < plan->num_rows; row++)
+    {
+        float t = shim_rowsum32(p, c, v, work_in, row);
+        float vv = (1.0f * t) * D[row];
+        float w = coef * Sr[row] + vv;
+        u[row] = u[row] + D[row] * w;
+    }
+    return 0;
+}
+
+int fdd_amg_smooth_start_f32(float *work, float *Sr, const float *f, const float *D, float coef, int n, void *s)
+{
+    (void)s;
+    for (int i = 0; i < n; i++)
+    {
+        float sr = D[i] * f[i];
+        Sr[i] = sr;
+        work[i] = D[i] * (coef * sr);
+    }
+    return 0;
+}
+
+int fdd_amg_vector_set_to_value_f32(float *data, float value, int n, void *s)
+{
+    (void)s;
+    for (int i = 0; i < n; i++) data[i] = value;
+    return 0;
+}

@@ -115,6 +115,7 @@ def oracle():
         L.orc_subdomain_create.restype = vp
         L.orc_subdomain_residual_norm.restype = ctypes.c_double
         L.orc_amg_create.restype = vp
+        L.orc_amg32_create.restype = vp
         _oracle = L
     return _oracle
 
@@ -569,6 +570,40 @@ def low_order_hierarchy(mesh, point_dof, num_dofs, min_size=30, max_levels=8):
 # geometric factors are non-zero (the reference's Kershaw / pebble-bed inputs,
 # run.py:36-74, are such meshes; they are not available here).
 # --------------------------------------------------------------------------
+
+class OracleAmgF32:
+    """The V-cycle with Float = float (oracle/fdd_oracle_amg_f32.c) on a hierarchy given as Problem.amg_attach takes it."""
+
+    def __init__(self, levels, cheby_order=2, num_vcycles=1):
+        self.L = oracle()
+        ip = ctypes.POINTER(ctypes.c_int)
+        self.n = levels[0]["A"].shape[0]
+        self.a = vp(self.L.orc_amg32_create(len(levels), cheby_order, num_vcycles))
+        for l, lv in enumerate(levels):
+            A = lv["A"].tocsr()
+            A.sort_indices()
+            arrs = [np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32), np.ascontiguousarray(A.data, dtype=np.float64),
+                    np.ascontiguousarray(lv["D"], dtype=np.float64), np.ascontiguousarray(lv["coefs"], dtype=np.float64)]
+            if lv.get("P") is not None:
+                P = lv["P"].tocsr()
+                P.sort_indices()
+                parr = [np.ascontiguousarray(P.indptr, dtype=np.int32), np.ascontiguousarray(P.indices, dtype=np.int32), np.ascontiguousarray(P.data, dtype=np.float64)]
+                pargs = (P.shape[1], parr[0].ctypes.data_as(ip), parr[1].ctypes.data_as(ip), _p(parr[2]))
+            else:
+                pargs = (0, None, None, None)
+            self.L.orc_amg32_set_level(self.a, l, A.shape[0], arrs[0].ctypes.data_as(ip), arrs[1].ctypes.data_as(ip), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), *pargs)  # copied inside
+
+    def vcycle(self, f):
+        u = np.zeros(self.n)
+        self.L.orc_amg32_vcycle(self.a, _p(u), _p(np.ascontiguousarray(f, dtype=np.float64)))
+        return u
+
+    def close(self):
+        if self.a:
+            self.L.orc_amg32_destroy(self.a)
+            self.a = None
+
+
 class DeformedMesh(BoxMesh):
     """BoxMesh with x -> x + a*s(x,y,z)*(1, -0.7, 0.5), s = sin(pi x) sin(pi y) sin(pi z): the boundary stays put,
     elements stay conforming (one global map), the Jacobian is full.  Geometric factors are the isoparametric ones

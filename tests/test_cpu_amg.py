@@ -167,3 +167,24 @@ print("ok", its)
 """ % (S.ROOT, S.HERE, HOST_CPU_SO, str(tmp_path / "quad"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_host_layer_float_vcycle_on_cpu_shim():
+    """`Float = float` V-cycle of the host layer (host/amg.hpp) against the oracle's float cycle (amg_checks.check_amg_f32)."""
+    subprocess.check_call(["make", "-C", S.ORACLE_DIR, "-s"])
+    subprocess.check_call(["make", "-C", SHIM_DIR, "-s"])
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import support as S, amg_checks
+from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H, lib
+lib._host = lib._Lib(%r, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
+H.init(0, use_torch_stream=False); H.comm_single(); H.set_print(False)
+p = H.Problem.box((4, 4, 4), (1, 1, 1), 3, 2, True)
+for lvl in range(p.info["num_levels"]):
+    p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
+its = amg_checks.check_amg_f32(p, 3, 2)
+print("ok", its)
+""" % (S.ROOT, S.HERE, HOST_CPU_SO)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

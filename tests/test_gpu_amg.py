@@ -79,6 +79,17 @@ def test_fused_smoother_equals_reference_launch_sequence(own_stream):
     assert np.array_equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("E,N,red", [((4, 4, 4), 3, 2), ((3, 2, 2), 5, 2)])
+def test_float_vcycle_matches_oracle(own_stream, E, N, red):
+    """`Float = float` (AMG/config.hpp:4): f32 SpMV + fused smoother kernels, one hipGraph (amg_checks.check_amg_f32)."""
+    p = make_problem(E, N, red)
+    try:
+        its = amg_checks.check_amg_f32(p, N, red)
+        assert its <= 8
+    finally:
+        p.close()
+
+
 def test_errors(own_stream):
     p = make_problem((2, 2, 2), 3, 2)
     try:

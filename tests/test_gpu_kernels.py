@@ -1107,6 +1107,89 @@ def test_amg_smoother_fused_into_spmv(gpu, shape):
         lib.hip().call("fdd_csr_plan_destroy", plan)
 
 
+@pytest.mark.parametrize("shape", ["short_rows", "stencil"])
+def test_f32_spmv_and_fused_smoother(gpu, shape):
+    """`Float = float` entries (AMG/config.hpp:4): f32 SpMV y = alpha*A*x + beta*y_in and the fused smoother
+    epilogues, bit-exact against an IEEE-single restatement (numpy float32 scalars, products added in
+    column order, no contraction), on both row-block sizes."""
+    f32 = np.float32
+    rng = np.random.default_rng(97)
+    if shape == "short_rows":
+        n = 700
+        lens = rng.integers(0, 4, n)  # includes empty rows: the small row blocks
+        ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        col = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) for k in lens] + [np.zeros(0, int)]).astype(np.int32)
+    else:
+        import scipy.sparse as sp
+
+        m = 9
+        T = sp.diags([1.0, -2.0, 1.0], [-1, 0, 1], shape=(m, m))
+        A = (sp.kron(sp.kron(T, sp.eye(m)), sp.eye(m)) + sp.kron(sp.kron(sp.eye(m), T), sp.eye(m)) + sp.kron(sp.eye(m), sp.kron(sp.eye(m), T))).tocsr()
+        A.sort_indices()
+        ptr, col = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+        n = m**3
+    val = rng.uniform(-1, 1, len(col)).astype(f32)
+    x, yin, fv, Sr_in = (rng.uniform(-1, 1, n).astype(f32) for _ in range(4))
+    D = (rng.uniform(0.5, 1.5, n)).astype(f32)
+    u0 = rng.uniform(-1, 1, n).astype(f32)
+    coef, alpha, beta = f32(-0.37), f32(0.75), f32(-1.25)
+
+    def rowsum(v):
+        out = np.zeros(n, f32)
+        for r in range(n):
+            s_ = f32(0)
+            for j in range(ptr[r], ptr[r + 1]):
+                s_ = f32(s_ + f32(val[j] * v[col[j]]))
+            out[r] = s_
+        return out
+
+    Ax = rowsum(x)
+    t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    nan = lambda: torch.full((n,), float("nan"), dtype=torch.float32, device=gpu)
+    plan = vp()
+    lib.hip().call("fdd_csr_plan_create_f32", ctypes.byref(plan), vp(ptr.ctypes.data), n, n, len(col))
+    dp, dc, dv, dD, dx = dev(ptr, gpu), dev(col, gpu), t32(val), t32(D), t32(x)
+    try:
+        kind = ctypes.c_int()
+        lib.hip().call("fdd_csr_plan_kind", plan, ctypes.byref(kind))
+        assert kind.value == 1
+        # y = alpha*A*x + beta*y_in; beta = 0 never reads y
+        y = nan()
+        k("fdd_csr_plan_matvec_to_f32", plan, y, t32(yin), dp, dc, dv, dx, float(alpha), float(beta))
+        assert np.array_equal(y.cpu().numpy(), (alpha * Ax + beta * yin).astype(f32))
+        y = nan()
+        k("fdd_csr_plan_matvec_to_f32", plan, y, None, dp, dc, dv, dx, float(alpha), 0.0)
+        assert np.array_equal(y.cpu().numpy(), (alpha * Ax).astype(f32))
+        # residual: work = -A x + f; Sr = D*work; w = coef*Sr; out = w*D
+        work = (f32(-1) * Ax + f32(1) * fv).astype(f32)
+        Sr = (D * work).astype(f32)
+        out = ((coef * Sr).astype(f32) * D).astype(f32)
+        dwork, dSr = nan(), nan()
+        k("fdd_amg_smooth_residual_matvec_f32", plan, dwork, dSr, dp, dc, dv, dx, t32(fv), dD, float(coef))
+        assert np.array_equal(dSr.cpu().numpy(), Sr) and np.array_equal(dwork.cpu().numpy(), out)
+        # start: Sr = D*f; out = D*(coef*Sr)
+        Sr0 = (D * fv).astype(f32)
+        out0 = (D * (coef * Sr0).astype(f32)).astype(f32)
+        dwork, dSr = nan(), nan()
+        k("fdd_amg_smooth_start_f32", dwork, dSr, t32(fv), dD, float(coef), n)
+        assert np.array_equal(dSr.cpu().numpy(), Sr0) and np.array_equal(dwork.cpu().numpy(), out0)
+        # polynomial / update: v = (A x)*D; w = coef*Sr + v; out = w*D | u += D*w
+        v = (Ax * D).astype(f32)
+        w = ((coef * Sr_in).astype(f32) + v).astype(f32)
+        dout = nan()
+        k("fdd_amg_smooth_polynomial_matvec_f32", plan, dout, dp, dc, dv, dx, t32(Sr_in), dD, float(coef))
+        assert np.array_equal(dout.cpu().numpy(), (w * D).astype(f32))
+        du = t32(u0)
+        k("fdd_amg_smooth_update_matvec_f32", plan, du, dp, dc, dv, dx, t32(Sr_in), dD, float(coef))
+        assert np.array_equal(du.cpu().numpy(), (u0 + (D * w).astype(f32)).astype(f32))
+        # set
+        d = nan()
+        k("fdd_amg_vector_set_to_value_f32", d, 0.25, n)
+        assert np.array_equal(d.cpu().numpy(), np.full(n, 0.25, f32))
+    finally:
+        lib.hip().call("fdd_csr_plan_destroy", plan)
+
+
 def test_graph_capture_and_replay(gpu):
     """fdd_graph_*: a captured launch sequence replays with the same result;
     the default stream is refused (it cannot be captured)."""
