@@ -329,6 +329,59 @@ int launch_rows(double *Au, const int *A_ptr, const int *A_col, const double *A_
     return 0;
 }
 
+// Exactly one stored entry in every row (the scatter matrices Q: the plan checks its host row pointers): the row
+// pointers are i and are not read, y[i] = val[i]*x[col[i]] is a two-deep load chain instead of three, and the index
+// and value streams are non-temporal.  0.0 + a*x keeps the row sum's bits (a sum that starts from +0.0).
+template <typename Epi, bool UNIT, int NPT>
+__global__ __launch_bounds__(kBlock) void csr_one_per_row_kernel(double *__restrict__ Au, const int *__restrict__ A_col, const double *__restrict__ A_val, const double *__restrict__ u, Epi epi, int n)
+{
+    const int tile = fdd_xcd_chunked_block(blockIdx.x, gridDim.x) * (kBlock * NPT);
+    int c[NPT];
+    double a[NPT], x[NPT];
+    typename Epi::Opnd o[NPT];
+#pragma unroll
+    for (int r = 0; r < NPT; r++)
+    {
+        const int row = tile + r * kBlock + threadIdx.x;
+        const int rs = (row < n) ? row : 0; // unconditional loads on a selected index
+        c[r] = __builtin_nontemporal_load(A_col + rs);
+        a[r] = UNIT ? 1.0 : __builtin_nontemporal_load(A_val + rs);
+        o[r] = epi.operand(rs, Au);
+    }
+#pragma unroll
+    for (int r = 0; r < NPT; r++) x[r] = u[c[r]];
+#pragma unroll
+    for (int r = 0; r < NPT; r++)
+    {
+        const int row = tile + r * kBlock + threadIdx.x;
+        if (row < n) Au[row] = epi.finish(0.0 + a[r] * x[r], o[r], row);
+    }
+}
+
+template <typename Epi>
+int launch_one_per_row(double *Au, const int *A_col, const double *A_val, const double *u, const Epi &epi, int n, void *stream, bool unit_values)
+{
+    static const int npt = fdd_env_int("FDD_TUNE_CSR_ONE_NPT", 4);
+    const int per = kBlock * ((npt == 8) ? 8 : 4);
+    const int grid = (n + per - 1) / per;
+    if (unit_values)
+    {
+        if (npt == 8)
+            hipLaunchKernelGGL((csr_one_per_row_kernel<Epi, true, 8>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, A_col, A_val, u, epi, n);
+        else
+            hipLaunchKernelGGL((csr_one_per_row_kernel<Epi, true, 4>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, A_col, A_val, u, epi, n);
+    }
+    else
+    {
+        if (npt == 8)
+            hipLaunchKernelGGL((csr_one_per_row_kernel<Epi, false, 8>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, A_col, A_val, u, epi, n);
+        else
+            hipLaunchKernelGGL((csr_one_per_row_kernel<Epi, false, 4>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, A_col, A_val, u, epi, n);
+    }
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // LDS-staged gather-scatter (dssum) on the row blocks of a boolean gather
 // matrix Qt: the balanced form of fdd_dssum.hip's lane-per-node kernel.
@@ -529,6 +582,7 @@ struct fdd_csr_plan
     int has_long_rows; // some row exceeds a block (workgroup-reduced in SpMV)
     int block_nnz;     // kBlockNnzSmall or kBlockNnzMax: non-zeros (and rows) per row block
     int xcd_chunked;   // SpMV row blocks in XCD-chunked order
+    int one_per_row;   // kind 0 with exactly one entry in every row: the row pointers are not read
     int value_bytes;   // 8: the fp64 entries; 4: a plan of the f32 entries (always row blocks; twice the non-zeros per block measured no faster)
     int num_blocks;
     int *row_blocks_dev; // num_blocks + 1
@@ -552,6 +606,7 @@ static int plan_launch(const fdd_csr_plan *plan, double *y, const int *A_ptr, co
         fdd_set_error("fp64 SpMV on a plan of fdd_csr_plan_create_f32");
         return 1;
     }
+    if (plan->one_per_row) return launch_one_per_row(y, A_col, A_val, x, epi, plan->num_rows, stream, plan->unit_values != 0);
     if (plan->kind == 0) return launch_rows(y, A_ptr, A_col, A_val, x, epi, 0, plan->num_rows, stream, plan->unit_values != 0);
     const dim3 grid(plan->num_blocks), block(kBlock);
     if (plan->unit_values)
@@ -639,6 +694,7 @@ static int plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows,
     p->block_nnz = ((double)num_nnz < 4.0 * (double)num_rows) ? kBlockNnzSmall : kBlockNnzMax;
     if (const char *e = getenv("FDD_TUNE_CSR_BLOCK_NNZ")) p->block_nnz = (atoi(e) <= kBlockNnzSmall) ? kBlockNnzSmall : kBlockNnzMax;
     p->value_bytes = f32 ? 4 : 8;
+    p->one_per_row = 0;
     p->xcd_chunked = fdd_env_int("FDD_TUNE_CSR_XCD", 0);
     p->num_blocks = 0;
     p->row_blocks_dev = nullptr;
@@ -651,6 +707,9 @@ static int plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows,
     if (const char *e = getenv("FDD_TUNE_CSR_ROW_BLOCK_THRESHOLD")) threshold = atof(e);
     if (num_rows == 0 || (not f32 and (double)num_nnz <= threshold * (double)num_rows))
     {
+        bool one = num_rows > 0 && num_nnz == num_rows && A_ptr_host[0] == 0;
+        for (int i = 0; one && i < num_rows; i++) one = (A_ptr_host[i + 1] == i + 1);
+        p->one_per_row = (one && fdd_env_int("FDD_TUNE_CSR_ONE_PER_ROW", 1)) ? 1 : 0;
         *plan = p;
         return 0;
     }
@@ -813,6 +872,11 @@ int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr
     if (plan->num_rows == 0 || plan->num_cols == 0) return 0; // csr_matrix.tpp:304,334
     FDD_REQUIRE(Au != nullptr && A_ptr != nullptr && u != nullptr);
 
+    if (plan->one_per_row)
+    {
+        if (weight) return launch_one_per_row(Au, A_col, A_val, u, EpiWeight{weight}, plan->num_rows, stream, plan->unit_values != 0);
+        return launch_one_per_row(Au, A_col, A_val, u, EpiPlain{}, plan->num_rows, stream, plan->unit_values != 0);
+    }
     if (plan->kind == 0)
     {
         if (weight) return launch_rows(Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, 0, plan->num_rows, stream, plan->unit_values != 0);

@@ -9,7 +9,8 @@ r = d["roofline"]
 if r:
     print(f"roofline: {r['kernel']}  {r['achieved']:.0f} GB/s = {100 * r['frac']:.1f}% of {r['peak']:.0f}  ({r['launches']} launches, avg {r['avg_launch_us']:.1f} us)")
 for k, v in (d.get("spmv") or {}).items():
-    print(f"spmv {k}: {v['avg_us']:.1f} us  {v['GBps']:.0f} GB/s = {100 * v['frac_of_hbm_peak']:.1f}% of HBM peak")
+    moved = f"  (moved: {v['GBps_moved']:.0f} GB/s = {100 * v['frac_moved_of_hbm_peak']:.1f}%)" if "GBps_moved" in v else ""
+    print(f"spmv {k}: {v['avg_us']:.1f} us  {v['GBps']:.0f} GB/s = {100 * v['frac_of_hbm_peak']:.1f}% of HBM peak on the CSR formula{moved}")
 if r and r.get("traffic"):
     print(f"  PMC traffic {r['traffic'] / 1e6:.1f} MB per launch vs algorithmic {r['algorithmic_bytes_per_launch'] / 1e6:.1f} MB")
 tot = 0.0
