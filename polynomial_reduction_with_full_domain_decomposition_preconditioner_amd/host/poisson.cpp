@@ -206,7 +206,7 @@ int main(int argc, char *argv[])
     {
         printf("\nRun info:\n");
         printf("-------------------------------------------------------------------------\n");
-        printf("Number of dimensions: %d\n", 3);
+        printf("Number of dimensions: %lld\n", info[FDDH_INFO_DIM]);
         printf("Total number of elements: %lld\n", info[FDDH_INFO_NUM_TOTAL_ELEMENTS]);
         printf("Total number of unique nodes: %lld\n", info[FDDH_INFO_NUM_TOTAL_NODES]);
         printf("Polynomial degree: %d\n", poly_degree);

@@ -386,3 +386,28 @@ def test_two_dimensional_mesh_from_files(setup, tmp_path):
 
     its = dim2_checks.check_two_dimensional_solve(H, str(tmp_path / "quad"))
     assert 0 < its < 40
+
+
+def test_poisson_driver_binary(setup, tmp_path):
+    """The compiled driver (host/poisson.cpp, the reference's poisson.cpp:main): a generated box problem, its mesh
+    written in the reference's file format, then the same solve from those files -- same iteration count,
+    manufactured solution recovered, in a process of its own (no Python, no torch)."""
+    import os
+    import re
+    import subprocess
+
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
+
+    exe = os.path.join(lib.PKG_DIR, "poisson")
+    assert os.path.exists(exe), "build() links the driver next to the libraries"
+    d = str(tmp_path / "mesh")
+    runs = []
+    for args in (["-", "3", "2", "0", "0", "--box", "4", "4", "4", "--write-mesh", d], [d, "3", "2", "0", "0"]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        its = int(re.search(r"Iterations: (\d+)", out.stdout).group(1))
+        err = float(re.search(r"max \|u - u\*\| on rank 0: (\S+)", out.stdout).group(1))
+        assert "Number of dimensions: 3" in out.stdout
+        assert 0 < its < 30 and err < 1e-4, out.stdout  # outer tolerance 1e-7 on the residual (domain.hpp:113)
+        runs.append((its, err))
+    assert runs[0][0] == runs[1][0]
