@@ -113,7 +113,7 @@ def cpu_host_lib():
     return HOST_CPU_SO
 
 
-@pytest.mark.parametrize("world,with_sub", [(2, False), (2, True), (3, True), (4, False)])
+@pytest.mark.parametrize("world,with_sub", [(2, False), (2, True), (3, True), (4, False), (8, True)])  # 8 = 2x2x2: edges shared by 4 ranks, the centre node by 8 (the scaling run's topology)
 def test_host_layer_multirank_gloo(cpu_host_lib, world, with_sub):
     import torch.multiprocessing as mp
 
