@@ -241,10 +241,27 @@ class CSR_Matrix
     {
         At.initialize(num_cols, num_rows);
         if ((num_rows == 0) or (num_cols == 0)) return;
-        At.reserve(num_nnz);
+        // What add_entry + assemble (csr_matrix.tpp:288-300) produces, by a counting transpose instead of a sort of
+        // tuples: this matrix's rows are in ascending order with sorted, duplicate-free columns, so the transposed
+        // rows come out sorted and duplicate-free; entries assemble would drop (|v| <= tolerance) are dropped here.
+        std::vector<int> tp(num_cols + 1, 0);
         for (int i = 0; i < num_rows; i++)
-            for (int j = ptr_hst[i]; j < ptr_hst[i + 1]; j++) At.add_entry(col_hst[j], i, val_hst[j]);
-        At.assemble();
+            for (int j = ptr_hst[i]; j < ptr_hst[i + 1]; j++)
+                if (std::abs(val_hst[j]) > At.sparse_tolerance) tp[col_hst[j] + 1]++;
+        for (int c = 0; c < num_cols; c++) tp[c + 1] += tp[c];
+        std::vector<int> tc(tp[num_cols]);
+        std::vector<DType> tv(tp[num_cols]);
+        std::vector<int> next(tp.begin(), tp.end() - 1);
+        for (int i = 0; i < num_rows; i++)
+            for (int j = ptr_hst[i]; j < ptr_hst[i + 1]; j++)
+                if (std::abs(val_hst[j]) > At.sparse_tolerance)
+                {
+                    const int k = next[col_hst[j]]++;
+                    tc[k] = i;
+                    tv[k] = val_hst[j];
+                }
+        if (tp[num_cols] == 0) return;
+        At.assemble_from_csr(num_cols, num_rows, tp.data(), tc.data(), tv.data());
     }
 
     void diagonal(fdd::memory D)

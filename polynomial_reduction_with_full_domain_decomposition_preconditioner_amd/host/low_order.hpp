@@ -25,12 +25,43 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 namespace fdd
 {
 namespace low_order
 {
+
+// Setup runs on the host cores of the rank (one rank per GPU: 16 of them on a one-GPU box): contiguous index
+// ranges on std::thread, results concatenated in range order, so every output is the one the serial loop gives.
+// FDD_HOST_THREADS overrides the count (1 = serial).
+inline int host_threads()
+{
+    if (const char *e = getenv("FDD_HOST_THREADS")) return std::max(1, atoi(e));
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::min(16u, std::max(1u, hw));
+}
+
+// f(begin, end, part) for `parts` contiguous ranges covering [0, n)
+template <typename F>
+inline void parallel_ranges(long long n, int parts, F f)
+{
+    if (parts <= 1 or n < 2 * parts)
+    {
+        f(0LL, n, 0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < parts; t++) pool.emplace_back(f, n * t / parts, n * (t + 1) / parts, t);
+    for (std::thread &th : pool) th.join();
+}
+
+inline int range_parts(long long n)
+{
+    const int t = host_threads();
+    return (n < 2 * t) ? 1 : t;
+}
 
 struct HostCSR
 {
@@ -64,31 +95,52 @@ inline HostCSR from_triplets(int rows, int cols, std::vector<int> &ti, std::vect
     std::vector<int>().swap(ti);
     std::vector<int>().swap(tj);
     std::vector<double>().swap(tv);
-    // sort each row by column (stable: insertion order of equal columns is kept) and merge duplicates
-    std::vector<int> order;
-    std::vector<int> out_ptr(rows + 1, 0);
-    for (int i = 0; i < rows; i++)
-    {
-        const int a = A.ptr[i], b = A.ptr[i + 1];
-        order.resize(b - a);
-        for (int k = 0; k < b - a; k++) order[k] = a + k;
-        std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return cj[p] < cj[q]; });
-        int last = -1;
-        for (int k = 0; k < b - a; k++)
+    // sort each row by column (stable: insertion order of equal columns is kept) and merge duplicates;
+    // row ranges in parallel, pieces concatenated in row order
+    const int parts = range_parts(rows);
+    std::vector<std::vector<int>> pcol(parts);
+    std::vector<std::vector<double>> pval(parts);
+    std::vector<int> row_len(rows, 0);
+    parallel_ranges(rows, parts, [&](long long r0, long long r1, int part) {
+        std::vector<int> order;
+        std::vector<int> oc; // thread-local while growing (the headers in pcol / pval share cache lines), moved out at the end
+        std::vector<double> ov;
+        for (long long i = r0; i < r1; i++)
         {
-            const int p = order[k];
-            if (cj[p] != last)
+            const int a = A.ptr[i], b = A.ptr[i + 1];
+            order.resize(b - a);
+            for (int k = 0; k < b - a; k++) order[k] = a + k;
+            std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return cj[p] < cj[q]; });
+            int last = -1;
+            const size_t before = oc.size();
+            for (int k = 0; k < b - a; k++)
             {
-                A.col.push_back(cj[p]);
-                A.val.push_back(cv[p]);
-                last = cj[p];
+                const int p = order[k];
+                if (cj[p] != last)
+                {
+                    oc.push_back(cj[p]);
+                    ov.push_back(cv[p]);
+                    last = cj[p];
+                }
+                else
+                    ov.back() += cv[p];
             }
-            else
-                A.val.back() += cv[p];
+            row_len[i] = (int)(oc.size() - before);
         }
-        out_ptr[i + 1] = (int)A.col.size();
+        pcol[part] = std::move(oc);
+        pval[part] = std::move(ov);
+    });
+    A.ptr[0] = 0; // the old pointers (into cj / cv) are no longer needed
+    for (int i = 0; i < rows; i++) A.ptr[i + 1] = A.ptr[i] + row_len[i];
+    A.col.reserve(A.ptr[rows]);
+    A.val.reserve(A.ptr[rows]);
+    for (int t = 0; t < parts; t++)
+    {
+        A.col.insert(A.col.end(), pcol[t].begin(), pcol[t].end());
+        A.val.insert(A.val.end(), pval[t].begin(), pval[t].end());
+        std::vector<int>().swap(pcol[t]);
+        std::vector<double>().swap(pval[t]);
     }
-    A.ptr.swap(out_ptr);
     return A;
 }
 
@@ -104,16 +156,26 @@ inline HostCSR assemble_fem(const double *x, const double *y, const double *z, c
     static const double Dref[3][4] = {{1.0, 0.0, 0.0, -1.0}, {0.0, 1.0, 0.0, -1.0}, {0.0, 0.0, 1.0, -1.0}};
 
     const int N = poly_degree, n = N + 1, n3 = n * n * n;
-    std::vector<int> ti, tj;
+    // Element ranges in parallel.  The tetrahedra of one element are first summed into the element's own 27-neighbour
+    // stencil (a vertex pair of a cell differs by at most one step per direction) and only then emitted as triplets:
+    // 6 * 16 entries per cell would be 10^9 triplets (17 GB) at 32^3 elements of degree 7.
+    const int parts = range_parts(num_elements);
+    std::vector<std::vector<int>> pti(parts), ptj(parts);
+    std::vector<std::vector<double>> ptv(parts);
+    parallel_ranges(num_elements, parts, [&](long long e0, long long e1, int part) {
+    std::vector<int> ti, tj; // thread-local while growing, moved out at the end
     std::vector<double> tv;
-    const size_t guess = (size_t)num_elements * N * N * N * 6 * 10;
+    std::vector<double> K((size_t)n3 * 27);
+    std::vector<unsigned char> touched((size_t)n3 * 27);
+    const size_t guess = (size_t)(e1 - e0) * n3 * 8; // 7-point rows on a rectilinear mesh, 15 at most on a deformed one
     ti.reserve(guess);
     tj.reserve(guess);
     tv.reserve(guess);
-
-    for (int e = 0; e < num_elements; e++)
+    for (long long e = e0; e < e1; e++)
     {
         const size_t base = (size_t)e * n3;
+        std::fill(K.begin(), K.end(), 0.0);
+        std::fill(touched.begin(), touched.end(), (unsigned char)0);
         for (int sz = 0; sz < N; sz++)
             for (int sy = 0; sy < N; sy++)
                 for (int sx = 0; sx < N; sx++)
@@ -157,18 +219,52 @@ inline HostCSR assemble_fem(const double *x, const double *y, const double *z, c
                             }
                         for (int i = 0; i < 4; i++)
                         {
-                            const int di = point_dof[loc[i]];
-                            if (di < 0) continue;
+                            if (point_dof[loc[i]] < 0) continue;
+                            const int li = (int)(loc[i] - base);
                             for (int j = 0; j < 4; j++)
                             {
-                                const int dj = point_dof[loc[j]];
-                                if (dj < 0 or not(std::abs(At[i][j]) > epsilon)) continue; // :3031
-                                ti.push_back(di);
-                                tj.push_back(dj);
-                                tv.push_back(At[i][j]);
+                                if (point_dof[loc[j]] < 0 or not(std::abs(At[i][j]) > epsilon)) continue; // :3031
+                                const int d0 = tets[t][j][0] - tets[t][i][0], d1 = tets[t][j][1] - tets[t][i][1], d2 = tets[t][j][2] - tets[t][i][2];
+                                const size_t slot = (size_t)li * 27 + (size_t)((d0 + 1) + 3 * (d1 + 1) + 9 * (d2 + 1));
+                                K[slot] += At[i][j];
+                                touched[slot] = 1;
                             }
                         }
                     }
+        // the element's merged entries, row by row, neighbours in ascending local index
+        for (int li = 0; li < n3; li++)
+        {
+            const int di = point_dof[base + li];
+            if (di < 0) continue;
+            for (int s = 0; s < 27; s++)
+            {
+                if (not touched[(size_t)li * 27 + s]) continue;
+                const int lj = li + (s % 3 - 1) + ((s / 3) % 3 - 1) * n + (s / 9 - 1) * n * n;
+                ti.push_back(di);
+                tj.push_back(point_dof[base + lj]);
+                tv.push_back(K[(size_t)li * 27 + s]);
+            }
+        }
+    }
+    pti[part] = std::move(ti);
+    ptj[part] = std::move(tj);
+    ptv[part] = std::move(tv);
+    });
+    std::vector<int> ti, tj;
+    std::vector<double> tv;
+    size_t total = 0;
+    for (int t = 0; t < parts; t++) total += pti[t].size();
+    ti.reserve(total);
+    tj.reserve(total);
+    tv.reserve(total);
+    for (int t = 0; t < parts; t++)
+    {
+        ti.insert(ti.end(), pti[t].begin(), pti[t].end());
+        tj.insert(tj.end(), ptj[t].begin(), ptj[t].end());
+        tv.insert(tv.end(), ptv[t].begin(), ptv[t].end());
+        std::vector<int>().swap(pti[t]);
+        std::vector<int>().swap(ptj[t]);
+        std::vector<double>().swap(ptv[t]);
     }
     return from_triplets(num_dofs, num_dofs, ti, tj, tv);
 }
@@ -180,35 +276,56 @@ inline HostCSR multiply(const HostCSR &A, const HostCSR &B)
     C.rows = A.rows;
     C.cols = B.cols;
     C.ptr.assign(A.rows + 1, 0);
-    std::vector<int> marker(B.cols, -1);
-    std::vector<double> acc(B.cols, 0.0);
-    std::vector<int> cols;
-    for (int i = 0; i < A.rows; i++)
-    {
-        cols.clear();
-        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+    // row ranges in parallel (each with its own accumulator row), pieces concatenated in row order
+    const int parts = range_parts(A.rows);
+    std::vector<std::vector<int>> pcol(parts);
+    std::vector<std::vector<double>> pval(parts);
+    std::vector<int> row_len(A.rows, 0);
+    parallel_ranges(A.rows, parts, [&](long long r0, long long r1, int part) {
+        std::vector<long long> marker(B.cols, -1);
+        std::vector<double> acc(B.cols, 0.0);
+        std::vector<int> cols;
+        std::vector<int> oc; // thread-local while growing, moved out at the end
+        std::vector<double> ov;
+        for (long long i = r0; i < r1; i++)
         {
-            const int k = A.col[p];
-            const double a = A.val[p];
-            for (int q = B.ptr[k]; q < B.ptr[k + 1]; q++)
+            cols.clear();
+            for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
             {
-                const int j = B.col[q];
-                if (marker[j] != i)
+                const int k = A.col[p];
+                const double a = A.val[p];
+                for (int q = B.ptr[k]; q < B.ptr[k + 1]; q++)
                 {
-                    marker[j] = i;
-                    acc[j] = 0.0;
-                    cols.push_back(j);
+                    const int j = B.col[q];
+                    if (marker[j] != i)
+                    {
+                        marker[j] = i;
+                        acc[j] = 0.0;
+                        cols.push_back(j);
+                    }
+                    acc[j] += a * B.val[q];
                 }
-                acc[j] += a * B.val[q];
             }
+            std::sort(cols.begin(), cols.end());
+            for (int j : cols)
+            {
+                oc.push_back(j);
+                ov.push_back(acc[j]);
+            }
+            row_len[i] = (int)cols.size();
         }
-        std::sort(cols.begin(), cols.end());
-        for (int j : cols)
-        {
-            C.col.push_back(j);
-            C.val.push_back(acc[j]);
-        }
-        C.ptr[i + 1] = (int)C.col.size();
+        pcol[part] = std::move(oc);
+        pval[part] = std::move(ov);
+    });
+    for (int i = 0; i < A.rows; i++) C.ptr[i + 1] = C.ptr[i] + row_len[i];
+    C.col.reserve(C.ptr[A.rows]);
+    C.val.reserve(C.ptr[A.rows]);
+    for (int t = 0; t < parts; t++)
+    {
+        C.col.insert(C.col.end(), pcol[t].begin(), pcol[t].end());
+        C.val.insert(C.val.end(), pval[t].begin(), pval[t].end());
+        std::vector<int>().swap(pcol[t]);
+        std::vector<double>().swap(pval[t]);
     }
     return C;
 }
@@ -246,12 +363,14 @@ inline std::vector<double> diagonal(const HostCSR &A)
 inline void spmv(std::vector<double> &y, const HostCSR &A, const std::vector<double> &x)
 {
     y.resize(A.rows);
-    for (int i = 0; i < A.rows; i++)
-    {
-        double s = 0.0;
-        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++) s += A.val[p] * x[A.col[p]];
-        y[i] = s;
-    }
+    parallel_ranges(A.rows, range_parts(A.rows), [&](long long r0, long long r1, int) {
+        for (long long i = r0; i < r1; i++)
+        {
+            double s = 0.0;
+            for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++) s += A.val[p] * x[A.col[p]];
+            y[i] = s;
+        }
+    });
 }
 
 // largest eigenvalue of D A D, D = diag(A)^-1/2, by power iteration from a fixed start

@@ -37,6 +37,7 @@
 #include <cmath>
 #include <map>
 #include <unordered_map>
+#include <chrono>
 #include <vector>
 
 #include "amg.hpp"
@@ -358,8 +359,12 @@ class Subdomain
             exit(EXIT_FAILURE);
         }
         options.cheby_order = cheby_order;
+        const auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = clock();
         fdd::low_order::HostCSR A = fdd::low_order::assemble_fem(fine_mesh->x.data(), fine_mesh->y.data(), fine_mesh->z.data(), point_dof.data(), num_dofs, poly_degree[0], fine_mesh->num_local_elements, epsilon);
+        const double t1 = clock();
         std::vector<fdd::low_order::Level> lv = fdd::low_order::build(std::move(A), options, verbose);
+        const double t2 = clock();
         amg_hierarchy = amg::Hierarchy();
         for (size_t l = 0; l < lv.size(); l++)
         {
@@ -368,6 +373,7 @@ class Subdomain
                           coarsest ? nullptr : lv[l].P.col.data(), coarsest ? nullptr : lv[l].P.val.data());
             lv[l] = fdd::low_order::Level(); // free the host copy as we go
         }
+        if (verbose) printf("low_order: FEM matrix %.2f s, hierarchy %.2f s, levels to the device %.2f s (%d host threads)\n", t1 - t0, t2 - t1, clock() - t2, fdd::low_order::host_threads());
         amg_finalize();
         return (int)amg_hierarchy.levels.size();
     }
