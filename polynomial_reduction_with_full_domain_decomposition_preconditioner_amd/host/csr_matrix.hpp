@@ -93,10 +93,12 @@ class CSR_Matrix
 
         initialization_check();
 
-        std::stable_sort(entries.begin(), entries.end(), [](const std::tuple<int, int, DType> &a, const std::tuple<int, int, DType> &b) {
+        const auto before = [](const std::tuple<int, int, DType> &a, const std::tuple<int, int, DType> &b) {
             if (std::get<0>(a) != std::get<0>(b)) return std::get<0>(a) < std::get<0>(b);
             return std::get<1>(a) < std::get<1>(b);
-        });
+        };
+        // entries added row by row (the scatter matrices Q: one per point) are in order already
+        if (not std::is_sorted(entries.begin(), entries.end(), before)) std::stable_sort(entries.begin(), entries.end(), before);
 
         ptr_hst.assign(num_rows + 1, 0);
         col_hst.clear();
