@@ -31,7 +31,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, E, N, red, with_sub):
+def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -50,7 +50,14 @@ def _worker(rank, world, port, E, N, red, with_sub):
         lib.host().call("fddh_comm_selftest", 1000)  # all-reduce sum/max, all-gather, all-gatherv, barrier
 
         Pg = S.rank_grid(world)
-        p = H.Problem.box(E, Pg, N, red, with_sub)
+        if mesh_dir:
+            # the reference's per-rank input files (<dir>/lx1_<N+1>/<name>_<rank>.<N>.dat), one set per level degree
+            for deg in (S.level_degrees(N, red) if with_sub else [N]):
+                S.write_mesh_files(mesh_dir, S.BoxMesh(E, deg, Pg, rank), proc_id=rank)
+            dist.barrier()
+            p = H.Problem.from_directory(mesh_dir, N, red, with_subdomain=with_sub)
+        else:
+            p = H.Problem.box(E, Pg, N, red, with_sub)
         for lvl in range(p.info["num_levels"]):
             p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
 
@@ -151,3 +158,11 @@ print("ok")
 """ % (S.ROOT, S.HERE, HOST_CPU_SO)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_host_layer_multirank_from_mesh_files(cpu_host_lib, tmp_path):
+    """Two ranks, each reading its own files of the reference's mesh format (domain.tpp:45-224), then the same
+    checks as above against the oracle's 2-rank world."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker, args=(2, _free_port(), (4, 4, 4), 3, 2, True, str(tmp_path / "mesh")), nprocs=2, join=True)
