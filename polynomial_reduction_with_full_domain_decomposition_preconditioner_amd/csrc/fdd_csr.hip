@@ -714,6 +714,11 @@ static int plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows,
         return 0;
     }
 
+    // wide-row blocks hold at most one row per lane: every row's pointers and epilogue operands are then requested
+    // with the block's other loads and nothing is loaded after the barrier (7-entry rows of the AMG's finest level:
+    // V-cycle 2.97 -> 2.90 ms).  FDD_TUNE_CSR_ROW_CAP overrides (development).
+    static const int wide_cap = fdd_env_int("FDD_TUNE_CSR_ROW_CAP", kBlock);
+    const int row_cap = (p->block_nnz == kBlockNnzMax && wide_cap > 0) ? wide_cap : p->block_nnz;
     std::vector<int> blocks;
     blocks.push_back(0);
     int r = 0;
@@ -721,7 +726,7 @@ static int plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows,
     {
         const int base = A_ptr_host[r];
         int e = r;
-        while (e < num_rows && (e - r) < p->block_nnz && A_ptr_host[e + 1] - base <= p->block_nnz) e++;
+        while (e < num_rows && (e - r) < row_cap && A_ptr_host[e + 1] - base <= p->block_nnz) e++;
         if (e == r)
         {
             e = r + 1; // one row longer than a block: workgroup-reduced
