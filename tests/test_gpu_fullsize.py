@@ -87,3 +87,33 @@ def test_manufactured_solution_with_amg_preconditioner(problem):
         out[bits] = (u, its)
     assert abs(out[64][1] - out[32][1]) <= 1
     assert np.abs(out[64][0] - out[32][0]).max() <= 1e-5 * np.abs(u_star).max()
+
+
+# ---- the fp64-MFMA path (N = 15) at the same number of points: 16^3 elements of degree 15 ----
+@pytest.fixture(scope="module")
+def problem15(gpu):
+    H.init(0)
+    H.comm_single()
+    H.set_print(False)
+    p = H.Problem.box((16, 16, 16), (1, 1, 1), 15, RED, True)
+    yield p
+    p.close()
+
+
+def test_mfma_path_properties_and_solve(problem15):
+    """Degree 15 runs the matrix-core stiffness kernel (gather-on-load form inside the solves): the same
+    size-independent properties, and the FDD-preconditioned flexible PCG recovers the manufactured solution."""
+    p = problem15
+    assert p.n == 16**3 * 16**3 and p.info["num_total_nodes"] == 241**3
+    scale = np.abs(p.stiffness(S.seeded_uniform(p.n, 3))).max()
+    assert np.abs(p.stiffness(np.full(p.n, -1.75))).max() <= 1e-11 * scale
+    u, v = S.seeded_uniform(p.n, 11) - 0.5, S.seeded_uniform(p.n, 12) - 0.5
+    us, vs = p.dssum(u, True, True), p.dssum(v, True, True)
+    Aus, Avs = p.stiffness(us, dssum=True), p.stiffness(vs, dssum=True)
+    wgt = 1.0 / p.mesh_array("node_degree")
+    uAv, vAu, uAu = np.dot(us * wgt, Avs), np.dot(vs * wgt, Aus), np.dot(us * wgt, Aus)
+    assert uAu > 0 and abs(uAv - vAu) <= 1e-11 * uAu
+    u_star, f = p.make_rhs_from(S.seeded_uniform(p.n, 1234))
+    x, its, hist = p.solve(f, "fcg")
+    assert 0 < its < 500 and hist[-1] <= 1e-7 * hist[0] * 1.0001, (its, hist[-1] / hist[0])
+    assert np.abs(x - u_star).max() <= 1e-3 * np.abs(u_star).max()  # 1e-7 on the residual of an operator of condition ~1e4
