@@ -40,6 +40,11 @@ typedef int (*fddh_allreduce_fn)(void *ctx, void *buf, long long n);
 typedef int (*fddh_allgather_fn)(void *ctx, const void *send, void *recv, long long bytes);
 typedef int (*fddh_barrier_fn)(void *ctx);
 int fddh_comm_callbacks(int rank, int size, void *ctx, fddh_allreduce_fn allreduce_sum_f64, fddh_allreduce_fn allreduce_max_f64, fddh_allgather_fn allgather_bytes, fddh_barrier_fn barrier);
+/* The same with the point-to-point exchange the composite region needs (the reference's gslib pull of neighbour
+ * elements, subdomain.tpp:601-642, 4626): one grouped call, n peers; send_bytes[i] from send[i] go to peers[i] and
+ * recv_bytes[i] from peers[i] arrive in recv[i] (device buffers of this rank; either side may be 0). */
+typedef int (*fddh_exchange_fn)(void *ctx, int n, const int *peers, const void *const *send, const long long *send_bytes, void *const *recv, const long long *recv_bytes);
+int fddh_comm_callbacks_ex(int rank, int size, void *ctx, fddh_allreduce_fn allreduce_sum_f64, fddh_allreduce_fn allreduce_max_f64, fddh_allgather_fn allgather_bytes, fddh_barrier_fn barrier, fddh_exchange_fn exchange_bytes);
 int fddh_comm_info(int *rank, int *size, char *name, size_t name_len);
 /* run every collective of the active communicator once on n doubles and verify the results */
 int fddh_comm_selftest(int n);
@@ -53,6 +58,19 @@ typedef struct fddh_problem fddh_problem;
 int fddh_problem_create_box(fddh_problem **out, const int E[3], const int P[3], int poly_degree, int poly_reduction, int with_subdomain);
 /* Nek5000-export directory, the reference's input (poisson.cpp:61-68, domain.tpp:45-224) */
 int fddh_problem_create_dir(fddh_problem **out, const char *directory, int poly_degree, int poly_reduction, int subdomain_overlap, int superdomain_overlap, int with_subdomain);
+/* The same with the reference's overlap arguments (poisson.cpp:61-68) and construction flags:
+ *   FDDH_WITH_SUBDOMAIN    build the Subdomain preconditioner
+ *   FDDH_BLOCK_LOCAL       more than one rank: keep every rank's own elements only (no neighbour rings, no
+ *                          superdomain): block-Jacobi, the comparison point of the full-domain-decomposition method
+ *   FDDH_FORCE_COMPOSITE   build the region through the composite setup even on one rank (test hook) */
+enum
+{
+    FDDH_WITH_SUBDOMAIN = 1,
+    FDDH_BLOCK_LOCAL = 2,
+    FDDH_FORCE_COMPOSITE = 4
+};
+int fddh_problem_create_box_ex(fddh_problem **out, const int E[3], const int P[3], int poly_degree, int poly_reduction, int subdomain_overlap, int superdomain_overlap, int flags);
+int fddh_problem_create_dir_ex(fddh_problem **out, const char *directory, int poly_degree, int poly_reduction, int subdomain_overlap, int superdomain_overlap, int flags);
 int fddh_problem_destroy(fddh_problem *p);
 /* write the box mesh of this rank as the reference's file set under `directory` */
 int fddh_write_box_mesh_files(const char *directory, const int E[3], const int P[3], int poly_degree, int rank);
@@ -75,6 +93,31 @@ enum
 };
 int fddh_problem_info(const fddh_problem *p, long long *info, int n);
 int fddh_problem_level_degree(const fddh_problem *p, int level, int *poly_degree);
+
+/* The composite region of this rank (subdomain.tpp:455-579, 2581-2583) */
+enum
+{
+    FDDH_SUB_IS_COMPOSITE = 0,   /* 1: rings + superdomain (more than one rank), 0: the rank's own conforming elements */
+    FDDH_SUB_NUM_ELEMS,          /* own + ring elements */
+    FDDH_SUB_NUM_EXT_ELEMS,      /* + the extended ring */
+    FDDH_SUB_NUM_POINTS,         /* points of all of them = head of a composite vector */
+    FDDH_SUB_NUM_SUB_DOFS,       /* subdomain dofs: regular + interface */
+    FDDH_SUB_NUM_SUB_EXT_DOFS,   /* + extended */
+    FDDH_SUB_NUM_INTERFACE_DOFS,
+    FDDH_SUB_NUM_SUP_DOFS,       /* superdomain dofs: interface + regular */
+    FDDH_SUB_NUM_SUP_EXT_DOFS,   /* + extended = tail of a composite vector */
+    FDDH_SUB_NUM_UNIQUE_DOFS,    /* Subdomain::num_dofs */
+    FDDH_SUB_NUM_COARSE_DOFS,    /* degree-1 dofs of the whole domain */
+    FDDH_SUB_NUM_VALUES,
+    FDDH_SUB_OWN_POINTS,
+    FDDH_SUB_NUM_PEERS,          /* ranks this one exchanges ring data with */
+    FDDH_SUB_INFO_COUNT
+};
+int fddh_problem_sub_info(const fddh_problem *p, long long *info, int n);
+/* global element id and polynomial level of every region element (FDDH_SUB_NUM_EXT_ELEMS entries) */
+int fddh_problem_sub_region(const fddh_problem *p, int *element, int *level, int n);
+/* composite dofs kept per coarsening level of the superdomain (at most n values; *num_levels receives the count) */
+int fddh_problem_sub_composite_levels(const fddh_problem *p, int *kept, int n, int *num_levels);
 
 /* mesh arrays of a level as Domain::initialize holds them: name in
  * {"x","y","z","glo_num"(int64),"node_degree"(int32),"p_mask","g_1".."g_6"} */
@@ -151,7 +194,8 @@ int fddh_problem_solve(fddh_problem *p, int solver_id, const double *f, double *
 /* Subdomain (preconditioner) operations; type 0 = flexible_conjugate_gradient,
  * 1 = generalized_minimum_residual */
 int fddh_problem_precond_apply(fddh_problem *p, int type, const double *r, double *z, double *history, int history_cap, int *num_history);
-/* op 0 = tree_operator, 1 = stiffness_matrix, 2 = direct_stiffness_summation; in/out of sub_num_values */
+/* op 0 = tree_operator (in: an outer vector of num_local_points; collective on a composite region),
+ * 1 = stiffness_matrix, 2 = direct_stiffness_summation; in/out of sub_num_values = [region points | superdomain dofs] */
 int fddh_problem_sub_op(fddh_problem *p, int op, const double *in, double *out);
 int fddh_problem_sub_residual_norm(fddh_problem *p, const double *r, double *norm);
 

@@ -215,6 +215,31 @@ int orc_subdomain_gmres(orc_subdomain *s, double *u_l, const double *f_l, const 
 int orc_subdomain_fcg(orc_subdomain *s, double *u_l, const double *f_l, const orc_subdomain_opts *opts, double *history, int history_cap, int *num_hist);
 
 /* ------------------------------------------------------------------ */
+/* The full-domain-decomposition composite (subdomain.tpp:86-2747) of    */
+/* every rank of an R-rank run, and the exchange half of tree_operator   */
+/* (subdomain.tpp:4613-4645): fdd_oracle_composite.c                     */
+/* ------------------------------------------------------------------ */
+typedef struct orc_fdd orc_fdd;
+/* meshes[rank * num_levels + level]: rank's mesh at degree poly_degree[level];
+ * J_cf_pairs[l_f * num_levels + l_c] (l_f < l_c): interpolator from level l_c to
+ * level l_f, n_f x n_c row-major (subdomain.tpp:142-164) */
+orc_fdd *orc_fdd_create(int num_ranks, int num_levels, const int *poly_degree, const double *const *D_hat, const double *const *J_cf_pairs, const orc_mesh *meshes, int subdomain_overlap, int superdomain_overlap);
+void orc_fdd_destroy(orc_fdd *F);
+orc_subdomain *orc_fdd_subdomain(orc_fdd *F, int rank); /* the rank's composite: orc_subdomain_stiffness / _dssum / _residual_norm apply */
+/* info[12]: sub elems, sub extended elems, points, sub dofs, sub extended dofs, interface dofs, sup dofs,
+ * sup extended dofs, unique dofs, coarse dofs, num_values, own points */
+void orc_fdd_info(const orc_fdd *F, int rank, int *info);
+void orc_fdd_region(const orc_fdd *F, int rank, int *id, int *level); /* global element and level of every region element */
+const int *orc_fdd_composite_levels(const orc_fdd *F, int rank);       /* composite dofs per coarsening level, -1 terminated */
+/* which: 0 Q, 1 Qt, 2 Q_int, 3 Qt_int, 4 QQt_int, 5 superdomain A, 6 superdomain Pt, 7 Qt_coarse */
+const orc_csr *orc_fdd_matrix(const orc_fdd *F, int rank, int which);
+const double *orc_fdd_norm_weight(const orc_fdd *F, int rank);  /* sub extended + sup extended dofs */
+const double *orc_fdd_inner_weight(const orc_fdd *F, int rank); /* num_values */
+void orc_fdd_tree_operator(orc_fdd *F, double *const *Tu, const double *const *u);
+/* z = M^-1 r on every rank; method 0 flexible CG, 1 GMRES; history: num_ranks rows of history_cap */
+void orc_fdd_precondition(orc_fdd *F, double *const *z, const double *const *r, int method, const orc_subdomain_opts *opts, double *history, int history_cap, int *num_hist);
+
+/* ------------------------------------------------------------------ */
 /* Low-order AMG V-cycle given a hierarchy (subdomain.tpp:19-83,        */
 /* 3987-4159); the hierarchy itself comes from HYPRE in the reference   */
 /* and is an input here (fdd_oracle_amg.c)                              */

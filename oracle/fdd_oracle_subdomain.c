@@ -32,53 +32,12 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct
-{
-    int num_points;
-    int num_elements;
-    int poly_degree;
-    int offset;
-} orc_level; /* subdomain.hpp:89-95 */
+#include "fdd_oracle_priv.h"
 
-struct orc_subdomain
-{
-    int dim;
-    int num_levels;
-    int *poly_degree;
-    orc_level *levels;
+void *orc_xcalloc(size_t n, size_t sz);
+static void *xcalloc(size_t n, size_t sz) { return orc_xcalloc(n, sz); }
 
-    double **D_hat; /* per level */
-    double **J_cf;  /* J_cf[l]: level l+1 (coarse) -> level l (fine), n_f x n_c */
-
-    /* subdomain_operator (subdomain.hpp:46-70) */
-    int num_points;
-    int num_dofs;
-    int num_extended_dofs;
-    orc_csr Q, Qt;
-    double *geom_fact[ORC_NUM_GEOM_FACTS];
-    int *offset, *vertex, *level;
-
-    /* superdomain_operator: empty in this configuration */
-    int sup_num_extended_dofs;
-
-    orc_csr Qt_coarse;
-    orc_csr Q_int, Qt_int, QQt_int;
-
-    double *norm_weight;
-    double *inner_weight;
-
-    int num_values;
-    int num_blocks;
-
-    double *work[3];
-    double *f, *u_k, *r_k, *r_kp1, *q_k, *z_k, *p_k;
-    double **V, **Z;
-    int cap_vectors;
-
-    orc_amg *amg; /* low-order preconditioner hierarchy (not owned) */
-};
-
-static void *xcalloc(size_t n, size_t sz)
+void *orc_xcalloc(size_t n, size_t sz)
 {
     void *p = calloc(n ? n : 1, sz);
     if (!p)
@@ -104,8 +63,10 @@ static int rank_cmp_val(const void *a_, const void *b_)
     return (a->idx < b->idx) ? -1 : (a->idx > b->idx);
 }
 
+static void ranking(double *data, int size) { orc_ranking(data, size); }
+
 /* ranking lambda, subdomain.tpp:881-918: dense ranks, 0 stays 0 */
-static void ranking(double *data, int size)
+void orc_ranking(double *data, int size)
 {
     if (size == 0) return;
 
@@ -313,7 +274,16 @@ orc_subdomain *orc_subdomain_create(int num_levels, const int *poly_degree, cons
 
     /* work arrays hold the whole tree (subdomain.tpp:588-595) */
     size_t tree = (size_t)s->levels[num_levels - 1].offset + (size_t)s->levels[num_levels - 1].num_points;
-    size_t wsize = tree + (size_t)P + 16;
+    s->own_points = s->levels[0].num_points;
+    s->num_unique_dofs = num_dofs;
+    orc_subdomain_alloc_solver(s, tree + (size_t)P + 16);
+
+    return s;
+}
+
+/* solver vectors (subdomain.tpp:3860-3873) and work arrays */
+void orc_subdomain_alloc_solver(orc_subdomain *s, size_t wsize)
+{
     for (int w = 0; w < 3; w++) s->work[w] = (double *)xcalloc(wsize, sizeof(double));
 
     size_t nv = (size_t)s->num_values;
@@ -327,8 +297,6 @@ orc_subdomain *orc_subdomain_create(int num_levels, const int *poly_degree, cons
     s->cap_vectors = 0;
     s->V = NULL;
     s->Z = NULL;
-
-    return s;
 }
 
 void orc_subdomain_destroy(orc_subdomain *s)
@@ -349,6 +317,8 @@ void orc_subdomain_destroy(orc_subdomain *s)
     orc_csr_free(&s->Q_int);
     orc_csr_free(&s->Qt_int);
     orc_csr_free(&s->QQt_int);
+    orc_csr_free(&s->sup_A);
+    orc_csr_free(&s->sup_Pt);
     for (int g = 0; g < ORC_NUM_GEOM_FACTS; g++) free(s->geom_fact[g]);
     free(s->offset);
     free(s->vertex);
@@ -379,6 +349,13 @@ int orc_subdomain_num_dofs(const orc_subdomain *s) { return s->num_dofs; }
 void orc_subdomain_tree_operator(orc_subdomain *s, double *Tu, const double *u)
 {
     int dim = s->dim;
+
+    if (s->tree_done)
+    {
+        /* composite region: the tree was built and exchanged for all ranks at once (orc_fdd_tree_operator) */
+        if (Tu != s->f) memcpy(Tu, s->f, (size_t)s->num_values * sizeof(double));
+        return;
+    }
 
     /* fill up tree: cast copy of the outer vector (subdomain.tpp:4571) */
     orc_sub_copy_f64_f64(s->work[0], u, s->levels[0].num_points);
@@ -433,7 +410,9 @@ void orc_subdomain_stiffness(orc_subdomain *s, double *Au, const double *u)
     double *GDu[3] = {s->work[0], s->work[1], s->work[2]};
     const double *G[6] = {s->geom_fact[0], s->geom_fact[1], s->geom_fact[2], s->geom_fact[3], s->geom_fact[4], s->geom_fact[5]};
 
-    /* superdomain_operator.A.multiply: empty matrix, no-op */
+    /* superdomain_operator.A.multiply on the tail (subdomain.tpp:3951); an empty matrix is a no-op */
+    if (s->sup_num_extended_dofs > 0 && s->sup_A.num_nnz > 0)
+        orc_csr_multiply(Au + s->num_points, s->sup_A.ptr, s->sup_A.col, s->sup_A.val, u + s->num_points, s->sup_A.num_rows);
 
     orc_sub_stiffness_matrix_1(GDu, u, (const double *const *)s->D_hat, s->offset, s->vertex, s->level, s->poly_degree, G, s->num_points, s->dim);
     orc_sub_stiffness_matrix_2(Au, (const double *const *)GDu, (const double *const *)s->D_hat, s->offset, s->vertex, s->level, s->poly_degree, s->num_points, s->dim);
@@ -443,14 +422,17 @@ void orc_subdomain_stiffness(orc_subdomain *s, double *Au, const double *u)
 void orc_subdomain_dssum(orc_subdomain *s, double *QQtu, const double *u)
 {
     orc_csr_multiply(s->work[0], s->Qt.ptr, s->Qt.col, s->Qt.val, u, s->Qt.num_rows);
+    memcpy(s->work[0] + s->num_extended_dofs, u + s->num_points, (size_t)s->sup_num_extended_dofs * sizeof(double)); /* :3977 */
     orc_csr_multiply(s->work[1], s->QQt_int.ptr, s->QQt_int.col, s->QQt_int.val, s->work[0], s->QQt_int.num_rows);
     orc_csr_multiply(QQtu, s->Q.ptr, s->Q.col, s->Q.val, s->work[1], s->Q.num_rows);
+    memcpy(QQtu + s->num_points, s->work[1] + s->num_extended_dofs, (size_t)s->sup_num_extended_dofs * sizeof(double)); /* :3984 */
 }
 
 /* subdomain.tpp:4491-4515 */
 double orc_subdomain_residual_norm(orc_subdomain *s, const double *r)
 {
     orc_csr_multiply_weight(s->work[1], s->Qt.ptr, s->Qt.col, s->Qt.val, r, s->norm_weight, s->Qt.num_rows);
+    memcpy(s->work[1] + s->num_extended_dofs, r + s->num_points, (size_t)s->sup_num_extended_dofs * sizeof(double)); /* :4501 */
 
     int num_values = s->num_extended_dofs + s->sup_num_extended_dofs;
     int num_blocks = (num_values + ORC_BLOCK_SIZE - 1) / ORC_BLOCK_SIZE;
@@ -464,7 +446,9 @@ double orc_subdomain_residual_norm(orc_subdomain *s, const double *r)
 static double assembled_inner_product(orc_subdomain *s, const double *u, const double *v)
 {
     orc_csr_multiply_weight(s->work[0], s->Qt.ptr, s->Qt.col, s->Qt.val, u, s->norm_weight, s->Qt.num_rows);
+    memcpy(s->work[0] + s->num_extended_dofs, u + s->num_points, (size_t)s->sup_num_extended_dofs * sizeof(double)); /* :4286 */
     orc_csr_multiply_weight(s->work[1], s->Qt.ptr, s->Qt.col, s->Qt.val, v, s->norm_weight, s->Qt.num_rows);
+    memcpy(s->work[1] + s->num_extended_dofs, v + s->num_points, (size_t)s->sup_num_extended_dofs * sizeof(double)); /* :4294 */
 
     int num_values = s->num_extended_dofs + s->sup_num_extended_dofs;
     int num_blocks = (num_values + ORC_BLOCK_SIZE - 1) / ORC_BLOCK_SIZE;
@@ -485,16 +469,18 @@ void orc_subdomain_point_dofs(const orc_subdomain *s, int *dof)
 /* subdomain.tpp:3987-4159 on the conforming composite: Qt_int = Q_int = I, empty tail */
 void orc_subdomain_low_order_preconditioner(orc_subdomain *s, double *z, const double *r)
 {
-    if (!s->amg || orc_amg_level_size(s->amg, 0) != s->num_dofs)
+    if (!s->amg || orc_amg_level_size(s->amg, 0) != s->num_unique_dofs)
     {
-        fprintf(stderr, "fdd_oracle: low_order_preconditioner needs an attached AMG hierarchy over the %d dofs\n", s->num_dofs);
+        fprintf(stderr, "fdd_oracle: low_order_preconditioner needs an attached AMG hierarchy over the %d dofs\n", s->num_unique_dofs);
         abort();
     }
     orc_csr_multiply(s->work[0], s->Qt.ptr, s->Qt.col, s->Qt.val, r, s->Qt.num_rows);                        /* :3996 */
+    memcpy(s->work[0] + s->num_extended_dofs, r + s->num_points, (size_t)s->sup_num_extended_dofs * sizeof(double)); /* :4000 */
     orc_csr_multiply(s->work[1], s->Qt_int.ptr, s->Qt_int.col, s->Qt_int.val, s->work[0], s->Qt_int.num_rows); /* :4004 */
     orc_amg_vcycle(s->amg, s->work[2], s->work[1]);                                                            /* :4008-4142 */
     orc_csr_multiply(s->work[0], s->Q_int.ptr, s->Q_int.col, s->Q_int.val, s->work[2], s->Q_int.num_rows);     /* :4146 */
     orc_csr_multiply(z, s->Q.ptr, s->Q.col, s->Q.val, s->work[0], s->Q.num_rows);                              /* :4153 */
+    memcpy(z + s->num_points, s->work[0] + s->num_extended_dofs, (size_t)s->sup_num_extended_dofs * sizeof(double)); /* :4157 */
 }
 
 static void apply_inner_preconditioner(orc_subdomain *s, const orc_subdomain_opts *opts, double *z, const double *r)

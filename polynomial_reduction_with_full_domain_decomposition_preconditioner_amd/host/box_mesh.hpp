@@ -70,6 +70,12 @@ MeshData<DType> make_box_mesh(const BoxSpec &spec, int N, int rank)
 
     auto mult = [&](long long g, long long G) -> int { return (g % N == 0 && g > 0 && g < G - 1) ? 2 : 1; };
 
+    // Global node ids the way Nek5000 hands them out: the element VERTICES first, 1..V in lexicographic order of
+    // the (Ex+1)(Ey+1)(Ez+1) vertex grid -- the same ids at every polynomial degree, which is what lets elements of
+    // different degree share their corners in the composite region (subdomain.tpp:930-966 restores the corner ids
+    // after the per-level offset) -- then every other node, lexicographic on the degree-N grid.
+    const long long V = (long long)(Ex + 1) * (Ey + 1) * (Ez + 1);
+
     size_t p = 0;
     for (int ez = 0; ez < lz; ez++)
         for (int ey = 0; ey < ly; ey++)
@@ -81,7 +87,10 @@ MeshData<DType> make_box_mesh(const BoxSpec &spec, int N, int rank)
                         for (int i = 0; i < n; i++, p++)
                         {
                             const long long gi = EX * N + i, gj = EY * N + j, gk = EZ * N + k;
-                            m.glo_num[p] = 1 + gi + Gx * (gj + Gy * gk);
+                            if (gi % N == 0 && gj % N == 0 && gk % N == 0)
+                                m.glo_num[p] = 1 + gi / N + (long long)(Ex + 1) * (gj / N + (long long)(Ey + 1) * (gk / N));
+                            else
+                                m.glo_num[p] = V + 1 + gi + Gx * (gj + Gy * gk);
                             m.node_degree[p] = mult(gi, Gx) * mult(gj, Gy) * mult(gk, Gz);
                             const bool bd = gi == 0 || gi == Gx - 1 || gj == 0 || gj == Gy - 1 || gk == 0 || gk == Gz - 1;
                             m.p_mask[p] = bd ? 0.0 : 1.0;

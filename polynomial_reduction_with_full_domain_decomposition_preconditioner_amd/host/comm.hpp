@@ -16,6 +16,12 @@
  * gs_add becomes: scatter the prefix into a dense interface-slot vector,
  * all-reduce it, gather back (slots = sorted unique global ids that appear in
  * any rank's prefix).
+ * The fourth exchange of the reference, the gslib "pull" of neighbour elements
+ * at reduced degree into a rank's composite region (subdomain.tpp:601-642,
+ * 4626), is a grouped send / receive between the ranks whose regions overlap:
+ * Comm::exchange, one packed device buffer per peer and direction
+ * (ncclSend/ncclRecv inside one group on xGMI; torch.distributed
+ * batch_isend_irecv behind the callbacks).
  */
 #ifndef FDD_COMM_HPP
 #define FDD_COMM_HPP
@@ -24,12 +30,33 @@
 
 #include <algorithm>
 #include <cstring>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "fdd_device.hpp"
 
 namespace fdd
 {
+
+// A failed collective does not end the process from inside the library: it throws, the C-ABI entry that was running
+// returns non-zero and fddh_last_error() has the text (the driver prints it and exits with a failure code).
+struct CommError : public std::runtime_error
+{
+    explicit CommError(const std::string &what) : std::runtime_error(what) {}
+};
+
+// one peer of a grouped point-to-point exchange: `send_bytes` from `send` go to `peer`, `recv_bytes` arrive from it
+// in `recv` (device buffers; either side may be empty).  A peer appears at most once per call and is never the
+// calling rank.
+struct ExchangeOp
+{
+    int peer = 0;
+    const void *send = nullptr;
+    size_t send_bytes = 0;
+    void *recv = nullptr;
+    size_t recv_bytes = 0;
+};
 
 class Comm
 {
@@ -45,7 +72,62 @@ class Comm
     virtual void allreduce_max(double *buf_dev, size_t n) = 0;
     // every rank contributes `bytes` from send_dev; recv_dev gets size*bytes in rank order
     virtual void allgather(const void *send_dev, void *recv_dev, size_t bytes) = 0;
+    // grouped sends and receives on device buffers, ordered on the rank's stream like the collectives
+    virtual void exchange(const ExchangeOp *ops, int n) = 0;
     virtual void barrier() = 0;
+
+    // Point-to-point exchange of host byte strings (setup only): out[p] goes to rank p, the result holds what every
+    // rank sent to this one.  Sizes are agreed on first (a dense size x size count matrix: setup runs at rank counts
+    // where that is small); messages are staged through device scratch.
+    std::vector<std::vector<char>> exchange_host(const std::vector<std::vector<char>> &out)
+    {
+        std::vector<std::vector<char>> in(size);
+        if (size == 1)
+        {
+            in[0] = out[0];
+            return in;
+        }
+        std::vector<double> counts((size_t)size * size, 0.0);
+        for (int p = 0; p < size; p++) counts[(size_t)rank * size + p] = (double)out[p].size();
+        allreduce_sum_host(counts.data(), counts.size());
+        in[rank] = out[rank];
+        std::vector<ExchangeOp> ops;
+        std::vector<memory> sbuf(size), rbuf(size);
+        for (int p = 0; p < size; p++)
+        {
+            if (p == rank) continue;
+            const size_t ns = out[p].size(), nr = (size_t)counts[(size_t)p * size + rank];
+            if (ns == 0 and nr == 0) continue;
+            ExchangeOp op;
+            op.peer = p;
+            if (ns)
+            {
+                sbuf[p] = dev().malloc<char>(ns);
+                sbuf[p].copyFrom(out[p].data(), ns);
+                op.send = sbuf[p].ptr();
+                op.send_bytes = ns;
+            }
+            if (nr)
+            {
+                rbuf[p] = dev().malloc<char>(nr);
+                op.recv = rbuf[p].ptr();
+                op.recv_bytes = nr;
+            }
+            ops.push_back(op);
+        }
+        if (not ops.empty()) exchange(ops.data(), (int)ops.size());
+        for (const ExchangeOp &op : ops)
+        {
+            if (op.recv_bytes)
+            {
+                in[op.peer].resize(op.recv_bytes);
+                rbuf[op.peer].copyTo(in[op.peer].data(), op.recv_bytes);
+                rbuf[op.peer].free();
+            }
+            if (op.send_bytes) sbuf[op.peer].free();
+        }
+        return in;
+    }
 
     // ---- host-side helpers for setup (tiny, staged through device scratch) ----
     void allreduce_sum_host(double *v, size_t n)
@@ -117,6 +199,10 @@ class SingleComm : public Comm
     {
         if (send_dev != recv_dev) FDD_CALL(fdd_memcpy_d2d(recv_dev, send_dev, bytes, dev().stream));
     }
+    void exchange(const ExchangeOp *, int n) override
+    {
+        if (n > 0) throw CommError("point-to-point exchange on a single-rank communicator");
+    }
     void barrier() override {}
 };
 
@@ -131,6 +217,8 @@ struct CommCallbacks
     int (*allreduce_max_f64)(void *ctx, void *buf, long long n);
     int (*allgather_bytes)(void *ctx, const void *send, void *recv, long long bytes);
     int (*barrier)(void *ctx);
+    // n peers: send_bytes[i] from send[i] to peers[i], recv_bytes[i] from peers[i] into recv[i] (one group)
+    int (*exchange_bytes)(void *ctx, int n, const int *peers, const void *const *send, const long long *send_bytes, void *const *recv, const long long *recv_bytes);
 };
 
 class CallbackComm : public Comm
@@ -139,11 +227,7 @@ class CallbackComm : public Comm
 
     static void ok(int rc, const char *what)
     {
-        if (rc != 0)
-        {
-            fprintf(stderr, "ERROR: communication callback %s failed (code %d)\n", what, rc);
-            exit(EXIT_FAILURE);
-        }
+        if (rc != 0) throw CommError(std::string("communication callback ") + what + " failed (code " + std::to_string(rc) + ")");
     }
 
   public:
@@ -156,6 +240,24 @@ class CallbackComm : public Comm
     void allreduce_sum(double *buf, size_t n) override { ok(cb_.allreduce_sum_f64(cb_.ctx, buf, (long long)n), "allreduce_sum_f64"); }
     void allreduce_max(double *buf, size_t n) override { ok(cb_.allreduce_max_f64(cb_.ctx, buf, (long long)n), "allreduce_max_f64"); }
     void allgather(const void *send, void *recv, size_t bytes) override { ok(cb_.allgather_bytes(cb_.ctx, send, recv, (long long)bytes), "allgather_bytes"); }
+    void exchange(const ExchangeOp *ops, int n) override
+    {
+        if (n <= 0) return;
+        if (not cb_.exchange_bytes) throw CommError("the communication callbacks have no exchange_bytes entry (needed by the composite region)");
+        std::vector<int> peers(n);
+        std::vector<const void *> sp(n);
+        std::vector<void *> rp(n);
+        std::vector<long long> sb(n), rb(n);
+        for (int i = 0; i < n; i++)
+        {
+            peers[i] = ops[i].peer;
+            sp[i] = ops[i].send;
+            sb[i] = (long long)ops[i].send_bytes;
+            rp[i] = ops[i].recv;
+            rb[i] = (long long)ops[i].recv_bytes;
+        }
+        ok(cb_.exchange_bytes(cb_.ctx, n, peers.data(), sp.data(), sb.data(), rp.data(), rb.data()), "exchange_bytes");
+    }
     void barrier() override { ok(cb_.barrier(cb_.ctx), "barrier"); }
 };
 
@@ -175,6 +277,8 @@ class RcclComm : public Comm
     typedef int (*CommDestroy_t)(void *);
     typedef int (*AllReduce_t)(const void *, void *, size_t, int, int, void *, void *);
     typedef int (*AllGather_t)(const void *, void *, size_t, int, void *, void *);
+    typedef int (*SendRecv_t)(void *, size_t, int, int, void *, void *); // ncclSend (const buffer) / ncclRecv
+    typedef int (*Group_t)(void);
     typedef const char *(*GetErrorString_t)(int);
 
     void *lib_ = nullptr;
@@ -185,6 +289,8 @@ class RcclComm : public Comm
     CommDestroy_t comm_destroy_ = nullptr;
     AllReduce_t all_reduce_ = nullptr;
     AllGather_t all_gather_ = nullptr;
+    SendRecv_t send_ = nullptr, recv_ = nullptr;
+    Group_t group_start_ = nullptr, group_end_ = nullptr;
     GetErrorString_t get_error_string_ = nullptr;
 
     enum
@@ -197,11 +303,7 @@ class RcclComm : public Comm
 
     void ok(int rc, const char *what)
     {
-        if (rc != 0)
-        {
-            fprintf(stderr, "ERROR: RCCL %s failed: %s\n", what, get_error_string_ ? get_error_string_(rc) : "?");
-            exit(EXIT_FAILURE);
-        }
+        if (rc != 0) throw CommError(std::string("RCCL ") + what + " failed: " + (get_error_string_ ? get_error_string_(rc) : "?"));
     }
 
     void load()
@@ -213,22 +315,19 @@ class RcclComm : public Comm
             lib_ = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (lib_) break;
         }
-        if (!lib_)
-        {
-            fprintf(stderr, "ERROR: cannot load librccl: %s\n", dlerror());
-            exit(EXIT_FAILURE);
-        }
+        if (!lib_) throw CommError(std::string("cannot load librccl: ") + dlerror());
         get_unique_id_ = (GetUniqueId_t)dlsym(lib_, "ncclGetUniqueId");
         comm_init_rank_ = (CommInitRank_t)dlsym(lib_, "ncclCommInitRank");
         comm_destroy_ = (CommDestroy_t)dlsym(lib_, "ncclCommDestroy");
         all_reduce_ = (AllReduce_t)dlsym(lib_, "ncclAllReduce");
         all_gather_ = (AllGather_t)dlsym(lib_, "ncclAllGather");
+        send_ = (SendRecv_t)dlsym(lib_, "ncclSend");
+        recv_ = (SendRecv_t)dlsym(lib_, "ncclRecv");
+        group_start_ = (Group_t)dlsym(lib_, "ncclGroupStart");
+        group_end_ = (Group_t)dlsym(lib_, "ncclGroupEnd");
         get_error_string_ = (GetErrorString_t)dlsym(lib_, "ncclGetErrorString");
-        if (!get_unique_id_ || !comm_init_rank_ || !all_reduce_ || !all_gather_)
-        {
-            fprintf(stderr, "ERROR: librccl lacks a required entry point\n");
-            exit(EXIT_FAILURE);
-        }
+        if (!get_unique_id_ || !comm_init_rank_ || !all_reduce_ || !all_gather_ || !send_ || !recv_ || !group_start_ || !group_end_)
+            throw CommError("librccl lacks a required entry point");
     }
 
   public:
@@ -260,6 +359,18 @@ class RcclComm : public Comm
     void allreduce_sum(double *buf, size_t n) override { ok(all_reduce_(buf, buf, n, kFloat64, kSum, comm_, dev().stream), "ncclAllReduce"); }
     void allreduce_max(double *buf, size_t n) override { ok(all_reduce_(buf, buf, n, kFloat64, kMax, comm_, dev().stream), "ncclAllReduce"); }
     void allgather(const void *send, void *recv, size_t bytes) override { ok(all_gather_(send, recv, bytes, kInt8, comm_, dev().stream), "ncclAllGather"); }
+    // one group: every send and receive of the call progresses together over the xGMI links (all peers are one hop)
+    void exchange(const ExchangeOp *ops, int n) override
+    {
+        if (n <= 0) return;
+        ok(group_start_(), "ncclGroupStart");
+        for (int i = 0; i < n; i++)
+        {
+            if (ops[i].send_bytes) ok(send_(const_cast<void *>(ops[i].send), ops[i].send_bytes, kInt8, ops[i].peer, comm_, dev().stream), "ncclSend");
+            if (ops[i].recv_bytes) ok(recv_(ops[i].recv, ops[i].recv_bytes, kInt8, ops[i].peer, comm_, dev().stream), "ncclRecv");
+        }
+        ok(group_end_(), "ncclGroupEnd");
+    }
     void barrier() override
     {
         FDD_CALL(fdd_memset(token_.ptr(), 0, sizeof(double), dev().stream));

@@ -6,15 +6,22 @@
  * their local reductions -- no communication inside the inner solve, which is
  * the FDD property.
  *
- * SCOPE OF THE COMPOSITE SETUP.  The reference's constructor
- * (subdomain.tpp:86-3705) builds, with HYPRE BoomerAMG internals, a composite
- * of: own elements at degree N, rings of neighbour elements at reduced degree,
- * and an AMG-coarsened superdomain.  That setup is out of scope this round
- * (SURVEY.md 2a, 8(f) next-1).  This class builds the operators the reference
- * constructor produces when the subdomain region holds only the rank's own
- * conforming elements: exact for single-rank runs (configs C1-C3); for
- * multi-rank runs it is the "block-local" preconditioner named in SURVEY.md
- * 8(e) (no rings, no superdomain -- labelled as such wherever reported).
+ * THE COMPOSITE.  The reference's constructor (subdomain.tpp:86-3705) builds a
+ * composite of: own elements at degree N, rings of neighbour elements at
+ * reduced degree, and an algebraically coarsened superdomain.  With more than
+ * one rank that composite is built by composite.hpp (regions, ring-data pull,
+ * non-conforming Q with J_cf rows, superdomain A / Pt, interface maps, weights)
+ * and this class runs the reference's solve path on it: tree_operator with its
+ * exchange half (ring pull by grouped send / receive, coarse level by
+ * all-gather, Qt_coarse, Pt), mixed-degree stiffness on level-sorted element
+ * lists plus the CSR tail, the Q / QQt_int / Qt chain, weighted norms.  The one
+ * labelled deviation: the superdomain is graded by this build's own smoothed
+ * aggregation where the reference walks HYPRE BoomerAMG's hierarchy
+ * (composite.hpp).  `block_local = true` keeps the rank's own elements only
+ * (no rings, no superdomain: block-Jacobi, kept as the comparison point).
+ *
+ * With one rank the region holds the rank's own conforming elements and the
+ * constructor reduces to:
  *   - dof_num = dense rank of glo_num*mask, 0 on Dirichlet points
  *     (ranking lambda subdomain.tpp:881-918, applied at :1151-1176);
  *   - Q one 1.0 per non-Dirichlet point (subdomain.tpp:1517-1520), Qt = Q^T;
@@ -41,6 +48,7 @@
 #include <vector>
 
 #include "amg.hpp"
+#include "composite.hpp"
 #include "config.hpp"
 #include "csr_matrix.hpp"
 #include "domain.hpp"
@@ -77,6 +85,7 @@ struct Stiffness_Operator // subdomain.hpp:46-70
         bool contiguous = true;  // elements e*(N+1)^3 apart from `first_offset`
         int first_offset = 0;
         fdd::memory elem_offset; // int[num_elements] when not contiguous
+        const double *G[NUM_GEOM_FACTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // geometric factors of the list's first point (contiguous lists)
     };
     std::vector<LevelList> level_lists;
 };
@@ -140,6 +149,19 @@ class Subdomain
     fdd::memory points_without_dof; // Dirichlet points: empty rows of Q
     int num_points_without_dof = 0;
 
+    // ---- composite region (more than one rank): composite.hpp builds it, this class runs on it ----
+    bool is_composite = false;
+    fdd::composite::Composite comp;            // host description; the big per-point arrays are released after the upload
+    int own_points = 0;                        // points of the rank's own elements = head of every composite vector
+    fdd::memory ring_geom[NUM_GEOM_FACTS];     // geometric factors of the ring / extended elements (the own ones stay the Domain's)
+    std::vector<DType> norm_weight_hst;
+    // tree exchange (subdomain.tpp:4615-4644), all on device buffers
+    fdd::memory send_index, send_all, recv_all, unpack_index; // pack: send_all[k] = tree[send_index[k]]; unpack: head ring part [i] = recv_all[unpack_index[i]]
+    std::vector<fdd::ExchangeOp> exchange_ops;
+    int num_send_points = 0, num_ring_points = 0;
+    fdd::memory coarse_all;                    // the all-gathered degree-1 level of every rank, `coarse_pad` values per rank
+    int coarse_pad = 0;
+
     Math<DType> math;
     int dim = 3;
 
@@ -188,7 +210,7 @@ class Subdomain
         timer.stop("subdomain.tree_construction.gpu_to_gpu");
 
         timer.start("subdomain.tree_construction.subdomain");
-        if (build_tree)
+        if (build_tree or is_composite) // the composite's rings and superdomain are fed by the tree
         {
             for (int l = 0; l < num_levels - 1; l++)
             {
@@ -214,6 +236,12 @@ class Subdomain
         }
         timer.stop("subdomain.tree_construction.subdomain");
 
+        if (is_composite)
+        {
+            tree_exchange(Tu);
+            return;
+        }
+
         // Tree exchange.  With only own elements in the region the gs pull of
         // subdomain.tpp:4626-4630 is a device copy of the level-0 slice; the
         // coarse level has no superdomain consumer, so no all-gather is issued.
@@ -231,6 +259,38 @@ class Subdomain
         // superdomain_operator.Pt.multiply: empty matrix (subdomain.tpp:4643-4644)
     }
 
+    // The exchange half of tree_operator (subdomain.tpp:4613-4645), on device buffers throughout where the
+    // reference stages the whole tree through the host:
+    //   ring pull     gslib gs on (+owner, -copy) ids (:4626)  ->  pack, ONE grouped send / receive with the ranks
+    //                 whose regions overlap this one, unpack into the ring part of the head;
+    //   coarse level  MPI_Allgatherv (:4620-4621)               ->  all-gather (fixed count per rank, Qt_coarse
+    //                 addresses the padded layout), then Qt_coarse and Pt into the tail (:4639-4644).
+    void tree_exchange(fdd::memory &Tu)
+    {
+        void *stream = fdd::dev().stream;
+        timer.start("subdomain.tree_exchange.subdomain");
+        if (num_send_points > 0) FDD_CALL(fdd_gather_indexed(send_all.as<double>(), work_dev[0].as<double>(), send_index.template as<int>(), nullptr, num_send_points, stream));
+        if (not exchange_ops.empty()) fdd::comm().exchange(exchange_ops.data(), (int)exchange_ops.size());
+        Tu.copyFrom(work_dev[0], (size_t)own_points * sizeof(DType)); // the rank's own elements: the level-0 slice (:4630)
+        if (num_ring_points > 0) FDD_CALL(fdd_gather_indexed(Tu.as<double>() + own_points, recv_all.as<double>(), unpack_index.template as<int>(), nullptr, num_ring_points, stream));
+        timer.stop("subdomain.tree_exchange.subdomain");
+
+        if (superdomain_operator.num_extended_dofs == 0) return;
+        timer.start("subdomain.tree_exchange.superdomain");
+        fdd::memory coarse = work_dev[0].slice(levels[num_levels - 1].offset, coarse_pad);
+        fdd::comm().allgather(coarse.ptr(), coarse_all.ptr(), (size_t)coarse_pad * sizeof(DType));
+        timer.stop("subdomain.tree_exchange.superdomain");
+
+        timer.start("subdomain.tree_construction.assemble_coarse");
+        Qt_coarse.multiply(work_dev[1], coarse_all); // :4639
+        timer.stop("subdomain.tree_construction.assemble_coarse");
+
+        timer.start("subdomain.tree_construction.superdomain");
+        fdd::memory Tu_sup = Tu.slice(subdomain_operator.num_points, superdomain_operator.num_extended_dofs);
+        superdomain_operator.Pt.multiply(Tu_sup, work_dev[1]); // :4643-4644
+        timer.stop("subdomain.tree_construction.superdomain");
+    }
+
     // subdomain.tpp:4491-4515
     void residual_norm(DType &r_norm, fdd::memory &r)
     {
@@ -238,12 +298,28 @@ class Subdomain
         fdd::memory work_sub = work_dev[1].slice(0, subdomain_operator.num_extended_dofs);
 
         subdomain_operator.Qt.multiply_weight(work_sub, r_sub_l, norm_weight);
-        // r_sup.copyTo(work_sup): empty tail
+        copy_tail(work_dev[1], r); // r_sup.copyTo(work_sup), :4501
 
         const int nv = subdomain_operator.num_extended_dofs + superdomain_operator.num_extended_dofs;
         FDD_CALL(fdd_sub_weighted_inner_product(scalars.as<double>(), reduce_ws.as<double>(), work_dev[1].as<double>(), work_dev[1].as<double>(), norm_weight.as<double>(), nv, fdd::dev().stream));
         fetch_scalars(&r_norm, 1);
         r_norm = std::sqrt(r_norm);
+    }
+
+    // the superdomain part of a composite vector next to the assembled subdomain part: [ext sub dofs | ext sup dofs]
+    void copy_tail(fdd::memory &dofs, fdd::memory &values)
+    {
+        const int nue = superdomain_operator.num_extended_dofs;
+        if (nue == 0) return;
+        fdd::memory dst = dofs.slice(subdomain_operator.num_extended_dofs, nue);
+        dst.copyFrom(values.slice(subdomain_operator.num_points, nue), (size_t)nue * sizeof(DType));
+    }
+    void copy_tail_back(fdd::memory &values, fdd::memory &dofs)
+    {
+        const int nue = superdomain_operator.num_extended_dofs;
+        if (nue == 0) return;
+        fdd::memory dst = values.slice(subdomain_operator.num_points, nue);
+        dst.copyFrom(dofs.slice(subdomain_operator.num_extended_dofs, nue), (size_t)nue * sizeof(DType));
     }
 
     // subdomain.tpp:4277-4307
@@ -252,10 +328,12 @@ class Subdomain
         fdd::memory u_sub_l = u.slice(0, subdomain_operator.num_points);
         fdd::memory u_work_sub = work_dev[0].slice(0, subdomain_operator.num_extended_dofs);
         subdomain_operator.Qt.multiply_weight(u_work_sub, u_sub_l, norm_weight);
+        copy_tail(work_dev[0], u); // :4286
 
         fdd::memory v_sub_l = v.slice(0, subdomain_operator.num_points);
         fdd::memory v_work_sub = work_dev[1].slice(0, subdomain_operator.num_extended_dofs);
         subdomain_operator.Qt.multiply_weight(v_work_sub, v_sub_l, norm_weight);
+        copy_tail(work_dev[1], v); // :4294
 
         const int nv = subdomain_operator.num_extended_dofs + superdomain_operator.num_extended_dofs;
         FDD_CALL(fdd_sub_weighted_inner_product(scalars.as<double>(), reduce_ws.as<double>(), work_dev[0].as<double>(), work_dev[1].as<double>(), norm_weight.as<double>(), nv, fdd::dev().stream));
@@ -307,6 +385,7 @@ class Subdomain
         fdd::memory r_sub_l = r.slice(0, subdomain_operator.num_points);
         fdd::memory z_sub_l = z.slice(0, subdomain_operator.num_points);
         subdomain_operator.Qt.multiply(work_dev[0], r_sub_l); // :3996
+        copy_tail(work_dev[0], r);                            // :4000
         if (Qt_int.is_identity)
             fine.f.copyFrom(work_dev[0], (size_t)num_dofs * sizeof(DType)); // :4004-4008 with Qt_int = I
         else
@@ -321,6 +400,7 @@ class Subdomain
         {
             Q_int.multiply(work_dev[0], fine.u);
             subdomain_operator.Q.multiply(z_sub_l, work_dev[0]);
+            copy_tail_back(z, work_dev[0]); // :4157
         }
     }
 
@@ -379,6 +459,11 @@ class Subdomain
     }
     void apply_low_order_preconditioner(fdd::memory &z, fdd::memory &r) { low_order_preconditioner(z, r); }
 
+    bool block_local = false;             // more than one rank: keep the rank's own elements only (no rings, no superdomain): block-Jacobi, the comparison point
+    bool force_composite = false;         // build the region through composite.hpp even on one rank (test hook: must equal the conforming region)
+    bool composite() const { return is_composite; }
+    const fdd::composite::Composite &composite_description() const { return comp; }
+    fdd::composite::GradingOptions grading; // superdomain coarsening (composite.hpp)
     bool build_tree = true;               // run the degree-tree restrictions as the reference always does
     bool fused_dssum = true;              // gather-scatter kernel instead of the Qt / QQt_int / Q SpMV chain
     bool restructured = true;             // inner GMRES with cached assembled basis, multi-dot / multi-axpy
@@ -472,6 +557,49 @@ class Subdomain
             superdomain_operator.D_hat.push_back(D_hat[l].second);
         }
 
+        is_composite = (fdd::comm().size > 1 and not block_local) or force_composite;
+        if (is_composite)
+            initialize_composite(domains, domain);
+        else
+            initialize_conforming(domains, domain);
+
+        num_values = subdomain_operator.num_points + superdomain_operator.num_extended_dofs; // subdomain.tpp:3858
+        num_blocks = (num_values + BLOCK_SIZE - 1) / BLOCK_SIZE;
+
+        {
+            inner_weight = fdd::dev().malloc<DType>(num_values);
+            subdomain_operator.Q.multiply(inner_weight, norm_weight);
+            std::vector<DType> w(num_values);
+            inner_weight.copyTo(w.data(), (size_t)num_values * sizeof(DType));
+            // the tail takes the superdomain part of norm_weight (subdomain.tpp:2742-2744)
+            for (int i = 0; i < superdomain_operator.num_extended_dofs; i++) w[(size_t)subdomain_operator.num_points + i] = norm_weight_hst[(size_t)subdomain_operator.num_extended_dofs + i];
+            for (int i = 0; i < num_values; i++)
+                if (w[i] > 0.0) w[i] = 1.0;
+            inner_weight.copyFrom(w.data(), (size_t)num_values * sizeof(DType));
+        }
+
+        // solver vectors (subdomain.tpp:3860-3873)
+        f = fdd::dev().malloc<DType>(num_values);
+        u_k = fdd::dev().malloc<DType>(num_values);
+        r_k = fdd::dev().malloc<DType>(num_values);
+        r_kp1 = fdd::dev().malloc<DType>(num_values);
+        q_k = fdd::dev().malloc<DType>(num_values);
+        z_k = fdd::dev().malloc<DType>(num_values);
+        p_k = fdd::dev().malloc<DType>(num_values);
+        allocate_krylov_scalars(); // the point-space Krylov basis is allocated by the solvers that use it
+
+        reduce_ws = fdd::dev().malloc<double>(fdd_reduce_workspace_doubles());
+        scalars = fdd::dev().malloc<double>(2 * FDD_MULTI_MAX);
+
+        // the big boolean matrices' host mirrors are not needed after setup
+        subdomain_operator.Q.release_host();
+        subdomain_operator.Qt.release_host();
+    }
+
+    // the region of a single rank (or of a block-local run): the rank's own conforming elements
+    template <typename PType>
+    void initialize_conforming(std::unordered_map<int, PType> &domains, PType &domain)
+    {
         const int P = domain.num_local_points;
         const int total_level_points = levels[num_levels - 1].offset + levels[num_levels - 1].num_points;
 
@@ -542,6 +670,7 @@ class Subdomain
             ll.num_elements = domain.num_local_elements;
             ll.contiguous = true;
             ll.first_offset = 0;
+            for (int g = 0; g < NUM_GEOM_FACTS; g++) ll.G[g] = subdomain_operator.G_ptrs[g];
             subdomain_operator.level_lists.push_back(ll);
         }
 
@@ -579,38 +708,195 @@ class Subdomain
             std::vector<DType> w(std::max(nw, 1), 1.0);
             norm_weight = fdd::dev().malloc<DType>(std::max(nw, 1));
             norm_weight.copyFrom(w.data(), w.size() * sizeof(DType));
+            norm_weight_hst = w;
             norm_weight_is_one = true; // no interface dofs shared with a superdomain: the kernels need not read it
         }
 
-        num_values = subdomain_operator.num_points + superdomain_operator.num_extended_dofs; // subdomain.tpp:3858
-        num_blocks = (num_values + BLOCK_SIZE - 1) / BLOCK_SIZE;
+    }
 
+    // one unit entry per row (or none where col < 0): the interface maps of subdomain.tpp:2653-2729
+    static void unit_matrix(CSR_Matrix<DType> &A, int rows, int cols, const int *col)
+    {
+        std::vector<int> ptr(rows + 1, 0), cc;
+        std::vector<DType> vv;
+        for (int i = 0; i < rows; i++)
         {
-            inner_weight = fdd::dev().malloc<DType>(num_values);
-            subdomain_operator.Q.multiply(inner_weight, norm_weight);
-            std::vector<DType> w(num_values);
-            inner_weight.copyTo(w.data(), (size_t)num_values * sizeof(DType));
-            for (int i = 0; i < num_values; i++)
-                if (w[i] > 0.0) w[i] = 1.0;
-            inner_weight.copyFrom(w.data(), (size_t)num_values * sizeof(DType));
+            if (col[i] >= 0)
+            {
+                cc.push_back(col[i]);
+                vv.push_back(1.0);
+            }
+            ptr[i + 1] = (int)cc.size();
+        }
+        A.assemble_from_csr(rows, cols, ptr.data(), cc.data(), vv.data());
+    }
+
+    static void host_csr_matrix(CSR_Matrix<DType> &A, const fdd::low_order::HostCSR &H)
+    {
+        A.assemble_from_csr(H.rows, H.cols, H.ptr.data(), H.col.data(), H.val.data());
+    }
+
+    // the composite region of a multi-rank run (subdomain.tpp:198-2747 via composite.hpp), uploaded
+    template <typename PType>
+    void initialize_composite(std::unordered_map<int, PType> &domains, PType &domain)
+    {
+        std::map<std::pair<int, int>, std::vector<double>> J;
+        for (auto &kv : J_cf) J[kv.first] = kv.second.first;
+        comp = fdd::composite::build(domains, poly_degree, subdomain_overlap, superdomain_overlap, (double)epsilon, J, D_hat[num_levels - 1].first, domain.scatter_matrix().col_hst, domain.num_local_nodes, grading);
+        const fdd::composite::Composite &c = comp;
+
+        own_points = levels[0].num_points;
+        const int NP = c.num_sub_ext_points;
+        const int nse = c.sub_num_ext_dofs, nue = c.sup_num_ext_dofs;
+        num_ring_points = NP - own_points;
+
+        rstdout("Composite region: %d own + %d ring + %d extended elements (%d points), %d + %d subdomain dofs, %d interface, superdomain %d of %d coarse dofs (+%d extended), %d unique dofs\n", levels[0].num_elements,
+                c.num_sub_elems - levels[0].num_elements, c.num_sub_ext_elems - c.num_sub_elems, NP, c.sub_num_dofs, nse - c.sub_num_dofs, c.num_interface_dofs, c.sup_num_dofs, c.num_coarse_dofs, nue - c.sup_num_dofs, c.num_dofs);
+
+        // geometry: own elements keep the Domain's arrays, the ring / extended elements get their own (subdomain.tpp:667-699)
+        for (int g = 0; g < NUM_GEOM_FACTS; g++)
+        {
+            subdomain_operator.geom_fact[g] = domain.geom_fact[g];
+            subdomain_operator.G_ptrs[g] = domain.geom_fact[g].template as<double>();
+            ring_geom[g] = fdd::dev().malloc<DType>(std::max(num_ring_points, 1));
+            if (num_ring_points > 0) ring_geom[g].copyFrom(c.G[g].data() + own_points, (size_t)num_ring_points * sizeof(DType));
         }
 
-        // solver vectors (subdomain.tpp:3860-3873)
-        f = fdd::dev().malloc<DType>(num_values);
-        u_k = fdd::dev().malloc<DType>(num_values);
-        r_k = fdd::dev().malloc<DType>(num_values);
-        r_kp1 = fdd::dev().malloc<DType>(num_values);
-        q_k = fdd::dev().malloc<DType>(num_values);
-        z_k = fdd::dev().malloc<DType>(num_values);
-        p_k = fdd::dev().malloc<DType>(num_values);
-        allocate_krylov_scalars(); // the point-space Krylov basis is allocated by the solvers that use it
+        // level-sorted element lists (subdomain.tpp:1603-1630 sorted by level): the region is ordered by level, so
+        // every degree is one contiguous run; the level-0 run splits into the own elements and the degree-N ring
+        // because their geometric factors live in different arrays
+        subdomain_operator.level_lists.clear();
+        for (int l = 0; l < num_levels; l++)
+        {
+            int first = c.level_first_elem[l], count = c.level_num_elems[l];
+            if (count == 0) continue;
+            if (l == 0)
+            {
+                typename Stiffness_Operator<DType>::LevelList own;
+                own.level = 0;
+                own.poly_degree = poly_degree[0];
+                own.num_elements = levels[0].num_elements;
+                own.first_offset = 0;
+                for (int g = 0; g < NUM_GEOM_FACTS; g++) own.G[g] = subdomain_operator.G_ptrs[g];
+                if (own.num_elements > 0) subdomain_operator.level_lists.push_back(own);
+                first += own.num_elements;
+                count -= own.num_elements;
+                if (count == 0) continue;
+            }
+            typename Stiffness_Operator<DType>::LevelList ll;
+            ll.level = l;
+            ll.poly_degree = poly_degree[l];
+            ll.num_elements = count;
+            ll.first_offset = c.sub[first].offset;
+            for (int g = 0; g < NUM_GEOM_FACTS; g++) ll.G[g] = ring_geom[g].template as<double>() + (ll.first_offset - own_points);
+            subdomain_operator.level_lists.push_back(ll);
+        }
 
-        reduce_ws = fdd::dev().malloc<double>(fdd_reduce_workspace_doubles());
-        scalars = fdd::dev().malloc<double>(2 * FDD_MULTI_MAX);
+        // Q with its J_cf rows, Qt (subdomain.tpp:1496-1585)
+        subdomain_operator.Q.initialize(NP, nse);
+        subdomain_operator.Q.reserve(c.Q_row.size());
+        for (size_t t = 0; t < c.Q_row.size(); t++) subdomain_operator.Q.add_entry(c.Q_row[t], c.Q_col[t], c.Q_val[t]);
+        subdomain_operator.Q.assemble();
+        subdomain_operator.Q.transpose(subdomain_operator.Qt);
+        subdomain_operator.num_dofs = c.sub_num_dofs;
+        subdomain_operator.num_points = NP;
+        subdomain_operator.num_extended_dofs = nse;
 
-        // the big boolean matrices' host mirrors are not needed after setup
-        subdomain_operator.Q.release_host();
-        subdomain_operator.Qt.release_host();
+        point_dof = c.point_dof;
+        point_dof_dev = fdd::dev().malloc<int>(std::max(NP, 1));
+        point_dof_dev.copyFrom(point_dof.data(), (size_t)NP * sizeof(int));
+
+        // superdomain operator (subdomain.tpp:2541-2575) and the coarse assembly (:1706-1713).  The coarse level is
+        // all-gathered with a fixed count per rank, so Qt_coarse's columns address that padded layout.
+        superdomain_operator.num_dofs = c.sup_num_dofs;
+        superdomain_operator.num_extended_dofs = nue;
+        superdomain_operator.num_points = 0;
+        host_csr_matrix(superdomain_operator.A, c.A_sup);
+        host_csr_matrix(superdomain_operator.Pt, c.Pt_sup);
+        {
+            const int nv = c.num_vertices, R = fdd::comm().size;
+            int max_count = 0;
+            for (int p = 0; p < R; p++) max_count = std::max(max_count, c.proc_count[p]);
+            coarse_pad = max_count * nv;
+            std::vector<int> owner_of(c.num_total_elements);
+            for (int p = 0; p < R; p++)
+                for (int e = 0; e < c.proc_count[p]; e++) owner_of[c.proc_offset[p] + e] = p;
+            fdd::low_order::HostCSR Q = c.Qt_coarse;
+            for (int &col : Q.col)
+            {
+                const int e = col / nv, v = col % nv, p = owner_of[e];
+                col = p * coarse_pad + (e - c.proc_offset[p]) * nv + v;
+            }
+            Q.cols = R * coarse_pad;
+            // the remap is monotone inside a rank and ranks are in order: rows stay sorted
+            host_csr_matrix(Qt_coarse, Q);
+            coarse_all = fdd::dev().malloc<DType>(std::max((size_t)R * coarse_pad, (size_t)1));
+        }
+
+        // interface maps and weights (subdomain.tpp:2581-2747)
+        num_interface_dofs = c.num_interface_dofs;
+        num_dofs = c.num_dofs;
+        unit_matrix(Q_int, nse + nue, num_dofs, c.Q_int_col.data());
+        unit_matrix(Qt_int, num_dofs, nse + nue, c.Qt_int_col.data());
+        unit_matrix(QQt_int, nse + nue, nse + nue, c.QQt_int_col.data());
+        norm_weight_hst.assign(c.norm_weight.begin(), c.norm_weight.end());
+        norm_weight = fdd::dev().malloc<DType>(std::max(nse + nue, 1));
+        norm_weight.copyFrom(norm_weight_hst.data(), norm_weight_hst.size() * sizeof(DType));
+        norm_weight_is_one = false;
+
+        // solve-time ring pull: what this rank packs for its peers and where the answers land
+        {
+            std::vector<int> sidx, uidx((size_t)std::max(num_ring_points, 1), 0);
+            size_t recv_total = 0;
+            for (const fdd::composite::PeerPlan &pl : c.peers) recv_total += (size_t)pl.recv_points;
+            exchange_ops.clear();
+            std::vector<size_t> send_at, recv_at;
+            size_t rat = 0;
+            for (const fdd::composite::PeerPlan &pl : c.peers)
+            {
+                send_at.push_back(sidx.size());
+                recv_at.push_back(rat);
+                for (size_t k = 0; k < pl.send_level.size(); k++)
+                {
+                    const int l = pl.send_level[k], e = pl.send_elem[k];
+                    const int np = levels[l].num_points / std::max(levels[l].num_elements, 1);
+                    for (int v = 0; v < np; v++) sidx.push_back(levels[l].offset + e * np + v);
+                }
+                for (int r : pl.recv_elem)
+                    for (int v = 0; v < c.sub[r].num_points; v++) uidx[(size_t)c.sub[r].offset - own_points + v] = (int)rat++;
+            }
+            num_send_points = (int)sidx.size();
+            send_index = fdd::dev().malloc<int>(std::max(num_send_points, 1));
+            send_index.copyFrom(sidx.data(), sidx.size() * sizeof(int));
+            send_all = fdd::dev().malloc<DType>(std::max(num_send_points, 1));
+            recv_all = fdd::dev().malloc<DType>(std::max(recv_total, (size_t)1));
+            unpack_index = fdd::dev().malloc<int>(std::max(num_ring_points, 1));
+            unpack_index.copyFrom(uidx.data(), (size_t)num_ring_points * sizeof(int));
+            for (size_t k = 0; k < c.peers.size(); k++)
+            {
+                fdd::ExchangeOp op;
+                op.peer = c.peers[k].rank;
+                op.send = send_all.template as<DType>() + send_at[k];
+                op.send_bytes = (size_t)c.peers[k].send_points * sizeof(DType);
+                op.recv = recv_all.template as<DType>() + recv_at[k];
+                op.recv_bytes = (size_t)c.peers[k].recv_points * sizeof(DType);
+                exchange_ops.push_back(op);
+            }
+        }
+
+        // work arrays: the degree tree (plus the padded coarse send), region vectors, dof vectors, the gathered coarse level
+        {
+            const size_t total_level_points = (size_t)levels[num_levels - 1].offset + (size_t)levels[num_levels - 1].num_points;
+            size_t W = std::max({total_level_points + (size_t)coarse_pad, (size_t)NP, (size_t)(nse + nue), (size_t)c.num_coarse_dofs, (size_t)num_dofs}) + 16;
+            work_dev.resize(3);
+            for (int w = 0; w < 3; w++) work_dev[w] = fdd::dev().malloc<DType>(W);
+        }
+
+        // the per-point arrays the solve path no longer needs
+        for (int g = 0; g < NUM_GEOM_FACTS; g++) std::vector<double>().swap(comp.G[g]);
+        std::vector<int>().swap(comp.Q_row);
+        std::vector<int>().swap(comp.Q_col);
+        std::vector<double>().swap(comp.Q_val);
     }
 
     void allocate_krylov()
@@ -635,7 +921,7 @@ class Subdomain
     // subdomain.tpp:3969-3985
     void direct_stiffness_summation(fdd::memory &QQtu, fdd::memory &u)
     {
-        if (fused_dssum and subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0)
+        if (fused_dssum and not is_composite and subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0)
         {
             // Q * I * Qt in one gather-scatter pass over the dofs; points without
             // a dof (Dirichlet: empty rows of Q) get the 0.0 the SpMV writes.
@@ -646,10 +932,11 @@ class Subdomain
 
         fdd::memory u_sub_l = u.slice(0, subdomain_operator.num_points);
         subdomain_operator.Qt.multiply(work_dev[0], u_sub_l);
-        // u_sup -> work_dev[0] tail: empty
+        copy_tail(work_dev[0], u); // :3977
         QQt_int.multiply(work_dev[1], work_dev[0]);
         fdd::memory QQtu_sub_l = QQtu.slice(0, subdomain_operator.num_points);
         subdomain_operator.Q.multiply(QQtu_sub_l, work_dev[1]);
+        copy_tail_back(QQtu, work_dev[1]); // :3984
     }
 
     // subdomain.tpp:3942-3967
@@ -671,7 +958,7 @@ class Subdomain
                 if (ll.contiguous)
                 {
                     const double *Gs[NUM_GEOM_FACTS];
-                    for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = subdomain_operator.G_ptrs[g] + ll.first_offset;
+                    for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = ll.G[g];
                     FDD_CALL(fdd_stiffness_matrix_mfma(Au_sub_l.as<double>() + ll.first_offset, u_sub_l.as<double>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), Gs, nullptr, ll.num_elements, ll.poly_degree, fdd::dev().stream));
                 }
                 else
@@ -686,7 +973,7 @@ class Subdomain
                 if (ll.contiguous)
                 {
                     const double *Gs[NUM_GEOM_FACTS];
-                    for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = subdomain_operator.G_ptrs[g] + ll.first_offset;
+                    for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = ll.G[g];
                     FDD_CALL(fdd_sub_stiffness_matrix(Au_sub_l.as<double>() + ll.first_offset, u_sub_l.as<double>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), Gs, nullptr, ll.num_elements, ll.poly_degree, fdd::dev().stream));
                 }
                 else
@@ -700,7 +987,7 @@ class Subdomain
                 const int npts = ll.num_elements * (int)std::lround(std::pow(ll.poly_degree + 1, dim));
                 double *GDu[3] = {work_dev[0].as<double>(), work_dev[1].as<double>(), work_dev[2].as<double>()};
                 const double *Gs[NUM_GEOM_FACTS];
-                for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = subdomain_operator.G_ptrs[g] + ll.first_offset;
+                for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = ll.G[g];
                 FDD_CALL(fdd_dom_stiffness_matrix_1(GDu, u_sub_l.as<double>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), Gs, npts, ll.poly_degree, dim, fdd::dev().stream));
                 FDD_CALL(fdd_dom_stiffness_matrix_2(Au_sub_l.as<double>() + ll.first_offset, GDu, subdomain_operator.D_hat[ll.level].template as<double>(), npts, ll.poly_degree, dim, fdd::dev().stream));
             }
@@ -814,7 +1101,7 @@ class Subdomain
     // 4 node passes per step instead of 3 + 2(j+1) + 1 SpMVs.
     bool can_restructure() const
     {
-        return subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0 and not use_preconditioner and num_vectors + 1 <= FDD_MULTI_MAX;
+        return not is_composite and subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0 and not use_preconditioner and num_vectors + 1 <= FDD_MULTI_MAX;
     }
 
     void gather_weighted(fdd::memory &t, fdd::memory &v)
@@ -989,6 +1276,7 @@ class Subdomain
     // ------------------------------------------------------------------
     bool can_assemble() const
     {
+        if (is_composite) return false;
         if (not(subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0 and num_vectors + 1 <= FDD_MULTI_MAX and dim == 3)) return false;
         for (auto &ll : subdomain_operator.level_lists)
             if (ll.poly_degree > 15) return false;
@@ -1007,7 +1295,7 @@ class Subdomain
                 if (ll.contiguous)
                 {
                     const double *Gs[NUM_GEOM_FACTS];
-                    for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = subdomain_operator.G_ptrs[g] + ll.first_offset;
+                    for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = ll.G[g];
                     FDD_CALL(fdd_stiffness_matrix_mfma_gather(q.as<double>() + ll.first_offset, za.as<double>(), scale_dev, point_dof_dev.template as<int>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), Gs, nullptr, ll.num_elements, ll.poly_degree, fdd::dev().stream));
                 }
                 else
@@ -1018,7 +1306,7 @@ class Subdomain
             if (ll.contiguous)
             {
                 const double *Gs[NUM_GEOM_FACTS];
-                for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = subdomain_operator.G_ptrs[g] + ll.first_offset;
+                for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = ll.G[g];
                 FDD_CALL(fdd_sub_stiffness_matrix_gather_scaled(q.as<double>() + ll.first_offset, za.as<double>(), scale_dev, point_dof_dev.template as<int>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), Gs, nullptr, ll.num_elements, ll.poly_degree, fdd::dev().stream));
             }
             else

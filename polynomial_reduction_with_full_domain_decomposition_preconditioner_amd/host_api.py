@@ -31,6 +31,26 @@ INFO_NAMES = [
 _ALLREDUCE = ctypes.CFUNCTYPE(ctypes.c_int, vp, vp, ctypes.c_longlong)
 _ALLGATHER = ctypes.CFUNCTYPE(ctypes.c_int, vp, vp, vp, ctypes.c_longlong)
 _BARRIER = ctypes.CFUNCTYPE(ctypes.c_int, vp)
+_EXCHANGE = ctypes.CFUNCTYPE(ctypes.c_int, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_longlong))
+
+SUB_INFO_NAMES = [
+    "is_composite",
+    "num_elems",
+    "num_ext_elems",
+    "num_points",
+    "sub_dofs",
+    "sub_ext_dofs",
+    "interface_dofs",
+    "sup_dofs",
+    "sup_ext_dofs",
+    "unique_dofs",
+    "coarse_dofs",
+    "num_values",
+    "own_points",
+    "num_peers",
+]
+
+WITH_SUBDOMAIN, BLOCK_LOCAL, FORCE_COMPOSITE = 1, 2, 4
 
 _keepalive = []
 
@@ -144,9 +164,35 @@ def comm_torch_callbacks(on_gpu: bool = True, staged: bool = False) -> None:
             print("barrier callback failed:", exc, flush=True)
             return 1
 
-    cbs = (_ALLREDUCE(allreduce(dist.ReduceOp.SUM)), _ALLREDUCE(allreduce(dist.ReduceOp.MAX)), _ALLGATHER(allgather), _BARRIER(barrier))
+    def exchange(ctx, n, peers, send, send_bytes, recv, recv_bytes):
+        # the composite's ring pull: one message per peer and direction, all in flight together
+        try:
+            ops, staged_recv = [], []
+            for i in range(int(n)):
+                peer, ns, nr = int(peers[i]), int(send_bytes[i]), int(recv_bytes[i])
+                if ns:
+                    t = wrap(send[i], ns, torch.uint8)
+                    ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, peer))
+                if nr:
+                    t = wrap(recv[i], nr, torch.uint8)
+                    if staged:
+                        h = torch.empty(nr, dtype=torch.uint8)
+                        staged_recv.append((t, h))
+                        t = h
+                    ops.append(dist.P2POp(dist.irecv, t, peer))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            for t, h in staged_recv:
+                t.copy_(h)
+            return 0
+        except Exception as exc:  # pragma: no cover
+            print("exchange callback failed:", exc, flush=True)
+            return 1
+
+    cbs = (_ALLREDUCE(allreduce(dist.ReduceOp.SUM)), _ALLREDUCE(allreduce(dist.ReduceOp.MAX)), _ALLGATHER(allgather), _BARRIER(barrier), _EXCHANGE(exchange))
     _keepalive.append(cbs)
-    _H().call("fddh_comm_callbacks", rank, size, None, *[ctypes.cast(c, vp) for c in cbs])
+    _H().call("fddh_comm_callbacks_ex", rank, size, None, *[ctypes.cast(c, vp) for c in cbs])
 
 
 def rank_grid(num_ranks: int):
@@ -180,17 +226,41 @@ class Problem:
         self.info = self._info()
         self.n = self.info["num_local_points"]
 
+    @staticmethod
+    def _flags(with_subdomain, block_local, force_composite):
+        return (WITH_SUBDOMAIN if with_subdomain else 0) | (BLOCK_LOCAL if block_local else 0) | (FORCE_COMPOSITE if force_composite else 0)
+
     @classmethod
-    def box(cls, E, P=(1, 1, 1), poly_degree=7, poly_reduction=2, with_subdomain=True):
+    def box(cls, E, P=(1, 1, 1), poly_degree=7, poly_reduction=2, with_subdomain=True, subdomain_overlap=1, superdomain_overlap=1, block_local=False, force_composite=False):
+        """With more than one rank the Subdomain is the full-domain-decomposition composite (own elements, rings at
+        reduced degree, coarsened superdomain); block_local keeps the rank's own elements only."""
         h = vp()
-        _H().call("fddh_problem_create_box", ctypes.byref(h), _arr3(E), _arr3(P), poly_degree, poly_reduction, int(with_subdomain))
+        _H().call("fddh_problem_create_box_ex", ctypes.byref(h), _arr3(E), _arr3(P), poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, cls._flags(with_subdomain, block_local, force_composite))
         return cls(h)
 
     @classmethod
-    def from_directory(cls, directory, poly_degree, poly_reduction, subdomain_overlap=1, superdomain_overlap=1, with_subdomain=True):
+    def from_directory(cls, directory, poly_degree, poly_reduction, subdomain_overlap=1, superdomain_overlap=1, with_subdomain=True, block_local=False, force_composite=False):
         h = vp()
-        _H().call("fddh_problem_create_dir", ctypes.byref(h), os.fsencode(directory), poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, int(with_subdomain))
+        _H().call("fddh_problem_create_dir_ex", ctypes.byref(h), os.fsencode(directory), poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, cls._flags(with_subdomain, block_local, force_composite))
         return cls(h)
+
+    def sub_info(self):
+        buf = (ctypes.c_longlong * len(SUB_INFO_NAMES))()
+        _H().call("fddh_problem_sub_info", self.h, buf, len(SUB_INFO_NAMES))
+        return {k: int(buf[i]) for i, k in enumerate(SUB_INFO_NAMES)}
+
+    def sub_region(self):
+        n = self.sub_info()["num_ext_elems"]
+        ids, lv = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        ip = ctypes.POINTER(ctypes.c_int)
+        _H().call("fddh_problem_sub_region", self.h, ids.ctypes.data_as(ip), lv.ctypes.data_as(ip), n)
+        return ids, lv
+
+    def sub_composite_levels(self):
+        kept = np.zeros(32, np.int32)
+        nl = ctypes.c_int()
+        _H().call("fddh_problem_sub_composite_levels", self.h, kept.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), 32, ctypes.byref(nl))
+        return [int(k) for k in kept[: nl.value]]
 
     def close(self):
         if self.h:
@@ -301,8 +371,9 @@ class Problem:
 
     # --- low-order AMG preconditioner of the inner solve (hierarchy handed in) ---
     def sub_point_dofs(self):
-        dof = np.zeros(self.n, dtype=np.int32)
-        _H().call("fddh_problem_sub_point_dofs", self.h, dof.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), self.n)
+        n = self.sub_info()["num_points"]
+        dof = np.zeros(n, dtype=np.int32)
+        _H().call("fddh_problem_sub_point_dofs", self.h, dof.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n)
         return dof
 
     def amg_attach(self, levels):

@@ -115,6 +115,12 @@ def oracle():
         L.orc_subdomain_create.restype = vp
         L.orc_subdomain_residual_norm.restype = ctypes.c_double
         L.orc_amg_create.restype = vp
+        L.orc_fdd_create.restype = vp
+        L.orc_fdd_subdomain.restype = vp
+        L.orc_fdd_composite_levels.restype = ctypes.POINTER(ctypes.c_int)
+        L.orc_fdd_matrix.restype = ctypes.POINTER(OrcCsr)
+        L.orc_fdd_norm_weight.restype = ctypes.POINTER(ctypes.c_double)
+        L.orc_fdd_inner_weight.restype = ctypes.POINTER(ctypes.c_double)
         L.orc_amg32_create.restype = vp
         _oracle = L
     return _oracle
@@ -197,7 +203,10 @@ class BoxMesh:
         gj = EY[:, None] * N + j[None, :]
         gk = EZ[:, None] * N + k[None, :]
 
-        self.glo_num = (1 + gi + Gx * (gj + Gy * gk)).astype(np.int64).reshape(-1)
+        # vertices first (the same id at every degree, as Nek5000 numbers them), then the other nodes
+        V = (Ex + 1) * (Ey + 1) * (Ez + 1)
+        is_vertex = (gi % N == 0) & (gj % N == 0) & (gk % N == 0)
+        self.glo_num = np.where(is_vertex, 1 + gi // N + (Ex + 1) * (gj // N + (Ey + 1) * (gk // N)), V + 1 + gi + Gx * (gj + Gy * gk)).astype(np.int64).reshape(-1)
 
         def mult(g, G):
             # number of elements sharing a grid line index g along one axis
@@ -443,6 +452,128 @@ class OracleSubdomain:
         return u, its, hist[: nh.value].copy()
 
 
+class OracleFdd:
+    """orc_fdd: the full-domain-decomposition composite of every rank of an R-rank run
+    (oracle/fdd_oracle_composite.c) and the preconditioner application on it."""
+
+    INFO = ["sub_elems", "sub_ext_elems", "points", "sub_dofs", "sub_ext_dofs", "interface_dofs", "sup_dofs", "sup_ext_dofs", "unique_dofs", "coarse_dofs", "num_values", "own_points"]
+
+    def __init__(self, E, N, reduction, P, subdomain_overlap=1, superdomain_overlap=1, mesh_class=None, meshes=None):
+        self.L = oracle()
+        self.deg = level_degrees(N, reduction)
+        self.R = int(np.prod(P))
+        nl = len(self.deg)
+        mc = mesh_class or BoxMesh
+        # meshes[rank][level]
+        self.meshes = meshes if meshes is not None else [[mc(E, d, P, r) for d in self.deg] for r in range(self.R)]
+        flat = [m.orc_mesh() for row in self.meshes for m in row]
+        self._cm = (OrcMesh * len(flat))(*flat)
+        self._D = [np.ascontiguousarray(gll(d)[2]) for d in self.deg]
+        self._J = {}
+        Jp = (vp * (nl * nl))()
+        for lf in range(nl):
+            for lc in range(lf + 1, nl):
+                self._J[(lf, lc)] = np.ascontiguousarray(J_cf(self.deg[lc], self.deg[lf]))
+                Jp[lf * nl + lc] = self._J[(lf, lc)].ctypes.data
+        Dp = (vp * nl)(*[a.ctypes.data for a in self._D])
+        degs = (ctypes.c_int * nl)(*self.deg)
+        self.f = vp(self.L.orc_fdd_create(self.R, nl, degs, Dp, Jp, self._cm, subdomain_overlap, superdomain_overlap))
+        self.info = [self._info(r) for r in range(self.R)]
+        self.npts = [self.meshes[r][0].num_local_points for r in range(self.R)]
+
+    def _info(self, r):
+        buf = (ctypes.c_int * 12)()
+        self.L.orc_fdd_info(self.f, r, buf)
+        return dict(zip(self.INFO, list(buf)))
+
+    def close(self):
+        if self.f:
+            self.L.orc_fdd_destroy(self.f)
+            self.f = None
+
+    def _pp(self, arrays):
+        arr = (vp * self.R)()
+        for r, a in enumerate(arrays):
+            arr[r] = a.ctypes.data
+        return arr
+
+    def region(self, r):
+        n = self.info[r]["sub_ext_elems"]
+        ids = np.zeros(n, np.int32)
+        lv = np.zeros(n, np.int32)
+        ip = ctypes.POINTER(ctypes.c_int)
+        self.L.orc_fdd_region(self.f, r, ids.ctypes.data_as(ip), lv.ctypes.data_as(ip))
+        return ids, lv
+
+    def composite_levels(self, r):
+        p = self.L.orc_fdd_composite_levels(self.f, r)
+        out = []
+        k = 0
+        while p[k] >= 0:
+            out.append(p[k])
+            k += 1
+        return out
+
+    def sub(self, r):
+        return vp(self.L.orc_fdd_subdomain(self.f, r))
+
+    MATRICES = {"Q": 0, "Qt": 1, "Q_int": 2, "Qt_int": 3, "QQt_int": 4, "A_sup": 5, "Pt": 6, "Qt_coarse": 7}
+
+    def matrix(self, r, name):
+        """scipy CSR of one of the composite's operators"""
+        import scipy.sparse as sp
+
+        c = self.L.orc_fdd_matrix(self.f, r, self.MATRICES[name]).contents
+        ptr, col, val = c.to_numpy()
+        return sp.csr_matrix((val, col, ptr), shape=(c.num_rows, c.num_cols))
+
+    def norm_weight(self, r):
+        n = self.info[r]["sub_ext_dofs"] + self.info[r]["sup_ext_dofs"]
+        return np.ctypeslib.as_array(self.L.orc_fdd_norm_weight(self.f, r), shape=(n,)).copy()
+
+    def region_points(self, r, name):
+        """a mesh array (x, y, z, p_mask, ...) of the region's points, pulled from the owners' meshes"""
+        ids, lv = self.region(r)
+        counts = np.cumsum([0] + [self.meshes[p][0].num_local_elements for p in range(self.R)])
+        out = []
+        for e, l in zip(ids, lv):
+            p = int(np.searchsorted(counts, e, side="right") - 1)
+            m = self.meshes[p][l]
+            npts = m.num_elem_points
+            le = e - counts[p]
+            out.append(getattr(m, name)[le * npts : (le + 1) * npts])
+        return np.concatenate(out)
+
+    def tree(self, u):
+        out = [np.zeros(self.info[r]["num_values"]) for r in range(self.R)]
+        self.L.orc_fdd_tree_operator(self.f, self._pp(out), self._pp([np.ascontiguousarray(a) for a in u]))
+        return out
+
+    def stiffness(self, r, u):
+        out = np.zeros(self.info[r]["num_values"])
+        self.L.orc_subdomain_stiffness(self.sub(r), _p(out), _p(np.ascontiguousarray(u)))
+        return out
+
+    def dssum(self, r, u):
+        out = np.zeros(self.info[r]["num_values"])
+        self.L.orc_subdomain_dssum(self.sub(r), _p(out), _p(np.ascontiguousarray(u)))
+        return out
+
+    def residual_norm(self, r, v):
+        return self.L.orc_subdomain_residual_norm(self.sub(r), _p(np.ascontiguousarray(v)))
+
+    def precondition(self, r, method="gmres", num_vectors=4, max_iterations=4, tolerance=1e-12, use_preconditioner=False):
+        """r: one outer (own points) vector per rank; returns z per rank and the inner histories."""
+        z = [np.zeros(n) for n in self.npts]
+        opts = OrcSubdomainOpts(num_vectors, max_iterations, tolerance, int(use_preconditioner))
+        cap = max_iterations + 2
+        hist = np.zeros((self.R, cap))
+        nh = (ctypes.c_int * self.R)()
+        rr = [np.ascontiguousarray(a) for a in r]
+        self.L.orc_fdd_precondition(self.f, self._pp(z), self._pp(rr), 0 if method == "fcg" else 1, ctypes.byref(opts), _p(hist), cap, nh)
+        return z, [hist[k, : nh[k]].copy() for k in range(self.R)]
+
+
 def seeded_uniform(n, seed=1234):
     """Seeded stand-in for the reference's unseeded rand()/RAND_MAX RHS
     (domain.tpp:572-573)."""
@@ -662,7 +793,9 @@ class QuadMesh(BoxMesh):
         i, j = i.reshape(-1), j.reshape(-1)  # x fastest
         gi = EX[:, None] * N + i[None, :]
         gj = EY[:, None] * N + j[None, :]
-        self.glo_num = (1 + gi + Gx * gj).astype(np.int64).reshape(-1)
+        V = (Ex + 1) * (Ey + 1)
+        is_vertex = (gi % N == 0) & (gj % N == 0)
+        self.glo_num = np.where(is_vertex, 1 + gi // N + (Ex + 1) * (gj // N), V + 1 + gi + Gx * gj).astype(np.int64).reshape(-1)
 
         def mult(g, G):
             m = np.ones_like(g)
