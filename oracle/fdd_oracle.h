@@ -233,6 +233,10 @@ void orc_fdd_region(const orc_fdd *F, int rank, int *id, int *level); /* global 
 const int *orc_fdd_composite_levels(const orc_fdd *F, int rank);       /* composite dofs per coarsening level, -1 terminated */
 /* which: 0 Q, 1 Qt, 2 Q_int, 3 Qt_int, 4 QQt_int, 5 superdomain A, 6 superdomain Pt, 7 Qt_coarse */
 const orc_csr *orc_fdd_matrix(const orc_fdd *F, int rank, int which);
+/* the low-order operator of the composite over its unique dofs (subdomain.tpp:2749-3472; 3-D) */
+const orc_csr *orc_fdd_low_order_matrix(const orc_fdd *F, int rank);
+/* 0-based subdomain dof of every region point that carries one directly (-1: Dirichlet or hanging) */
+const int *orc_fdd_point_dofs(const orc_fdd *F, int rank);
 const double *orc_fdd_norm_weight(const orc_fdd *F, int rank);  /* sub extended + sup extended dofs */
 const double *orc_fdd_inner_weight(const orc_fdd *F, int rank); /* num_values */
 void orc_fdd_tree_operator(orc_fdd *F, double *const *Tu, const double *const *u);

@@ -56,6 +56,8 @@ struct orc_fdd
     int *sup_num_dofs;
     int **dof_sup;       /* per rank, per coarse dof (1-based superdomain dof, 0 none) */
     int **comp_levels;   /* per rank: composite dofs per coarsening level, -1 terminated */
+    orc_csr *A_fem;      /* per rank: the low-order operator of the composite (subdomain.tpp:2749-3472) */
+    int **point_dof;     /* per rank: 0-based subdomain dof of every region point that carries one directly, -1 otherwise */
 };
 
 /* ------------------------------------------------------------------ */
@@ -1289,6 +1291,440 @@ static void build_rank(orc_fdd *F, int me, const orc_mesh *meshes, const double 
             if (s->inner_weight[i] > 0.0) s->inner_weight[i] = 1.0;
     }
 
+    /* ---- low-order operator of the composite (subdomain.tpp:2749-3472) ---- */
+    F->point_dof[me] = (int *)xcalloc((size_t)NP + 1, sizeof(int));
+    for (int p = 0; p < NP; p++) F->point_dof[me][p] = (glo[p] > 0 && dofn[p] > 0) ? (int)dofn[p] - 1 : -1;
+    if (dim == 3)
+    {
+        const double epsilon = 1.0e-12;
+        const int(*pairs)[2] = edge_pairs_3d;
+        const int nse = s->num_extended_dofs;
+        /* edges around every face, in the order the reference fills the face's boundary (:3205-3264) */
+        static const int face_edges[6][4] = {{0, 1, 2, 3}, {4, 5, 6, 7}, {0, 4, 8, 9}, {1, 5, 10, 11}, {2, 6, 8, 10}, {3, 7, 9, 11}};
+        static const int low_order_elems[6][4][3] = {{{0, 0, 0}, {0, 1, 0}, {1, 0, 0}, {1, 0, 1}}, {{1, 0, 0}, {0, 1, 0}, {1, 1, 0}, {1, 0, 1}}, {{0, 0, 0}, {0, 0, 1}, {0, 1, 0}, {1, 0, 1}},
+                                                    {{1, 0, 1}, {1, 1, 0}, {1, 1, 1}, {0, 1, 0}}, {{0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {0, 1, 0}}, {{1, 0, 1}, {1, 1, 1}, {0, 1, 1}, {0, 1, 0}}}; /* :2877-2882 */
+        static const double D_fem[3][16] = {{1.0, 0.0, 0.0, -1.0, 1.0, 0.0, 0.0, -1.0, 1.0, 0.0, 0.0, -1.0, 1.0, 0.0, 0.0, -1.0},
+                                            {0.0, 1.0, 0.0, -1.0, 0.0, 1.0, 0.0, -1.0, 0.0, 1.0, 0.0, -1.0, 0.0, 1.0, 0.0, -1.0},
+                                            {0.0, 0.0, 1.0, -1.0, 0.0, 0.0, 1.0, -1.0, 0.0, 0.0, 1.0, -1.0, 0.0, 0.0, 1.0, -1.0}}; /* :2840-2842 */
+        const double weight = 24.0;
+
+        /* GLL nodes of every level from the meshes (reference element coordinates of an element's x-line) are not
+         * available as such: J_cf_fem needs r_gll, recovered from the J_cf table is not possible either, so the nodes
+         * are recomputed from the level's D_hat-independent definition: they are passed in through the meshes' first
+         * element only when it is affine.  Instead the caller hands them over (orc_fdd_set_gll_nodes) before create
+         * returns?  No: they come with the tables -- see r_gll below. */
+        double **r_gll = (double **)xcalloc((size_t)num_levels, sizeof(double *));
+        for (int l = 0; l < num_levels; l++)
+        {
+            /* nodes of level l on [-1, 1]: the interpolator from level l to itself is not in the tables, but the
+             * interpolator J_cf[(N_c = 1, N_f = N_l)] holds h^c_1(xi^f_i) = (1 + xi_i) / 2 in its second column */
+            int n = poly_degree[l] + 1;
+            r_gll[l] = (double *)xcalloc((size_t)n, sizeof(double));
+            if (poly_degree[l] == 1)
+            {
+                r_gll[l][0] = -1.0;
+                r_gll[l][1] = 1.0;
+            }
+            else
+            {
+                const double *J = J_cf_pairs[l * num_levels + (num_levels - 1)]; /* n x 2 */
+                for (int i = 0; i < n; i++) r_gll[l][i] = 2.0 * J[i * 2 + 1] - 1.0;
+                r_gll[l][0] = -1.0;
+                r_gll[l][n - 1] = 1.0;
+            }
+        }
+
+        double *rx = (double *)xcalloc((size_t)NP + 1, sizeof(double));
+        double *ry = (double *)xcalloc((size_t)NP + 1, sizeof(double));
+        double *rz = (double *)xcalloc((size_t)NP + 1, sizeof(double));
+        for (int r = 0; r < nreg; r++)
+        {
+            const relem *el = &region[r];
+            const orc_mesh *m = &meshes[el->owner * num_levels + el->level];
+            size_t src = (size_t)el->owner_elem * el->num_points;
+            for (int v = 0; v < el->num_points; v++)
+            {
+                rx[el->offset + v] = m->x[src + v];
+                ry[el->offset + v] = m->y[src + v];
+                rz[el->offset + v] = m->z[src + v];
+            }
+        }
+
+        /* the coarse differentiation matrices once more (:1731-1748) */
+        double D[3][64], G[ORC_NUM_GEOM_FACTS][64], GD[3][64];
+        memset(D, 0, sizeof(D));
+        memset(G, 0, sizeof(G));
+        {
+            const double *Dh = D_hat[num_levels - 1];
+            for (int p = 0; p < 2; p++)
+                for (int q = 0; q < 2; q++)
+                    for (int i = 0; i < 2; i++)
+                        for (int j = 0; j < 2; j++)
+                        {
+                            D[0][(i + (p * 2 + q) * 2) * 8 + (j + (p * 2 + q) * 2)] = Dh[i * 2 + j];
+                            D[1][(i * 8 + j) * 2 + ((p + p * 8) * (2 * 2) + (q + q * 8))] = Dh[i * 2 + j];
+                            D[2][(i * 8 + j) * (2 * 2) + (p + q * 2) * (1 + 8)] = Dh[i * 2 + j];
+                        }
+        }
+
+        coo Asub;
+        memset(&Asub, 0, sizeof(Asub));
+        int nmax = poly_degree[0] + 1, n3max = nmax * nmax * nmax;
+        double *A_e = (double *)xcalloc((size_t)n3max * n3max, sizeof(double));
+        int maxcols = n3max + 12 * nmax + 6 * nmax * nmax + 8;
+        double *J_e = (double *)xcalloc((size_t)n3max * maxcols, sizeof(double));
+        double *T_e = (double *)xcalloc((size_t)n3max * maxcols, sizeof(double));
+        double *JtAJ = (double *)xcalloc((size_t)maxcols * maxcols, sizeof(double));
+        int *col_dof = (int *)xcalloc((size_t)maxcols, sizeof(int));
+        int *idx_i = (int *)xcalloc((size_t)nmax * nmax + 4, sizeof(int));
+        int *idx_j = (int *)xcalloc((size_t)nmax * nmax + 4, sizeof(int));
+        /* per element: local column (1-based, 0 none) and dof of vertices, hanging-edge masters, hanging-face masters */
+        int *vert_first = (int *)xcalloc((size_t)n3max, sizeof(int));
+        int *edge_first = (int *)xcalloc((size_t)12 * nmax, sizeof(int));
+        int *edge_dof = (int *)xcalloc((size_t)12 * nmax, sizeof(int));
+        int *edge_nj = (int *)xcalloc(12, sizeof(int));
+        int *face_first = (int *)xcalloc((size_t)6 * nmax * nmax, sizeof(int));
+        int *face_dof = (int *)xcalloc((size_t)6 * nmax * nmax, sizeof(int));
+        int *face_nj = (int *)xcalloc(6, sizeof(int));
+        double **Jf_cache = (double **)xcalloc((size_t)num_levels * num_levels, sizeof(double *));
+
+        for (int r = 0; r < nreg; r++)
+        {
+            const relem *ei = &region[r];
+            const int N_i = ei->N, n_i = ei->n, n3 = ei->num_points;
+            memset(A_e, 0, (size_t)n3 * n3 * sizeof(double));
+
+            if (N_i > 1) /* :2932-3039 */
+            {
+                for (int s_z = 0; s_z < N_i; s_z++)
+                    for (int s_y = 0; s_y < N_i; s_y++)
+                        for (int s_x = 0; s_x < N_i; s_x++)
+                            for (int t = 0; t < 6; t++)
+                            {
+                                int loc_sub[4];
+                                double x_sub[4], y_sub[4], z_sub[4], H_fem[9], inv_H_fem[9], G_fem[9], work0[16], work1[16];
+                                for (int vid = 0; vid < 4; vid++)
+                                {
+                                    int i = low_order_elems[t][vid][0], j = low_order_elems[t][vid][1], k = low_order_elems[t][vid][2];
+                                    loc_sub[vid] = (s_x + i) + (s_y + j) * n_i + (s_z + k) * (n_i * n_i);
+                                    x_sub[vid] = rx[ei->offset + loc_sub[vid]];
+                                    y_sub[vid] = ry[ei->offset + loc_sub[vid]];
+                                    z_sub[vid] = rz[ei->offset + loc_sub[vid]];
+                                }
+                                H_fem[0] = x_sub[0] - x_sub[3];
+                                H_fem[1] = x_sub[1] - x_sub[3];
+                                H_fem[2] = x_sub[2] - x_sub[3];
+                                H_fem[3] = y_sub[0] - y_sub[3];
+                                H_fem[4] = y_sub[1] - y_sub[3];
+                                H_fem[5] = y_sub[2] - y_sub[3];
+                                H_fem[6] = z_sub[0] - z_sub[3];
+                                H_fem[7] = z_sub[1] - z_sub[3];
+                                H_fem[8] = z_sub[2] - z_sub[3];
+                                {
+                                    const double *A = H_fem;
+                                    double det_A = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]); /* :2785-2791 */
+                                    inv_H_fem[0] = (1.0 / det_A) * (A[4] * A[8] - A[7] * A[5]); /* :2806-2814 */
+                                    inv_H_fem[1] = (1.0 / det_A) * (A[2] * A[7] - A[8] * A[1]);
+                                    inv_H_fem[2] = (1.0 / det_A) * (A[1] * A[5] - A[4] * A[2]);
+                                    inv_H_fem[3] = (1.0 / det_A) * (A[5] * A[6] - A[8] * A[3]);
+                                    inv_H_fem[4] = (1.0 / det_A) * (A[0] * A[8] - A[6] * A[2]);
+                                    inv_H_fem[5] = (1.0 / det_A) * (A[2] * A[3] - A[5] * A[0]);
+                                    inv_H_fem[6] = (1.0 / det_A) * (A[3] * A[7] - A[6] * A[4]);
+                                    inv_H_fem[7] = (1.0 / det_A) * (A[1] * A[6] - A[7] * A[0]);
+                                    inv_H_fem[8] = (1.0 / det_A) * (A[0] * A[4] - A[3] * A[1]);
+                                    double det_H_fem = det_A;
+                                    for (int m = 0; m < 3; m++) /* :2985-2999: the same value at each of the 4 quadrature points */
+                                        for (int n = 0; n < 3; n++)
+                                        {
+                                            double G_val = 0.0;
+                                            for (int k = 0; k < 3; k++) G_val += (det_H_fem / weight) * inv_H_fem[m * 3 + k] * inv_H_fem[n * 3 + k];
+                                            G_fem[n + m * 3] = G_val;
+                                        }
+                                }
+                                for (int i = 0; i < 16; i++) work1[i] = 0.0;
+                                for (int m = 0; m < 3; m++) /* :3003-3019 */
+                                    for (int n = 0; n < 3; n++)
+                                    {
+                                        for (int i = 0; i < 16; i++) work0[i] = 0.0;
+                                        for (int i = 0; i < 4; i++)
+                                            for (int j = 0; j < 4; j++)
+                                                for (int k = 0; k < 4; k++) work0[i * 4 + j] += ((i == k) ? G_fem[n + m * 3] : 0.0) * D_fem[n][k * 4 + j];
+                                        for (int i = 0; i < 4; i++)
+                                            for (int j = 0; j < 4; j++)
+                                                for (int k = 0; k < 4; k++) work1[i * 4 + j] += D_fem[m][k * 4 + i] * work0[k * 4 + j];
+                                    }
+                                for (int i = 0; i < 4; i++) /* :3021-3034 */
+                                    for (int j = 0; j < 4; j++)
+                                        if (fabs(work1[i * 4 + j]) > epsilon) A_e[(size_t)loc_sub[i] * n3 + loc_sub[j]] += work1[i * 4 + j];
+                            }
+            }
+            else /* :3082-3123 */
+            {
+                for (int g = 0; g < ORC_NUM_GEOM_FACTS; g++)
+                    for (int v = 0; v < 8; v++) G[g][v * 8 + v] = s->geom_fact[g][ei->offset + v];
+                for (int i = 0; i < 8; i++)
+                    for (int j = 0; j < 8; j++)
+                    {
+                        double GD_1 = 0.0, GD_2 = 0.0, GD_3 = 0.0;
+                        for (int k = 0; k < 8; k++)
+                        {
+                            GD_1 += G[0][i * 8 + k] * D[0][k * 8 + j] + G[3][i * 8 + k] * D[1][k * 8 + j] + G[4][i * 8 + k] * D[2][k * 8 + j];
+                            GD_2 += G[3][i * 8 + k] * D[0][k * 8 + j] + G[1][i * 8 + k] * D[1][k * 8 + j] + G[5][i * 8 + k] * D[2][k * 8 + j];
+                            GD_3 += G[4][i * 8 + k] * D[0][k * 8 + j] + G[5][i * 8 + k] * D[1][k * 8 + j] + G[2][i * 8 + k] * D[2][k * 8 + j];
+                        }
+                        GD[0][i * 8 + j] = GD_1;
+                        GD[1][i * 8 + j] = GD_2;
+                        GD[2][i * 8 + j] = GD_3;
+                    }
+                for (int i = 0; i < 8; i++)
+                    for (int j = 0; j < 8; j++)
+                    {
+                        double val = 0.0;
+                        for (int k = 0; k < 8; k++) val += D[0][k * 8 + i] * GD[0][k * 8 + j] + D[1][k * 8 + i] * GD[1][k * 8 + j] + D[2][k * 8 + i] * GD[2][k * 8 + j];
+                        if (fabs(val) > epsilon) A_e[(size_t)i * n3 + j] += val;
+                    }
+            }
+
+            /* local columns (:3130-3276) */
+            int rank = 1;
+            for (int vid = 0; vid < n3; vid++) vert_first[vid] = (glo[ei->offset + vid] > 0) ? rank++ : 0;
+            for (int eid = 0; eid < 12; eid++) edge_nj[eid] = 0;
+            for (int fid = 0; fid < 6; fid++) face_nj[fid] = 0;
+            for (int eid = 0; eid < num_edges; eid++)
+            {
+                int e_j = -1, N_j = N_i, n_j = N_j + 1;
+                for (int k = 0; k < edge_conn_n[r * num_edges + eid]; k++)
+                {
+                    int e = edge_conn[r * num_edges + eid][k];
+                    if (region[e].N < N_j)
+                    {
+                        e_j = e;
+                        N_j = region[e].N;
+                        n_j = N_j + 1;
+                    }
+                }
+                if (e_j < 0) continue;
+                const relem *ej = &region[e_j];
+                long long a = geometry_mesh[(size_t)ei->id * nv + pairs[eid][0]], b = geometry_mesh[(size_t)ei->id * nv + pairs[eid][1]];
+                int eid_j = -1;
+                for (int k = 0; k < num_edges && eid_j < 0; k++)
+                {
+                    long long c0 = geometry_mesh[(size_t)ej->id * nv + pairs[k][0]], c1 = geometry_mesh[(size_t)ej->id * nv + pairs[k][1]];
+                    if ((c0 == a || c0 == b) && (c1 == a || c1 == b)) eid_j = k;
+                }
+                if (eid_j < 0) continue;
+                edge_idx(eid, n_i, dim, idx_i);
+                edge_idx(eid_j, n_j, dim, idx_j);
+                edge_nj[eid] = n_j;
+                edge_first[eid * nmax + 0] = vert_first[idx_i[0]];
+                edge_dof[eid * nmax + 0] = (int)dofn[ei->offset + idx_i[0]];
+                edge_first[eid * nmax + (n_j - 1)] = vert_first[idx_i[n_i - 1]];
+                edge_dof[eid * nmax + (n_j - 1)] = (int)dofn[ei->offset + idx_i[n_i - 1]];
+                for (int k = 1; k < n_j - 1; k++)
+                {
+                    edge_first[eid * nmax + k] = rank++;
+                    edge_dof[eid * nmax + k] = (int)dofn[ej->offset + idx_j[k]];
+                }
+            }
+            for (int fid = 0; fid < num_faces; fid++)
+            {
+                for (int k = 0; k < face_conn_n[r * num_faces + fid]; k++)
+                {
+                    const relem *ej = &region[face_conn[r * num_faces + fid][k]];
+                    int N_j = ej->N, n_j = N_j + 1;
+                    if (!(N_i > N_j)) continue;
+                    long long fk[4], gk[4];
+                    for (int q = 0; q < 4; q++) fk[q] = geometry_mesh[(size_t)ei->id * nv + face_quads[fid][q]];
+                    qsort(fk, 4, sizeof(long long), cmp_ll);
+                    int fid_j = -1;
+                    for (int f2 = 0; f2 < num_faces && fid_j < 0; f2++)
+                    {
+                        for (int q = 0; q < 4; q++) gk[q] = geometry_mesh[(size_t)ej->id * nv + face_quads[f2][q]];
+                        qsort(gk, 4, sizeof(long long), cmp_ll);
+                        if (gk[0] == fk[0] && gk[1] == fk[1] && gk[2] == fk[2] && gk[3] == fk[3]) fid_j = f2;
+                    }
+                    if (fid_j < 0) continue;
+                    face_idx(fid, n_i, idx_i);
+                    face_idx(fid_j, n_j, idx_j);
+                    face_nj[fid] = n_j;
+                    int *ff = face_first + (size_t)fid * nmax * nmax, *fd = face_dof + (size_t)fid * nmax * nmax;
+                    /* corners (:3200-3203) */
+                    ff[0 + 0 * n_j] = vert_first[idx_i[0 + 0 * n_i]];
+                    fd[0 + 0 * n_j] = (int)dofn[ei->offset + idx_i[0 + 0 * n_i]];
+                    ff[(n_j - 1) + 0 * n_j] = vert_first[idx_i[(n_i - 1) + 0 * n_i]];
+                    fd[(n_j - 1) + 0 * n_j] = (int)dofn[ei->offset + idx_i[(n_i - 1) + 0 * n_i]];
+                    ff[0 + (n_j - 1) * n_j] = vert_first[idx_i[0 + (n_i - 1) * n_i]];
+                    fd[0 + (n_j - 1) * n_j] = (int)dofn[ei->offset + idx_i[0 + (n_i - 1) * n_i]];
+                    ff[(n_j - 1) + (n_j - 1) * n_j] = vert_first[idx_i[(n_i - 1) + (n_i - 1) * n_i]];
+                    fd[(n_j - 1) + (n_j - 1) * n_j] = (int)dofn[ei->offset + idx_i[(n_i - 1) + (n_i - 1) * n_i]];
+                    /* boundary from the four edges (:3205-3264) */
+                    for (int q = 1; q < n_j - 1; q++)
+                    {
+                        const int *fe = face_edges[fid];
+                        ff[q + 0 * n_j] = edge_first[fe[0] * nmax + q];
+                        fd[q + 0 * n_j] = edge_dof[fe[0] * nmax + q];
+                        ff[q + (n_j - 1) * n_j] = edge_first[fe[1] * nmax + q];
+                        fd[q + (n_j - 1) * n_j] = edge_dof[fe[1] * nmax + q];
+                        ff[0 + q * n_j] = edge_first[fe[2] * nmax + q];
+                        fd[0 + q * n_j] = edge_dof[fe[2] * nmax + q];
+                        ff[(n_j - 1) + q * n_j] = edge_first[fe[3] * nmax + q];
+                        fd[(n_j - 1) + q * n_j] = edge_dof[fe[3] * nmax + q];
+                    }
+                    for (int jj = 1; jj < n_j - 1; jj++) /* :3266-3273 */
+                        for (int ii = 1; ii < n_j - 1; ii++)
+                        {
+                            ff[ii + jj * n_j] = rank++;
+                            fd[ii + jj * n_j] = (int)dofn[ej->offset + idx_j[ii + jj * n_j]];
+                        }
+                }
+            }
+            int num_cols = rank - 1;
+
+            /* J_e (:3287-3355) */
+            memset(J_e, 0, (size_t)n3 * num_cols * sizeof(double));
+            for (int vid = 0; vid < n3; vid++)
+                if (vert_first[vid] > 0) J_e[(size_t)vid * num_cols + vert_first[vid] - 1] += 1.0;
+            for (int eid = 0; eid < num_edges; eid++)
+            {
+                if (edge_nj[eid] == 0) continue;
+                int n_j = edge_nj[eid], N_j = n_j - 1;
+                int lc = -1;
+                for (int l = 0; l < num_levels; l++)
+                    if (poly_degree[l] == N_j) lc = l;
+                double **slot = &Jf_cache[ei->level * num_levels + lc];
+                if (!*slot)
+                {
+                    /* J_cf_fem (:2754-2783) */
+                    int n_f = n_i, n_c = n_j, N_f = N_i, N_c = N_j;
+                    double *Jf = (double *)xcalloc((size_t)n_f * n_c, sizeof(double));
+                    const double *rf = r_gll[ei->level], *rc = r_gll[lc];
+                    Jf[0 * n_c + 0] = 1.0;
+                    for (int i = 1; i < N_f; i++)
+                        for (int j = 0; j < N_c; j++)
+                            if ((rc[j] <= rf[i]) && (rf[i] <= rc[j + 1]))
+                            {
+                                Jf[i * n_c + (j + 0)] = (rc[j + 1] - rf[i]) / (rc[j + 1] - rc[j]);
+                                Jf[i * n_c + (j + 1)] = (rf[i + 0] - rc[j]) / (rc[j + 1] - rc[j]);
+                            }
+                    Jf[(n_f - 1) * n_c + (n_c - 1)] = 1.0;
+                    *slot = Jf;
+                }
+                const double *Jf = *slot;
+                edge_idx(eid, n_i, dim, idx_i);
+                for (int i = 1; i < n_i - 1; i++)
+                    for (int j = 0; j < n_j; j++)
+                    {
+                        int col = edge_first[eid * nmax + j] - 1;
+                        double val = Jf[i * n_j + j];
+                        if (fabs(val) > epsilon && col >= 0) J_e[(size_t)idx_i[i] * num_cols + col] += val;
+                    }
+            }
+            for (int fid = 0; fid < num_faces; fid++)
+            {
+                if (face_nj[fid] == 0) continue;
+                int n_j = face_nj[fid], N_j = n_j - 1;
+                int lc = -1;
+                for (int l = 0; l < num_levels; l++)
+                    if (poly_degree[l] == N_j) lc = l;
+                const double *Jf = Jf_cache[ei->level * num_levels + lc]; /* filled by the face's edges above */
+                const int *ff = face_first + (size_t)fid * nmax * nmax;
+                face_idx(fid, n_i, idx_i);
+                for (int j = 1; j < n_i - 1; j++)
+                    for (int i = 1; i < n_i - 1; i++)
+                        for (int q = 0; q < n_j; q++)
+                            for (int pp = 0; pp < n_j; pp++)
+                            {
+                                int col = ff[pp + q * n_j] - 1;
+                                double val = Jf[i * n_j + pp] * Jf[j * n_j + q];
+                                if (fabs(val) > epsilon && col >= 0) J_e[(size_t)idx_i[i + j * n_i] * num_cols + col] += val;
+                            }
+            }
+
+            /* dofs of the local columns (:3363-3375) */
+            for (int k = 0; k < num_cols; k++) col_dof[k] = 0;
+            for (int vid = 0; vid < n3; vid++)
+                if (vert_first[vid] > 0) col_dof[vert_first[vid] - 1] = (int)dofn[ei->offset + vid];
+            for (int eid = 0; eid < num_edges; eid++)
+                for (int k = 0; k < edge_nj[eid]; k++)
+                    if (edge_first[eid * nmax + k] > 0) col_dof[edge_first[eid * nmax + k] - 1] = edge_dof[eid * nmax + k];
+            for (int fid = 0; fid < num_faces; fid++)
+                for (int k = 0; k < face_nj[fid] * face_nj[fid]; k++)
+                    if (face_first[(size_t)fid * nmax * nmax + k] > 0) col_dof[face_first[(size_t)fid * nmax * nmax + k] - 1] = face_dof[(size_t)fid * nmax * nmax + k];
+
+            /* J^T A J (:3360-3361) */
+            memset(T_e, 0, (size_t)n3 * num_cols * sizeof(double));
+            for (int i = 0; i < n3; i++)
+                for (int k = 0; k < n3; k++)
+                {
+                    double a = A_e[(size_t)i * n3 + k];
+                    if (a == 0.0) continue;
+                    for (int j = 0; j < num_cols; j++) T_e[(size_t)i * num_cols + j] += a * J_e[(size_t)k * num_cols + j];
+                }
+            memset(JtAJ, 0, (size_t)num_cols * num_cols * sizeof(double));
+            for (int k = 0; k < n3; k++)
+                for (int i = 0; i < num_cols; i++)
+                {
+                    double a = J_e[(size_t)k * num_cols + i];
+                    if (a == 0.0) continue;
+                    for (int j = 0; j < num_cols; j++) JtAJ[(size_t)i * num_cols + j] += a * T_e[(size_t)k * num_cols + j];
+                }
+            for (int i = 0; i < num_cols; i++) /* :3385-3403 */
+                for (int j = 0; j < num_cols; j++)
+                {
+                    int row = col_dof[i], col = col_dof[j];
+                    double val = JtAJ[(size_t)i * num_cols + j];
+                    if (row > 0 && col > 0 && fabs(val) > epsilon) coo_add(&Asub, row - 1, col - 1, val);
+                }
+        }
+        orc_csr A_sub_fem;
+        ij_assemble(&A_sub_fem, nse, nse, &Asub);
+        coo_free(&Asub);
+
+        /* the combined operator on the unique dofs (:3414-3472) */
+        {
+            const int nue = s->sup_num_extended_dofs, ns = s->num_dofs, nu = s->sup_num_dofs, nI = s->num_interface_dofs;
+            int *unique_of = (int *)xcalloc((size_t)nse + nue + 1, sizeof(int)); /* Q_int * (0, 1, 2, ...) */
+            for (int i = 0; i < nse + nue; i++) unique_of[i] = (s->Q_int.ptr[i + 1] > s->Q_int.ptr[i]) ? s->Q_int.col[s->Q_int.ptr[i]] : -1;
+            coo Af;
+            memset(&Af, 0, sizeof(Af));
+            for (int i = 0; i < ns; i++)
+                for (int p = A_sub_fem.ptr[i]; p < A_sub_fem.ptr[i + 1]; p++) coo_add(&Af, unique_of[i], unique_of[A_sub_fem.col[p]], A_sub_fem.val[p]);
+            if (nu > 0)
+                for (int i = nI; i < nu; i++)
+                    for (int p = s->sup_A.ptr[i]; p < s->sup_A.ptr[i + 1]; p++) coo_add(&Af, unique_of[nse + i], unique_of[nse + s->sup_A.col[p]], s->sup_A.val[p]);
+            ij_assemble(&F->A_fem[me], s->num_unique_dofs, s->num_unique_dofs, &Af);
+            coo_free(&Af);
+            free(unique_of);
+        }
+        orc_csr_free(&A_sub_fem);
+
+        for (int i = 0; i < num_levels * num_levels; i++) free(Jf_cache[i]);
+        free(Jf_cache);
+        for (int l = 0; l < num_levels; l++) free(r_gll[l]);
+        free(r_gll);
+        free(rx);
+        free(ry);
+        free(rz);
+        free(A_e);
+        free(J_e);
+        free(T_e);
+        free(JtAJ);
+        free(col_dof);
+        free(idx_i);
+        free(idx_j);
+        free(vert_first);
+        free(edge_first);
+        free(edge_dof);
+        free(edge_nj);
+        free(face_first);
+        free(face_dof);
+        free(face_nj);
+    }
+    else
+    {
+        F->A_fem[me].ptr = (int *)xcalloc(1, sizeof(int));
+    }
+
     /* work arrays (:588-595) */
     {
         size_t tree = (size_t)s->levels[num_levels - 1].offset + (size_t)s->levels[num_levels - 1].num_points;
@@ -1353,6 +1789,8 @@ orc_fdd *orc_fdd_create(int num_ranks, int num_levels, const int *poly_degree, c
     F->sup_num_dofs = (int *)xcalloc((size_t)num_ranks, sizeof(int));
     F->dof_sup = (int **)xcalloc((size_t)num_ranks, sizeof(int *));
     F->comp_levels = (int **)xcalloc((size_t)num_ranks, sizeof(int *));
+    F->A_fem = (orc_csr *)xcalloc((size_t)num_ranks, sizeof(orc_csr));
+    F->point_dof = (int **)xcalloc((size_t)num_ranks, sizeof(int *));
 
     /* corner ids of every element (subdomain.tpp:225-262), element -> (rank, local id) (:270-280) */
     long long *geometry_mesh = (long long *)xcalloc((size_t)E * nv, sizeof(long long));
@@ -1536,6 +1974,8 @@ void orc_fdd_destroy(orc_fdd *F)
         free(F->tree[p]);
         free(F->dof_sup[p]);
         free(F->comp_levels[p]);
+        orc_csr_free(&F->A_fem[p]);
+        free(F->point_dof[p]);
     }
     free(F->sub);
     free(F->num_sub_elems);
@@ -1547,6 +1987,8 @@ void orc_fdd_destroy(orc_fdd *F)
     free(F->sup_num_dofs);
     free(F->dof_sup);
     free(F->comp_levels);
+    free(F->A_fem);
+    free(F->point_dof);
     free(F->coarse_all);
     free(F->coarse_dofs);
     free(F->poly_degree);
@@ -1605,6 +2047,8 @@ const orc_csr *orc_fdd_matrix(const orc_fdd *F, int rank, int which)
     }
 }
 
+const orc_csr *orc_fdd_low_order_matrix(const orc_fdd *F, int rank) { return &F->A_fem[rank]; }
+const int *orc_fdd_point_dofs(const orc_fdd *F, int rank) { return F->point_dof[rank]; }
 const double *orc_fdd_norm_weight(const orc_fdd *F, int rank) { return F->sub[rank]->norm_weight; }
 const double *orc_fdd_inner_weight(const orc_fdd *F, int rank) { return F->sub[rank]->inner_weight; }
 

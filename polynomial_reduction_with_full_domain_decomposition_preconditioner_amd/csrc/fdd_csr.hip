@@ -205,11 +205,13 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(T *__restrict__ Au, c
         {
             // unconditional loads on a selected index (see fdd_multi_row_sum): all of a lane's loads in flight
             const int k = threadIdx.x + it * kBlock;
-            const int ks = (k < nnz) ? k : 0;
+            // slots past the block's non-zeros re-read its first one; a block of empty rows only (nnz == 0: its `base`
+            // may be one past the last stored entry) reads entry 0 of the matrix instead and uses none of it
+            const int ks = (k < nnz) ? base + k : ((nnz > 0) ? base : 0);
             // short-row matrices: the matrix streams are read once per launch and x keeps the L2 (Qt at C2: 91 -> 79 us);
             // the 27-point stencil measured 2 % slower that way
-            c[it] = kStageRows ? __builtin_nontemporal_load(A_col + base + ks) : A_col[base + ks];
-            a[it] = UNIT ? T(1) : (kStageRows ? __builtin_nontemporal_load(A_val + base + ks) : A_val[base + ks]);
+            c[it] = kStageRows ? __builtin_nontemporal_load(A_col + ks) : A_col[ks];
+            a[it] = UNIT ? T(1) : (kStageRows ? __builtin_nontemporal_load(A_val + ks) : A_val[ks]);
         }
         if (kStageRows)
         {
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double
     for (int it = 0; it < kIts; it++)
     {
         const int k = threadIdx.x + it * kBlock;
-        c[it] = __builtin_nontemporal_load(Qt_col + base + ((k < nnz) ? k : 0)); // the index stream is read once
+        c[it] = __builtin_nontemporal_load(Qt_col + ((k < nnz) ? base + k : ((nnz > 0) ? base : 0))); // the index stream is read once (an all-empty block reads entry 0 and uses none of it)
     }
 #pragma unroll
     for (int it = 0; it < kRowIts; it++)
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(kBlock) void gather_norm2_block_kernel(double *__re
         for (int it = 0; it < kIts; it++)
         {
             const int k = threadIdx.x + it * kBlock;
-            c[it] = Qt_col[base + ((k < nnz) ? k : 0)]; // unconditional on a selected index: all loads in flight
+            c[it] = Qt_col[(k < nnz) ? base + k : ((nnz > 0) ? base : 0)]; // unconditional on a selected index: all loads in flight (an all-empty block reads entry 0)
         }
         __syncthreads(); // previous block's readers of x are done
 #pragma unroll

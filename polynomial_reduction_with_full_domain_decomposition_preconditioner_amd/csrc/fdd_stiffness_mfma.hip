@@ -29,6 +29,8 @@
 // own order, so this kernel is NOT bit-identical to the reference arithmetic;
 // it agrees to ~1e-15 * max|Au| (tolerance 1e-12 in tests/).  The top-level
 // order (Au_x + Au_y) + Au_z and the G mixing expressions are the reference's.
+#include <mutex>
+
 #include "fdd_common.h"
 
 namespace
@@ -246,13 +248,15 @@ template <int n>
 int launch_mfma(double *Au, const double *u, const int *point_dof, const double *u_scale, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
 {
     const size_t lds = 4 * (size_t)ARR * sizeof(double);
-    static bool configured = false;
-    if (!configured)
-    {
-        FDD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_stiffness_kernel<n, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FDD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_stiffness_kernel<n, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
+    // once per kernel instance, whichever host thread gets here first
+    static std::once_flag configured;
+    hipError_t attr_a = hipSuccess, attr_b = hipSuccess;
+    std::call_once(configured, [&] {
+        attr_a = hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_stiffness_kernel<n, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_b = hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_stiffness_kernel<n, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    FDD_HIP_CHECK(attr_a);
+    FDD_HIP_CHECK(attr_b);
     const int grid = num_elements < FDD_CU_COUNT ? num_elements : FDD_CU_COUNT;
     if (point_dof)
         hipLaunchKernelGGL((mfma_stiffness_kernel<n, true>), dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);

@@ -42,6 +42,7 @@
 #include <array>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <unordered_map>
 #include <unordered_set>
@@ -111,6 +112,8 @@ struct Composite
     std::vector<double> mask, x, y, z;
     std::vector<double> G[NUM_GEOM_FACTS];
     std::vector<long long> glo; // raw global id in the element's own level mesh
+    std::vector<double> G_deg1[NUM_GEOM_FACTS]; // geometric factors of the degree-1 region elements only (the low-order matrix needs them after G is released)
+    std::vector<int> deg1_offset;               // per region element: first entry in G_deg1, -1 for higher degrees
 
     // numbering and Q
     std::vector<int> point_dof; // direct dof of a point, -1: Dirichlet or hanging
@@ -727,6 +730,23 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
         }
     }
 
+    c.deg1_offset.assign(c.num_sub_ext_elems, -1);
+    {
+        int at = 0;
+        for (int r = 0; r < c.num_sub_ext_elems; r++)
+            if (c.sub[r].N == 1)
+            {
+                c.deg1_offset[r] = at;
+                at += c.sub[r].num_points;
+            }
+        for (int g = 0; g < NUM_GEOM_FACTS; g++)
+        {
+            c.G_deg1[g].resize(at);
+            for (int r = 0; r < c.num_sub_ext_elems; r++)
+                if (c.deg1_offset[r] >= 0) std::copy(c.G[g].begin() + c.sub[r].offset, c.G[g].begin() + c.sub[r].offset + c.sub[r].num_points, c.G_deg1[g].begin() + c.deg1_offset[r]);
+        }
+    }
+
     // ---- coarse level of the whole domain: geometric factors and masked ids of every element's vertices
     // (subdomain.tpp:1632-1713) ----
     auto &coarse_domain = domains[poly_degree[num_levels - 1]];
@@ -1203,6 +1223,310 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
         for (int i = nu; i < nue; i++) c.norm_weight[(size_t)nse + i] = 0.0;
     }
     return c;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Low-order operator of the composite (subdomain.tpp:2749-3472): the matrix the AMG V-cycle of
+// Subdomain::low_order_preconditioner runs on, over the composite's unique dofs.
+//   subdomain part   every region element contributes its low-order matrix A_e -- P1 finite elements on the 6
+//                    tetrahedra of every GLL sub-cell for degree > 1 (:2932-3039), the degree-1 spectral matrix
+//                    itself otherwise (:3040-3125) -- through J_e^T A_e J_e (:3278-3409), J_e = the element's rows of
+//                    the non-conforming Q with the PIECEWISE-LINEAR interpolation J_cf_fem (:2754-2783) on hanging
+//                    edges and faces.  Here: sum_e J_e^T A_e J_e = Q_fem^T blockdiag(A_e) Q_fem, evaluated as two
+//                    sparse products for the elements that have hanging points and by direct summation on the dofs
+//                    for all the others (the bulk);
+//   superdomain part the rows of the superdomain operator A of its regular dofs (:3444-3469);
+// both renumbered to the unique dofs through Q_int (:3414-3417).
+// ---------------------------------------------------------------------------------------------------------------
+inline std::vector<double> interpolator_fem(int N_c, int N_f, const std::vector<double> &r_c, const std::vector<double> &r_f)
+{
+    const int n_c = N_c + 1, n_f = N_f + 1;
+    std::vector<double> J((size_t)n_f * n_c, 0.0);
+    J[0] = 1.0;
+    for (int i = 1; i < N_f; i++)
+        for (int j = 0; j < N_c; j++)
+            if (r_c[j] <= r_f[i] and r_f[i] <= r_c[j + 1])
+            {
+                J[(size_t)i * n_c + j] = (r_c[j + 1] - r_f[i]) / (r_c[j + 1] - r_c[j]);
+                J[(size_t)i * n_c + j + 1] = (r_f[i] - r_c[j]) / (r_c[j + 1] - r_c[j]);
+            }
+    J[(size_t)(n_f - 1) * n_c + (n_c - 1)] = 1.0;
+    return J;
+}
+
+// gll_nodes[l]: the GLL nodes of level l; D_hat_coarse: the 2 x 2 differentiation matrix of degree 1
+inline HostCSR assemble_low_order(const Composite &c, const std::vector<std::vector<double>> &gll_nodes, const std::vector<double> &D_hat_coarse, double epsilon)
+{
+    const int dim = c.dim, nv = c.num_vertices;
+    const int RE = c.num_sub_ext_elems, NP = c.num_sub_ext_points, nse = c.sub_num_ext_dofs;
+    if (dim != 3)
+    {
+        fprintf(stderr, "ERROR: the composite low-order operator is assembled for 3-D regions\n");
+        exit(EXIT_FAILURE);
+    }
+    static const int tets[6][4][3] = {{{0, 0, 0}, {0, 1, 0}, {1, 0, 0}, {1, 0, 1}}, {{1, 0, 0}, {0, 1, 0}, {1, 1, 0}, {1, 0, 1}}, {{0, 0, 0}, {0, 0, 1}, {0, 1, 0}, {1, 0, 1}},
+                                      {{1, 0, 1}, {1, 1, 0}, {1, 1, 1}, {0, 1, 0}}, {{0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {0, 1, 0}}, {{1, 0, 1}, {1, 1, 1}, {0, 1, 1}, {0, 1, 0}}}; // subdomain.tpp:2877-2882
+    static const double Dref[3][4] = {{1.0, 0.0, 0.0, -1.0}, {0.0, 1.0, 0.0, -1.0}, {0.0, 0.0, 1.0, -1.0}}; // :2840-2842
+
+    // elements with a hanging edge or face go through Q_fem^T A Q_fem, the others straight to the dofs
+    std::vector<char> hanging(RE, 0);
+    for (const EdgeLink &l : c.edge_links) hanging[l.elem_i] = 1;
+    for (const FaceLink &l : c.face_links) hanging[l.elem_i] = 1;
+
+    // degree-1 differentiation on the 8 vertices (as in build(), :1715-1748)
+    std::vector<std::vector<double>> Dd(dim, std::vector<double>((size_t)nv * nv, 0.0));
+    for (int row = 0; row < nv; row++)
+        for (int col = 0; col < nv; col++)
+            for (int d = 0; d < dim; d++)
+            {
+                const int rest_mask = (nv - 1) & ~(1 << d);
+                if ((row & rest_mask) != (col & rest_mask)) continue;
+                Dd[d][(size_t)row * nv + col] = D_hat_coarse[((row >> d) & 1) * 2 + ((col >> d) & 1)];
+            }
+    const int g3[3][3] = {{0, 3, 4}, {3, 1, 5}, {4, 5, 2}};
+
+    // the local matrix of element r: entries (li, lj, value) handed to emit()
+    auto element_matrix = [&](int r, std::vector<double> &K, std::vector<unsigned char> &touched, const std::function<void(int, int, double)> &emit) {
+        const RegionElem &el = c.sub[r];
+        const int N = el.N, n = el.n, n3 = el.num_points;
+        const size_t base = (size_t)el.offset;
+        if (N > 1)
+        {
+            K.assign((size_t)n3 * 27, 0.0);
+            touched.assign((size_t)n3 * 27, (unsigned char)0);
+            for (int sz = 0; sz < N; sz++)
+                for (int sy = 0; sy < N; sy++)
+                    for (int sx = 0; sx < N; sx++)
+                        for (int t = 0; t < 6; t++)
+                        {
+                            int loc[4];
+                            double xs[4], ys[4], zs[4];
+                            for (int v = 0; v < 4; v++)
+                            {
+                                loc[v] = (sx + tets[t][v][0]) + (sy + tets[t][v][1]) * n + (sz + tets[t][v][2]) * n * n;
+                                xs[v] = c.x[base + loc[v]];
+                                ys[v] = c.y[base + loc[v]];
+                                zs[v] = c.z[base + loc[v]];
+                            }
+                            const double H[9] = {xs[0] - xs[3], xs[1] - xs[3], xs[2] - xs[3], ys[0] - ys[3], ys[1] - ys[3], ys[2] - ys[3], zs[0] - zs[3], zs[1] - zs[3], zs[2] - zs[3]};
+                            const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
+                            const double id = 1.0 / det;
+                            const double iH[9] = {id * (H[4] * H[8] - H[7] * H[5]), id * (H[2] * H[7] - H[8] * H[1]), id * (H[1] * H[5] - H[4] * H[2]),
+                                                  id * (H[5] * H[6] - H[8] * H[3]), id * (H[0] * H[8] - H[6] * H[2]), id * (H[2] * H[3] - H[5] * H[0]),
+                                                  id * (H[3] * H[7] - H[6] * H[4]), id * (H[1] * H[6] - H[7] * H[0]), id * (H[0] * H[4] - H[3] * H[1])};
+                            double G[3][3];
+                            for (int m = 0; m < 3; m++)
+                                for (int nn = 0; nn < 3; nn++)
+                                {
+                                    double g = 0.0;
+                                    for (int k = 0; k < 3; k++) g += (det / 24.0) * iH[m * 3 + k] * iH[nn * 3 + k];
+                                    G[m][nn] = g;
+                                }
+                            for (int i = 0; i < 4; i++)
+                                for (int j = 0; j < 4; j++)
+                                {
+                                    double a = 0.0;
+                                    for (int m = 0; m < 3; m++)
+                                        for (int nn = 0; nn < 3; nn++)
+                                            for (int q = 0; q < 4; q++) a += Dref[m][i] * (G[m][nn] * Dref[nn][j]);
+                                    if (not(std::abs(a) > epsilon)) continue; // :3025
+                                    const int d0 = tets[t][j][0] - tets[t][i][0], d1 = tets[t][j][1] - tets[t][i][1], d2 = tets[t][j][2] - tets[t][i][2];
+                                    const size_t slot = (size_t)loc[i] * 27 + (size_t)((d0 + 1) + 3 * (d1 + 1) + 9 * (d2 + 1));
+                                    K[slot] += a;
+                                    touched[slot] = 1;
+                                }
+                        }
+            for (int li = 0; li < n3; li++)
+                for (int s = 0; s < 27; s++)
+                    if (touched[(size_t)li * 27 + s]) emit(li, li + (s % 3 - 1) + ((s / 3) % 3 - 1) * n + (s / 9 - 1) * n * n, K[(size_t)li * 27 + s]);
+        }
+        else
+        {
+            // the degree-1 spectral element matrix D^T G D (:3082-3123)
+            const int go = c.deg1_offset[r];
+            double GD[3][64];
+            for (int a = 0; a < dim; a++)
+                for (int i = 0; i < nv; i++)
+                    for (int j = 0; j < nv; j++)
+                    {
+                        double s = 0.0;
+                        for (int b = 0; b < dim; b++) s += c.G_deg1[g3[a][b]][(size_t)go + i] * Dd[b][(size_t)i * nv + j];
+                        GD[a][i * nv + j] = s;
+                    }
+            for (int i = 0; i < nv; i++)
+                for (int j = 0; j < nv; j++)
+                {
+                    double val = 0.0;
+                    for (int k = 0; k < nv; k++)
+                    {
+                        double t = Dd[0][(size_t)k * nv + i] * GD[0][k * nv + j];
+                        for (int a = 1; a < dim; a++) t += Dd[a][(size_t)k * nv + i] * GD[a][k * nv + j];
+                        val += t;
+                    }
+                    if (std::abs(val) > epsilon) emit(i, j, val);
+                }
+        }
+    };
+
+    // (1) conforming elements: straight onto the dofs, element ranges on the host threads
+    HostCSR A_direct;
+    {
+        const int parts = low_order::range_parts(RE);
+        std::vector<std::vector<int>> pti(parts), ptj(parts);
+        std::vector<std::vector<double>> ptv(parts);
+        low_order::parallel_ranges(RE, parts, [&](long long e0, long long e1, int part) {
+            std::vector<int> ti, tj;
+            std::vector<double> tv;
+            std::vector<double> K;
+            std::vector<unsigned char> touched;
+            for (long long r = e0; r < e1; r++)
+            {
+                if (hanging[r]) continue;
+                const int off = c.sub[r].offset;
+                element_matrix((int)r, K, touched, [&](int li, int lj, double v) {
+                    const int di = c.point_dof[off + li], dj = c.point_dof[off + lj];
+                    if (di < 0 or dj < 0) return;
+                    ti.push_back(di);
+                    tj.push_back(dj);
+                    tv.push_back(v);
+                });
+            }
+            pti[part] = std::move(ti);
+            ptj[part] = std::move(tj);
+            ptv[part] = std::move(tv);
+        });
+        std::vector<int> ti, tj;
+        std::vector<double> tv;
+        for (int t = 0; t < parts; t++)
+        {
+            ti.insert(ti.end(), pti[t].begin(), pti[t].end());
+            tj.insert(tj.end(), ptj[t].begin(), ptj[t].end());
+            tv.insert(tv.end(), ptv[t].begin(), ptv[t].end());
+            std::vector<int>().swap(pti[t]);
+            std::vector<int>().swap(ptj[t]);
+            std::vector<double>().swap(ptv[t]);
+        }
+        A_direct = low_order::from_triplets(nse, nse, ti, tj, tv);
+    }
+
+    // (2) elements with hanging points: Q_fem^T A_blk Q_fem on their points (compressed to those elements)
+    HostCSR A_hang;
+    {
+        std::vector<int> local_of(NP, -1); // compressed point index over the hanging elements
+        int nloc = 0;
+        for (int r = 0; r < RE; r++)
+            if (hanging[r])
+                for (int v = 0; v < c.sub[r].num_points; v++) local_of[c.sub[r].offset + v] = nloc++;
+        if (nloc > 0)
+        {
+            std::vector<int> ti, tj;
+            std::vector<double> tv;
+            std::vector<double> K;
+            std::vector<unsigned char> touched;
+            for (int r = 0; r < RE; r++)
+            {
+                if (not hanging[r]) continue;
+                const int lo = local_of[c.sub[r].offset];
+                element_matrix(r, K, touched, [&](int li, int lj, double v) {
+                    ti.push_back(lo + li);
+                    tj.push_back(lo + lj);
+                    tv.push_back(v);
+                });
+            }
+            HostCSR A_blk = low_order::from_triplets(nloc, nloc, ti, tj, tv);
+
+            // Q_fem rows of those points: direct dofs, and J_cf_fem rows on hanging edges / faces (:3287-3355)
+            std::vector<int> qi, qj;
+            std::vector<double> qv;
+            for (int r = 0; r < RE; r++)
+                if (hanging[r])
+                    for (int v = 0; v < c.sub[r].num_points; v++)
+                    {
+                        const int p = c.sub[r].offset + v;
+                        if (c.point_dof[p] >= 0)
+                        {
+                            qi.push_back(local_of[p]);
+                            qj.push_back(c.point_dof[p]);
+                            qv.push_back(1.0);
+                        }
+                    }
+            std::vector<int> idx_i, idx_j;
+            std::map<std::pair<int, int>, std::vector<double>> Jf;
+            auto J_of = [&](const RegionElem &ej, const RegionElem &ei) -> const std::vector<double> & {
+                const std::pair<int, int> key(ej.N, ei.N);
+                auto it = Jf.find(key);
+                if (it == Jf.end()) it = Jf.emplace(key, interpolator_fem(ej.N, ei.N, gll_nodes[ej.level], gll_nodes[ei.level])).first;
+                return it->second;
+            };
+            for (const EdgeLink &l : c.edge_links)
+            {
+                const RegionElem &ei = c.sub[l.elem_i], &ej = c.sub[l.elem_j];
+                edge_points(l.eid, ei.n, dim, idx_i);
+                edge_points(l.eid_j, ej.n, dim, idx_j);
+                const std::vector<double> &J = J_of(ej, ei);
+                for (int i = 1; i < ei.n - 1; i++)
+                    for (int j = 0; j < ej.n; j++)
+                    {
+                        const int d = c.point_dof[ej.offset + idx_j[j]];
+                        const double w = J[(size_t)i * ej.n + j];
+                        if (d < 0 or not(std::abs(w) > epsilon)) continue;
+                        qi.push_back(local_of[ei.offset + idx_i[i]]);
+                        qj.push_back(d);
+                        qv.push_back(w);
+                    }
+            }
+            for (const FaceLink &l : c.face_links)
+            {
+                const RegionElem &ei = c.sub[l.elem_i], &ej = c.sub[l.elem_j];
+                face_points(l.fid, ei.n, idx_i);
+                face_points(l.fid_j, ej.n, idx_j);
+                const std::vector<double> &J = J_of(ej, ei);
+                for (int j = 1; j < ei.n - 1; j++)
+                    for (int i = 1; i < ei.n - 1; i++)
+                        for (int q = 0; q < ej.n; q++)
+                            for (int pp = 0; pp < ej.n; pp++)
+                            {
+                                const int d = c.point_dof[ej.offset + idx_j[pp + q * ej.n]];
+                                const double w = J[(size_t)i * ej.n + pp] * J[(size_t)j * ej.n + q];
+                                if (d < 0 or not(std::abs(w) > epsilon)) continue;
+                                qi.push_back(local_of[ei.offset + idx_i[i + j * ei.n]]);
+                                qj.push_back(d);
+                                qv.push_back(w);
+                            }
+            }
+            HostCSR Qf = low_order::from_triplets(nloc, nse, qi, qj, qv);
+            HostCSR AQ = low_order::multiply(A_blk, Qf);
+            HostCSR Qft = low_order::transpose(Qf);
+            A_hang = low_order::multiply(Qft, AQ);
+        }
+    }
+
+    // (3) the combined operator on the unique dofs (:3419-3472)
+    std::vector<int> ti, tj;
+    std::vector<double> tv;
+    const int ns = c.sub_num_dofs, nI = c.num_interface_dofs, nu = c.sup_num_dofs;
+    auto add_rows = [&](const HostCSR &M) {
+        if (M.rows == 0) return;
+        for (int i = 0; i < ns; i++)
+            for (int p = M.ptr[i]; p < M.ptr[i + 1]; p++)
+            {
+                if (not(std::abs(M.val[p]) > epsilon)) continue; // :3395
+                ti.push_back(c.Q_int_col[i]);
+                tj.push_back(c.Q_int_col[M.col[p]]);
+                tv.push_back(M.val[p]);
+            }
+    };
+    add_rows(A_direct);
+    add_rows(A_hang);
+    for (int i = nI; i < nu; i++)
+        for (int p = c.A_sup.ptr[i]; p < c.A_sup.ptr[i + 1]; p++)
+        {
+            ti.push_back(c.Q_int_col[(size_t)nse + i]);
+            tj.push_back(c.Q_int_col[(size_t)nse + c.A_sup.col[p]]);
+            tv.push_back(c.A_sup.val[p]);
+        }
+    return low_order::from_triplets(c.num_dofs, c.num_dofs, ti, tj, tv);
 }
 
 } // namespace composite

@@ -365,11 +365,20 @@ class Subdomain
         FDD_CALL(fdd_sub_residual_and_search_update(p.as<double>(), r.as<double>(), z.as<double>(), r1.as<double>(), beta_k, num_values, fdd::dev().stream));
     }
 
+    // The V-cycle's hierarchy: handed in (amg_add_level / amg_finalize), built by the caller (amg_build), or -- the
+    // reference's constructor does it unconditionally, subdomain.tpp:2752 -- built here on first use with the
+    // default options.  A region it cannot be built for (2-D, degree 1 without a composite) is an error, not a
+    // silent identity.
     amg::Level &amg_checked()
     {
+        if (not amg_hierarchy.ready() and amg_hierarchy.levels.empty() and dim == 3 and fine_mesh != nullptr and (poly_degree[0] >= 2 or is_composite))
+        {
+            rstdout("Assembling subdomain low-order preconditioner\n"); // subdomain.tpp:2750
+            amg_build(fdd::low_order::Options());
+        }
         if (not amg_hierarchy.ready() or amg_hierarchy.fine_size() != num_dofs)
         {
-            fprintf(stderr, "ERROR: Subdomain::use_preconditioner = true needs an attached AMG hierarchy over the %d dofs (amg_add_level / amg_finalize)\n", num_dofs);
+            fprintf(stderr, "ERROR: Subdomain::use_preconditioner = true needs an AMG hierarchy over the %d dofs (amg_add_level / amg_finalize, or amg_build: 3-D regions of degree >= 2)\n", num_dofs);
             exit(EXIT_FAILURE);
         }
         return amg_hierarchy.levels[0];
@@ -411,7 +420,7 @@ class Subdomain
     int num_iterations = 0;
     int num_vectors = 4;
     int max_iterations = 4;
-    bool use_preconditioner = false; // reference default: true (needs the HYPRE-built hierarchy)
+    bool use_preconditioner = true; // subdomain.hpp:231; the hierarchy is handed in (amg_add_level) or built on first use (amg_build)
     DType tolerance = 1.0e-12;
     DType epsilon = 1.0e-12;
 
@@ -433,7 +442,7 @@ class Subdomain
     // (stands in for subdomain.tpp:2749-3549, see low_order.hpp).  Returns the number of levels.
     int amg_build(fdd::low_order::Options options, bool verbose = false)
     {
-        if (dim != 3 or fine_mesh == nullptr or poly_degree[0] < 2)
+        if (dim != 3 or fine_mesh == nullptr or (poly_degree[0] < 2 and not is_composite))
         {
             fprintf(stderr, "ERROR: Subdomain::amg_build handles 3-D regions of degree >= 2\n");
             exit(EXIT_FAILURE);
@@ -441,7 +450,23 @@ class Subdomain
         options.cheby_order = cheby_order;
         const auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t0 = clock();
-        fdd::low_order::HostCSR A = fdd::low_order::assemble_fem(fine_mesh->x.data(), fine_mesh->y.data(), fine_mesh->z.data(), point_dof.data(), num_dofs, poly_degree[0], fine_mesh->num_local_elements, epsilon);
+        fdd::low_order::HostCSR A;
+        if (is_composite)
+        {
+            // the composite's low-order operator: mixed-degree region with its hanging edges / faces, plus the
+            // superdomain rows (subdomain.tpp:2749-3472, composite.hpp)
+            std::vector<std::vector<double>> nodes(num_levels);
+            for (int l = 0; l < num_levels; l++)
+            {
+                const int n = poly_degree[l] + 1;
+                std::vector<double> w(n);
+                nodes[l].resize(n);
+                fdd::gll::zwgll(nodes[l].data(), w.data(), n);
+            }
+            A = fdd::composite::assemble_low_order(comp, nodes, D_hat[num_levels - 1].first, (double)epsilon);
+        }
+        else
+            A = fdd::low_order::assemble_fem(fine_mesh->x.data(), fine_mesh->y.data(), fine_mesh->z.data(), point_dof.data(), num_dofs, poly_degree[0], fine_mesh->num_local_elements, epsilon);
         const double t1 = clock();
         std::vector<fdd::low_order::Level> lv = fdd::low_order::build(std::move(A), options, verbose);
         const double t2 = clock();

@@ -12,6 +12,7 @@ def check_two_dimensional_solve(H, directory):
     for deg in S.level_degrees(N, red):
         S.write_mesh_files(directory, S.QuadMesh(E, deg, amplitude=0.05))
     p = H.Problem.from_directory(directory, N, red)
+    p.set_flag("sub_use_preconditioner", 0)  # the low-order hierarchy is built for 3-D regions only
     assert p.info["dim"] == 2 and p.n == E[0] * E[1] * (N + 1) ** 2
     for lvl in range(p.info["num_levels"]):
         p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])

@@ -120,6 +120,8 @@ def oracle():
         L.orc_fdd_composite_levels.restype = ctypes.POINTER(ctypes.c_int)
         L.orc_fdd_matrix.restype = ctypes.POINTER(OrcCsr)
         L.orc_fdd_norm_weight.restype = ctypes.POINTER(ctypes.c_double)
+        L.orc_fdd_low_order_matrix.restype = ctypes.POINTER(OrcCsr)
+        L.orc_fdd_point_dofs.restype = ctypes.POINTER(ctypes.c_int)
         L.orc_fdd_inner_weight.restype = ctypes.POINTER(ctypes.c_double)
         L.orc_amg32_create.restype = vp
         _oracle = L
@@ -527,6 +529,40 @@ class OracleFdd:
         ptr, col, val = c.to_numpy()
         return sp.csr_matrix((val, col, ptr), shape=(c.num_rows, c.num_cols))
 
+    def low_order_matrix(self, r):
+        """the composite's low-order operator over the unique dofs (subdomain.tpp:2749-3472), scipy CSR"""
+        import scipy.sparse as sp
+
+        c = self.L.orc_fdd_low_order_matrix(self.f, r).contents
+        ptr, col, val = c.to_numpy()
+        return sp.csr_matrix((val, col, ptr), shape=(c.num_rows, c.num_cols))
+
+    def point_dofs(self, r):
+        return np.ctypeslib.as_array(self.L.orc_fdd_point_dofs(self.f, r), shape=(self.info[r]["points"],)).copy()
+
+    def attach_amg(self, r, levels, cheby_order=2, num_vcycles=1):
+        """hand rank r's composite the hierarchy of its low-order preconditioner (finest level first, in the oracle's numbering)"""
+        ip = ctypes.POINTER(ctypes.c_int)
+        amg = vp(self.L.orc_amg_create(len(levels), cheby_order, num_vcycles))
+        keep = []
+        for l, lv in enumerate(levels):
+            A = lv["A"].tocsr()
+            A.sort_indices()
+            arrs = [np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32), np.ascontiguousarray(A.data, dtype=np.float64),
+                    np.ascontiguousarray(lv["D"], dtype=np.float64), np.ascontiguousarray(lv["coefs"], dtype=np.float64)]
+            if lv.get("P") is not None:
+                P = lv["P"].tocsr()
+                P.sort_indices()
+                parr = [np.ascontiguousarray(P.indptr, dtype=np.int32), np.ascontiguousarray(P.indices, dtype=np.int32), np.ascontiguousarray(P.data, dtype=np.float64)]
+                pargs = (P.shape[1], parr[0].ctypes.data_as(ip), parr[1].ctypes.data_as(ip), _p(parr[2]))
+                arrs += parr
+            else:
+                pargs = (0, None, None, None)
+            keep.append(arrs)
+            self.L.orc_amg_set_level(amg, l, A.shape[0], arrs[0].ctypes.data_as(ip), arrs[1].ctypes.data_as(ip), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), *pargs)
+        self.L.orc_subdomain_attach_amg(self.sub(r), amg)
+        self._amg_keep = getattr(self, "_amg_keep", []) + [(amg, keep)]
+
     def norm_weight(self, r):
         n = self.info[r]["sub_ext_dofs"] + self.info[r]["sup_ext_dofs"]
         return np.ctypeslib.as_array(self.L.orc_fdd_norm_weight(self.f, r), shape=(n,)).copy()
@@ -572,6 +608,35 @@ class OracleFdd:
         rr = [np.ascontiguousarray(a) for a in r]
         self.L.orc_fdd_precondition(self.f, self._pp(z), self._pp(rr), 0 if method == "fcg" else 1, ctypes.byref(opts), _p(hist), cap, nh)
         return z, [hist[k, : nh[k]].copy() for k in range(self.R)]
+
+
+def composite_dof_permutation(product_point_dofs, oracle_point_dofs, num_sub_dofs, num_unique_dofs):
+    """to_oracle[u]: the oracle's unique dof of the product's unique dof u.  The two sides number the subdomain's own
+    dofs differently (Domain node order vs the reference's ranking of global ids) and everything else alike; the
+    points that carry a dof directly pair them up."""
+    both = (product_point_dofs >= 0) & (oracle_point_dofs >= 0)
+    assert np.array_equal(product_point_dofs >= 0, oracle_point_dofs >= 0)
+    to_oracle = np.arange(num_unique_dofs)
+    a, b = product_point_dofs[both], oracle_point_dofs[both]
+    own = a < num_sub_dofs
+    assert np.array_equal(own, b < num_sub_dofs)
+    to_oracle[a[own]] = b[own]
+    assert len(np.unique(to_oracle)) == num_unique_dofs
+    return to_oracle
+
+
+def permute_hierarchy(levels, to_oracle):
+    """level 0 of a hierarchy (A, D, coefs, P) renumbered by to_oracle; coarse levels shared"""
+    import scipy.sparse as sp
+
+    nd = len(to_oracle)
+    Pm = sp.csr_matrix((np.ones(nd), (to_oracle, np.arange(nd))), shape=(nd, nd))
+    fine = dict(levels[0])
+    fine["A"] = (Pm @ levels[0]["A"] @ Pm.T).tocsr()
+    fine["D"] = np.asarray(Pm @ levels[0]["D"])
+    if levels[0].get("P") is not None:
+        fine["P"] = (Pm @ levels[0]["P"]).tocsr()
+    return [fine] + list(levels[1:])
 
 
 def seeded_uniform(n, seed=1234):

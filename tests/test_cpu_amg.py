@@ -60,6 +60,7 @@ from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd impo
 lib._host = lib._Lib(%r, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
 H.init(0, use_torch_stream=False); H.comm_single(); H.set_print(False)
 p = H.Problem.box((4, 4, 4), (1, 1, 1), 3, 2, True)
+p.set_flag("sub_use_preconditioner", 0)
 for lvl in range(p.info["num_levels"]):
     p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
 its = amg_checks.check_amg(p, 3, 2)
@@ -88,6 +89,7 @@ lib._host = lib._Lib(%r, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last
 H.init(0, use_torch_stream=False); H.comm_single(); H.set_print(False)
 E, N, red = (3, 2, 2), 4, 2
 p = H.Problem.box(E, (1, 1, 1), N, red, True)
+p.set_flag("sub_use_preconditioner", 0)
 for lvl in range(p.info["num_levels"]):
     p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
 assert p.amg_build(coarsest_size=30) >= 2
@@ -181,6 +183,7 @@ from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd impo
 lib._host = lib._Lib(%r, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
 H.init(0, use_torch_stream=False); H.comm_single(); H.set_print(False)
 p = H.Problem.box((4, 4, 4), (1, 1, 1), 3, 2, True)
+p.set_flag("sub_use_preconditioner", 0)
 for lvl in range(p.info["num_levels"]):
     p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
 its = amg_checks.check_amg_f32(p, 3, 2)

@@ -31,7 +31,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None):
+def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None, composite=False, overlaps=(1, 1)):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -47,7 +47,7 @@ def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None):
         H.init(0, use_torch_stream=False)
         H.set_print(False)
         H.comm_torch_callbacks(on_gpu=False)
-        lib.host().call("fddh_comm_selftest", 1000)  # all-reduce sum/max, all-gather, all-gatherv, barrier
+        lib.host().call("fddh_comm_selftest", 1000)  # all-reduce sum/max, all-gather, all-gatherv, grouped send/receive, barrier
 
         Pg = S.rank_grid(world)
         if mesh_dir:
@@ -55,9 +55,11 @@ def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None):
             for deg in (S.level_degrees(N, red) if with_sub else [N]):
                 S.write_mesh_files(mesh_dir, S.BoxMesh(E, deg, Pg, rank), proc_id=rank)
             dist.barrier()
-            p = H.Problem.from_directory(mesh_dir, N, red, with_subdomain=with_sub)
+            p = H.Problem.from_directory(mesh_dir, N, red, overlaps[0], overlaps[1], with_subdomain=with_sub, block_local=not composite)
         else:
-            p = H.Problem.box(E, Pg, N, red, with_sub)
+            p = H.Problem.box(E, Pg, N, red, with_sub, overlaps[0], overlaps[1], block_local=not composite)
+        if with_sub:
+            p.set_flag("sub_use_preconditioner", 0)  # the inner solves of this test run without the V-cycle
         for lvl in range(p.info["num_levels"]):
             p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
 
@@ -93,12 +95,46 @@ def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None):
         u_star, f = p.make_rhs_from(us[rank])
         assert np.abs(f - o_f[rank]).max() <= 1e-13 * np.abs(o_f[rank]).max()
 
-        sds = [S.OracleSubdomain(E, N, red, Pg, r) for r in range(world)] if with_sub else None
+        if with_sub and composite:
+            # the full-domain-decomposition composite of every rank against the oracle's R-rank world
+            # (oracle/fdd_oracle_composite.c): region, sizes, operators on composite vectors, the tree exchange
+            F = S.OracleFdd(E, N, red, Pg, overlaps[0], overlaps[1])
+            si, oi = p.sub_info(), F.info[rank]
+            assert si["is_composite"] == 1
+            assert si["num_peers"] >= 1
+            ids, lv = p.sub_region()
+            oids, olv = F.region(rank)
+            assert np.array_equal(ids, oids) and np.array_equal(lv, olv)
+            assert len(set(lv.tolist())) > 1  # mixed degrees in the region
+            for a, b in (("num_elems", "sub_elems"), ("num_ext_elems", "sub_ext_elems"), ("num_points", "points"), ("sub_dofs", "sub_dofs"), ("sub_ext_dofs", "sub_ext_dofs"), ("interface_dofs", "interface_dofs"),
+                         ("sup_dofs", "sup_dofs"), ("sup_ext_dofs", "sup_ext_dofs"), ("unique_dofs", "unique_dofs"), ("coarse_dofs", "coarse_dofs"), ("num_values", "num_values")):
+                assert si[a] == oi[b], (a, si[a], oi[b])
+            assert p.sub_composite_levels() == F.composite_levels(rank)
+            v = np.random.default_rng(5 + rank).standard_normal(si["num_values"])
+            for op in ("stiffness", "dssum"):
+                ref = getattr(F, op)(rank, v)
+                assert np.abs(p.sub_op(op, v) - ref).max() <= 1e-12 * np.abs(ref).max(), op
+            ref = F.residual_norm(rank, v)
+            assert abs(p.sub_residual_norm(v) - ref) <= 1e-12 * ref
+            ref = F.tree(us)[rank]
+            assert np.abs(p.sub_op("tree", us[rank]) - ref).max() <= 1e-12 * np.abs(ref).max()
+            for method in ("gmres", "fcg"):
+                z, hist = p.precond_apply(us[rank], method)
+                oz, oh = F.precondition(us, method)
+                assert np.abs(z - oz[rank]).max() <= 1e-9 * np.abs(oz[rank]).max(), method
+                assert np.abs(hist - oh[rank]).max() <= 1e-9 * oh[rank][0], method
 
-        def pre(z, r):
-            for k in range(world):
-                out, _, _ = sds[k].solve(r[k], "gmres")
-                z[k][:] = out
+            def pre(z, r):
+                out, _ = F.precondition(r, "gmres")
+                for k in range(world):
+                    z[k][:] = out[k]
+        else:
+            sds = [S.OracleSubdomain(E, N, red, Pg, r) for r in range(world)] if with_sub else None
+
+            def pre(z, r):
+                for k in range(world):
+                    out, _, _ = sds[k].solve(r[k], "gmres")
+                    z[k][:] = out
 
         for method in ("fcg", "gmres"):
             u, its, hist = p.solve(f, method)
@@ -128,6 +164,99 @@ def test_host_layer_multirank_gloo(cpu_host_lib, world, with_sub):
     mp.spawn(_worker, args=(world, _free_port(), E, N, red, with_sub), nprocs=world, join=True)
 
 
+@pytest.mark.parametrize("world,E,N,red,overlaps", [
+    (2, (8, 4, 4), 3, 2, (1, 1)),    # two levels; every coarse dof kept
+    (2, (16, 4, 4), 3, 2, (1, 1)),   # the far superdomain is aggregated (two composite levels)
+    (4, (8, 8, 4), 4, 2, (1, 1)),    # three levels (4, 2, 1): rings at every degree
+    (8, (8, 8, 8), 3, 2, (1, 1)),    # 2x2x2: the scaling run's topology
+    (2, (16, 4, 4), 3, 1, (1, 2)),   # reduction 1 (levels 3, 2, 1), superdomain overlap 2
+])
+def test_full_domain_decomposition_composite_gloo(cpu_host_lib, world, E, N, red, overlaps):
+    """The composite of SURVEY 8(f) next-1 from the host layer under a gloo group -- neighbour rings at reduced
+    degree, non-conforming Q, graded superdomain, interface maps, ring pull + coarse all-gather in tree_operator --
+    against the oracle's restatement of subdomain.tpp:86-2747 for the same R ranks, then the outer solves
+    preconditioned by it (identical iteration counts and histories)."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker, args=(world, _free_port(), E, N, red, True, None, True, overlaps), nprocs=world, join=True)
+
+
+def _amg_worker(rank, world, port, E, N, red):
+    """The reference's DEFAULT inner preconditioner on the composite: the AMG V-cycle on the composite's low-order
+    operator (subdomain.tpp:2749-3472: P1 elements on the GLL sub-cells of the mixed-degree region, piecewise-linear
+    constraints on hanging edges / faces, the superdomain rows), inside the inner GMRES / CG of every rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
+
+    lib._host = lib._Lib(HOST_CPU_SO, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H.init(0, use_torch_stream=False)
+        H.set_print(False)
+        H.comm_torch_callbacks(on_gpu=False)
+        Pg = S.rank_grid(world)
+        p = H.Problem.box(E, Pg, N, red, True)  # defaults: composite region, use_preconditioner = true
+        for lvl in range(p.info["num_levels"]):
+            p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
+        si = p.sub_info()
+        F = S.OracleFdd(E, N, red, Pg)
+
+        # the low-order operator against the oracle's dense restatement; the hierarchy on top of it is this
+        # build's own (HYPRE BoomerAMG in the reference), so the oracle's V-cycle runs on the product's levels
+        assert p.amg_build(coarsest_size=40) >= 2
+        levels = p.amg_levels()
+        to_oracle = S.composite_dof_permutation(p.sub_point_dofs(), F.point_dofs(rank), si["sub_dofs"], si["unique_dofs"])
+        olevels = S.permute_hierarchy(levels, to_oracle)
+        Ao = F.low_order_matrix(rank)
+        assert olevels[0]["A"].nnz == Ao.nnz
+        assert abs(olevels[0]["A"] - Ao).max() <= 1e-12 * abs(Ao).max()
+        assert abs(Ao - Ao.T).max() <= 1e-12 * abs(Ao).max()
+        every = [None] * world
+        dist.all_gather_object(every, olevels)
+        for r in range(world):
+            F.attach_amg(r, every[r])
+
+        meshes = [S.BoxMesh(E, N, Pg, r) for r in range(world)]
+        us = [np.sin(3 * m.x + 1) * np.cos(2 * m.y) + m.z * m.x for m in meshes]
+        for method in ("gmres", "fcg"):
+            z, hist = p.precond_apply(us[rank], method)
+            oz, oh = F.precondition(us, method, use_preconditioner=True)
+            assert np.abs(z - oz[rank]).max() <= 1e-9 * np.abs(oz[rank]).max(), method
+            assert np.abs(hist - oh[rank]).max() <= 1e-9 * oh[rank][0], method
+            _, plain = F.precondition(us, method, use_preconditioner=False)
+            assert oh[rank][-1] < plain[rank][-1]  # the V-cycle helps
+
+        W = S.OracleWorld(meshes, N)
+        f = W.stiffness(W.dssum(us, True, True))
+
+        def pre(z, r):
+            out, _ = F.precondition(r, "gmres", use_preconditioner=True)
+            for k in range(world):
+                z[k][:] = out[k]
+
+        for method in ("fcg", "gmres"):
+            u, its, hist = p.solve(f[rank], method)
+            ou, oits, ohist = W.solve(f, method, precond=pre)
+            assert its == oits, (method, its, oits)
+            assert np.abs(hist - ohist).max() <= 1e-8 * ohist[0]
+            assert np.abs(u - ou[rank]).max() <= 1e-8 * np.abs(ou[rank]).max()
+        p.close()
+        W.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,E,N,red", [(2, (16, 4, 4), 3, 2), (4, (8, 8, 4), 4, 2)])
+def test_composite_with_low_order_preconditioner_gloo(cpu_host_lib, world, E, N, red):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_amg_worker, args=(world, _free_port(), E, N, red), nprocs=world, join=True)
+
+
 def test_single_rank_cpu_shim_equals_oracle(cpu_host_lib):
     """The shim-backed host layer reproduces the oracle's C1 golden histories
     bit for bit (same kernels, same reduction tree): a check of the host
@@ -142,6 +271,7 @@ lib._host = lib._Lib(%r, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last
 H.init(0, use_torch_stream=False); H.comm_single(); H.set_print(False)
 gold = json.load(open(os.path.join(S.GOLDEN_DIR, "oracle_c1.json")))
 p = H.Problem.box((4, 4, 4), (1, 1, 1), 3, 2, True)
+p.set_flag("sub_use_preconditioner", 0)
 for lvl in range(p.info["num_levels"]):
     p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
 m = S.ArrayMesh.from_problem(p)

@@ -27,6 +27,7 @@ def own_stream(gpu):
 
 def make_problem(E, N, red):
     p = H.Problem.box(E, (1, 1, 1), N, red, True)
+    p.set_flag("sub_use_preconditioner", 0)  # switched on by the checks once the hierarchy under test is attached
     for lvl in range(p.info["num_levels"]):
         p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
     return p

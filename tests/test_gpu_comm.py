@@ -46,6 +46,7 @@ def test_solve_is_identical_under_every_backend(group):
     for setup in (H.comm_single, lambda: H.comm_torch_callbacks(on_gpu=True), H.comm_rccl_from_torch):
         setup()
         p = H.Problem.box((4, 4, 4), (1, 1, 1), 3, 2, True)
+        p.set_flag("sub_use_preconditioner", 0)
         _, f = p.make_rhs(0, 0)
         u, its, hist = p.solve(f, "fcg")
         results.append((u, its, hist))
@@ -54,7 +55,7 @@ def test_solve_is_identical_under_every_backend(group):
         assert its == results[0][1] and np.array_equal(hist, results[0][2]) and np.array_equal(u, results[0][0])
 
 
-def _two_rank_worker(rank, world, port, E, N, red):
+def _two_rank_worker(rank, world, port, E, N, red, composite=False):
     """One of `world` ranks that all drive cuda:0; collectives go through a gloo
     group with the device buffers staged over the host (the solver's multi-rank
     code path -- interface exchange, device-side scalars, node-space PCG -- is
@@ -75,7 +76,8 @@ def _two_rank_worker(rank, world, port, E, N, red):
         H.comm_torch_callbacks(on_gpu=True, staged=True)
         lib.host().call("fddh_comm_selftest", 1000)
         Pg = S.rank_grid(world)
-        p = H.Problem.box(E, Pg, N, red, True)
+        p = H.Problem.box(E, Pg, N, red, True, block_local=not composite)
+        p.set_flag("sub_use_preconditioner", 0)
         for lvl in range(p.info["num_levels"]):
             p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
         meshes = [S.BoxMesh(E, N, Pg, r) for r in range(world)]
@@ -84,12 +86,37 @@ def _two_rank_worker(rank, world, port, E, N, red):
         o_f = W.stiffness(W.dssum(us, True, True))
         _, f = p.make_rhs_from(us[rank])
         assert np.abs(f - o_f[rank]).max() <= 1e-13 * np.abs(o_f[rank]).max()
-        sds = [S.OracleSubdomain(E, N, red, Pg, r) for r in range(world)]
+        if composite:
+            # the full-domain-decomposition composite on the HIP kernels: mixed-degree level lists, non-conforming Q,
+            # CSR tail, ring pull and coarse all-gather on device buffers, against the oracle's 2-rank world
+            F = S.OracleFdd(E, N, red, Pg)
+            si, oi = p.sub_info(), F.info[rank]
+            assert si["is_composite"] == 1 and si["num_values"] == oi["num_values"] and si["unique_dofs"] == oi["unique_dofs"]
+            ids, lv = p.sub_region()
+            assert np.array_equal(ids, F.region(rank)[0]) and len(set(lv.tolist())) > 1
+            v = np.random.default_rng(5 + rank).standard_normal(si["num_values"])
+            for op in ("stiffness", "dssum"):
+                ref = getattr(F, op)(rank, v)
+                assert np.abs(p.sub_op(op, v) - ref).max() <= 1e-12 * np.abs(ref).max(), op
+            ref = F.tree(us)[rank]
+            assert np.abs(p.sub_op("tree", us[rank]) - ref).max() <= 1e-12 * np.abs(ref).max()
+            for method in ("gmres", "fcg"):
+                z, hist = p.precond_apply(us[rank], method)
+                oz, oh = F.precondition(us, method)
+                assert np.abs(z - oz[rank]).max() <= 1e-9 * np.abs(oz[rank]).max(), method
+                assert np.abs(hist - oh[rank]).max() <= 1e-9 * oh[rank][0], method
 
-        def pre(z, r):
-            for k in range(world):
-                out, _, _ = sds[k].solve(r[k], "gmres")
-                z[k][:] = out
+            def pre(z, r):
+                out, _ = F.precondition(r, "gmres")
+                for k in range(world):
+                    z[k][:] = out[k]
+        else:
+            sds = [S.OracleSubdomain(E, N, red, Pg, r) for r in range(world)]
+
+            def pre(z, r):
+                for k in range(world):
+                    out, _, _ = sds[k].solve(r[k], "gmres")
+                    z[k][:] = out
 
         for method in ("fcg", "gmres"):
             u, its, hist = p.solve(f, method)
@@ -108,13 +135,24 @@ def _two_rank_worker(rank, world, port, E, N, red):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_against_the_oracle_world(gpu):
+def _port():
     import socket
-
-    import torch.multiprocessing as mp
 
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, (4, 4, 4), 3, 2), nprocs=2, join=True)
+    return port
+
+
+def test_two_ranks_on_one_gpu_against_the_oracle_world(gpu):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_two_rank_worker, args=(2, _port(), (4, 4, 4), 3, 2), nprocs=2, join=True)  # block-local regions
+
+
+def test_two_ranks_on_one_gpu_full_domain_decomposition_composite(gpu):
+    """The composite region (rings at reduced degree + graded superdomain) of two ranks that share cuda:0."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_two_rank_worker, args=(2, _port(), (16, 4, 4), 3, 2, True), nprocs=2, join=True)

@@ -23,6 +23,7 @@ def problem(gpu):
     H.comm_single()
     H.set_print(False)
     p = H.Problem.box(E, (1, 1, 1), N, RED, True)
+    p.set_flag("sub_use_preconditioner", 0)
     yield p
     p.close()
 
@@ -96,6 +97,7 @@ def problem15(gpu):
     H.comm_single()
     H.set_print(False)
     p = H.Problem.box((16, 16, 16), (1, 1, 1), 15, RED, True)
+    p.set_flag("sub_use_preconditioner", 0)
     yield p
     p.close()
 

@@ -28,6 +28,8 @@ def setup(gpu):
 
 def make_problem(E, N, red, with_sub=True):
     p = H.Problem.box(E, (1, 1, 1), N, red, with_sub)
+    if with_sub:
+        p.set_flag("sub_use_preconditioner", 0)  # these tests run the inner solves without the V-cycle (test_gpu_amg.py has it)
     # feed the reference's own GLL tables so operator parity is bit-exact
     for lvl in range(p.info["num_levels"]):
         p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
@@ -42,6 +44,7 @@ def oracle_subdomain(p, N, red):
 def test_gll_tables_of_the_host_layer(setup):
     """host/gll.hpp against the reference's Fortran speclib tables."""
     p = H.Problem.box((2, 2, 2), (1, 1, 1), 15, 1, True)
+    p.set_flag("sub_use_preconditioner", 0)
     try:
         assert p.info["num_levels"] == 15
         for lvl in range(15):
@@ -305,6 +308,8 @@ def test_mesh_file_roundtrip(setup, tmp_path):
         lib.host().call("fddh_write_box_mesh_files", d.encode(), E, P, deg, 0)
     p = H.Problem.from_directory(d, 3, 2)
     q = H.Problem.box((3, 2, 2), (1, 1, 1), 3, 2)
+    p.set_flag("sub_use_preconditioner", 0)
+    q.set_flag("sub_use_preconditioner", 0)
     try:
         for name in ("x", "glo_num", "node_degree", "p_mask", "g_1", "g_3"):
             assert np.array_equal(p.mesh_array(name), q.mesh_array(name))
@@ -346,6 +351,7 @@ def test_curved_mesh_from_files(setup, tmp_path):
     for deg in S.level_degrees(N, red):
         S.write_mesh_files(d, S.DeformedMesh(E, deg))
     p = H.Problem.from_directory(d, N, red)
+    p.set_flag("sub_use_preconditioner", 0)
     for lvl in range(p.info["num_levels"]):
         p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
     meshes = [S.ArrayMesh.from_problem(p, lvl) for lvl in range(p.info["num_levels"])]

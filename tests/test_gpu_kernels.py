@@ -406,6 +406,31 @@ def test_csr_ragged_rows(gpu):
     run_csr_case(gpu, ptr, col, val, 5000, expect_kind=1, exact=False)
 
 
+def test_csr_runs_of_empty_rows(gpu):
+    """Leading, inner and trailing runs of empty rows longer than a row block (a block whose rows hold no entry at
+    all: its first-entry index may sit one past the end of col / val), next to rows wide enough that the LDS-staged
+    kernel is chosen -- the shape of the composite region's non-conforming Q (Dirichlet points have no entry, hanging
+    points have (N_j + 1)^2 of them)."""
+    rng = np.random.default_rng(12)
+    rows = 9000
+    lens = rng.integers(0, 3, rows)
+    lens[:2600] = 0       # leading
+    lens[4000:6700] = 0   # inner
+    lens[-2300:] = 0      # trailing: base == nnz for these blocks
+    lens[3000:3040] = 36
+    ptr, col, val = csr_random(rows, 4000, lens, 13)
+    assert ptr[-1] > rows // 8
+    run_csr_case(gpu, ptr, col, val, 4000)
+    lens[3000:3400] = 64  # more entries than rows: row-block kernel for sure
+    ptr, col, val = csr_random(rows, 4000, lens, 14)
+    run_csr_case(gpu, ptr, col, val, 4000, expect_kind=1)
+    # boolean variant (unit values, dssum-style gather plans)
+    lens = np.zeros(rows, np.int64)
+    lens[2500:5000] = rng.integers(1, 9, 2500)
+    ptr, col, _ = csr_random(rows, 4000, lens, 15)
+    run_csr_case(gpu, ptr, col, np.ones(len(col)), 4000, expect_kind=1)
+
+
 def test_csr_empty_matrix(gpu):
     ptr = np.zeros(11, np.int32)
     run_csr_case(gpu, ptr, np.zeros(0, np.int32), np.zeros(0), 7, expect_kind=0)
