@@ -271,6 +271,7 @@ int fdd_vector_scaling_dev(double *au, const double *scale_dev, const double *u,
 int fdd_multi_lincomb_scaled_dev(double *q, int q_is_zero, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream); /* fdd_multi_axpy_scaled_dev; q_is_zero: q is taken to be 0 and is not read (it need not have been cleared) */
 int fdd_multi_lincomb_limited_dev(double *q, int q_is_zero, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, const double *last_dev, int m, int n, void *stream); /* only vectors 0..(int)*last_dev enter (NULL: all m) */
 int fdd_sqrt_sum_dev(double *out, const double *parts_dev, int nparts, void *stream); /* out[0] = sqrt(sum parts): a residual norm appended to a device-side history */
+int fdd_xmay_ratio_dev(double *out, const double *x, const double *num_dev, const double *den_dev, const double *y, int n, void *stream); /* out = x - (*num / *den) * y (domain.okl:191: r+ = r - alpha q with alpha on the device; out may be x) */
 int fdd_xpby_ratio_dev(double *out, const double *x, const double *num_dev, const double *den_dev, const double *y, int n, void *stream); /* out = x + (*num / *den) * y (domain.okl:226: p = z + beta p; out may be y) */
 /* out[0] = sum_nodes s*s*w with s = (Qt u)[node]*w[node]: Subdomain::residual_norm
  * (subdomain.tpp:4491-4515: multiply_weight + weighted_inner_product) without the dof vector */

@@ -141,6 +141,21 @@ struct XpbyRatioDevOp
     __device__ void one(long long i) const { out[i] = x[i] + (*num / *den) * y[i]; }
 };
 
+// out = x - (*num / *den) * y: the r+ = r - alpha*q half of solution_and_residual_update (domain.okl:186-193) on
+// a vector the node-space solve keeps beside its node vectors (the point-space residual the degree tree is fed with)
+struct XmayRatioDevOp
+{
+    double *out;
+    const double *x, *y, *num, *den;
+    __device__ void vec2(long long i) const
+    {
+        const double alpha = *num / *den;
+        const double2 a = ld2(x, i), b = ld2(y, i);
+        st2(out, i, make_double2(a.x - alpha * b.x, a.y - alpha * b.y));
+    }
+    __device__ void one(long long i) const { out[i] = x[i] - (*num / *den) * y[i]; }
+};
+
 } // namespace
 __global__ void fdd_sqrt_sum_kernel(double *out, const double *parts, int nparts)
 {
@@ -588,6 +603,14 @@ int fdd_xpby_ratio_dev(double *out, const double *x, const double *num_dev, cons
     if (n == 0) return 0;
     FDD_REQUIRE(out != nullptr && x != nullptr && y != nullptr && num_dev != nullptr && den_dev != nullptr);
     return launch_ew(XpbyRatioDevOp{out, x, y, num_dev, den_dev}, n, fdd_aligned16(out) && fdd_aligned16(x) && fdd_aligned16(y), stream);
+}
+
+int fdd_xmay_ratio_dev(double *out, const double *x, const double *num_dev, const double *den_dev, const double *y, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(out != nullptr && x != nullptr && y != nullptr && num_dev != nullptr && den_dev != nullptr);
+    return launch_ew(XmayRatioDevOp{out, x, y, num_dev, den_dev}, n, fdd_aligned16(out) && fdd_aligned16(x) && fdd_aligned16(y), stream);
 }
 
 int fdd_vector_scaling_dev(double *au, const double *scale_dev, const double *u, int n, void *stream)

@@ -49,6 +49,11 @@ struct NoPreconditioner
     int dofs() const { return 0; }
     void gmres_dofs(fdd::memory &, fdd::memory &, bool = true, bool = false) {}
     bool lazy_history = false;
+    bool composite() const { return false; }
+    bool composite_dof_space() const { return false; }
+    int own_dofs() const { return 0; }
+    fdd::memory new_dof_vector() { return fdd::dev().malloc<double>(1); }
+    void gmres_composite_dofs(fdd::memory &, fdd::memory &, bool = true, bool = false) {}
 };
 
 template <typename DType>
@@ -114,6 +119,8 @@ class Domain
     int dof_shift = -1; // >= 0: subdomain dof d is node d + dof_shift (the numbering makes it so), no renumbering pass
     fdd::memory nu, nr, nr1, nq, nz, np, nt, sub_f, sub_u;
     fdd::memory fcg_u_pts;
+    fdd::memory rp;                 // composite preconditioner: the residual on the element-local points (the degree tree and the ring / superdomain exchange start from it)
+    bool composite_precond = false; // the Subdomain is a full-domain-decomposition composite driven in dof space
 
     Math<DType> math;
 
@@ -587,10 +594,13 @@ class Domain
             // boundary prefix is gathered first, exchanged, and scattered last.
             const double *w = apply_assembled_weight ? assembled_weight.as<double>() : nullptr;
             const double *m = apply_dirichlet_mask ? dirichlet_mask.as<double>() : nullptr;
-            const int nb = (fdd::comm().size > 1 and num_interface_slots > 0) ? num_bdary_nodes : 0;
-            if (nb > 0)
+            // every rank of a multi-rank run enters the exchange, also one without shared nodes (an empty prefix):
+            // the collectives must match across ranks (gs_add_boundary and node_norm_enqueue gate the same way)
+            const bool multi = fdd::comm().size > 1 and num_interface_slots > 0;
+            const int nb = multi ? num_bdary_nodes : 0;
+            if (multi)
             {
-                Qt.gather_scatter(nullptr, work_dev[0].as<double>(), u.as<double>(), w, nullptr, 0, nb, 1);
+                if (nb > 0) Qt.gather_scatter(nullptr, work_dev[0].as<double>(), u.as<double>(), w, nullptr, 0, nb, 1);
                 gs_add_boundary(work_dev[0]);
             }
             Qt.gather_scatter(QQtu.as<double>(), nullptr, u.as<double>(), w, m, nb, num_local_nodes, 0);
@@ -658,7 +668,23 @@ class Domain
     {
         if (not(assembled_outer and Qt.unit_values and mesh.dim == 3 and poly_degree <= 15)) return false;
         if (not use_preconditioner) return true;
-        return preconditioner_type == 1 and subdomain.assembled_inner and subdomain.can_assemble() and (int)subdomain.point_dof.size() == num_local_points;
+        if (preconditioner_type != 1) return false;
+        if (subdomain.composite()) return subdomain.composite_dof_space() and own_nodes_have_dofs(subdomain);
+        return subdomain.assembled_inner and subdomain.can_assemble() and (int)subdomain.point_dof.size() == num_local_points;
+    }
+
+    // composite region: every unmasked node of the rank carries one of the subdomain's leading (own) dofs -- always,
+    // unless the region has no ring at the rank's own degree (subdomain_overlap 0), where own points hang
+    template <typename PType>
+    bool own_nodes_have_dofs(PType &subdomain)
+    {
+        const int nd = subdomain.own_dofs();
+        for (int p = 0; p < num_local_points; p++)
+        {
+            const int d = subdomain.point_dof[p];
+            if (mesh.p_mask[p] > 0.0 and (d < 0 or d >= nd)) return false;
+        }
+        return true;
     }
 
     void setup_nodes()
@@ -684,13 +710,15 @@ class Domain
     template <typename PType>
     void setup_dof_maps(PType &subdomain)
     {
-        const int nd = subdomain.dofs();
+        // the dofs that sit on this rank's nodes: all of them for an own-elements region, the leading ones of a composite
+        const int nd = subdomain.own_dofs();
         if (nodes_sub_dofs == nd and node_of_dof.ptr()) return;
+        composite_precond = subdomain.composite();
         std::vector<int> n_of_d(std::max(nd, 1), -1), d_of_n(std::max(num_local_nodes, 1), -1);
         for (int p = 0; p < num_local_points; p++)
         {
             const int d = subdomain.point_dof[p];
-            if (d >= 0)
+            if (d >= 0 and d < nd)
             {
                 n_of_d[d] = Q.col_hst[p];
                 d_of_n[Q.col_hst[p]] = d;
@@ -705,7 +733,8 @@ class Domain
         dof_of_node = fdd::dev().malloc<int>(std::max(num_local_nodes, 1));
         dof_of_node.copyFrom(d_of_n.data(), (size_t)num_local_nodes * sizeof(int));
         sub_f = fdd::dev().malloc<DType>(std::max(nd, 1));
-        sub_u = fdd::dev().malloc<DType>(std::max(nd, 1));
+        sub_u = subdomain.new_dof_vector(); // a composite keeps copies / hanging values behind its dofs
+        if (composite_precond and not rp.ptr()) rp = fdd::dev().malloc<DType>(std::max(num_local_points, 1));
         nodes_sub_dofs = nd;
     }
 
@@ -801,7 +830,14 @@ class Domain
         if (use_preconditioner)
         {
             timer.start("subdomain.solver");
-            if (dof_shift >= 0)
+            if (composite_precond)
+            {
+                // full domain decomposition: the inner solve starts from the residual on the points (degree tree,
+                // ring pull, coarse all-gather: Subdomain::tree_operator) and returns the composite's dof vector,
+                // whose leading entries are this rank's nodes
+                subdomain.gmres_composite_dofs(sub_u, rp);
+            }
+            else if (dof_shift >= 0)
             {
                 // the dofs are the node slice [dof_shift, dof_shift + dofs): the inner solve reads r^ in place
                 fdd::memory f_slice = rn.slice(dof_shift, nodes_sub_dofs);
@@ -855,6 +891,7 @@ class Domain
         fcg_nodes_active = true;
 
         gather_nodes(nr, f);
+        if (use_preconditioner and composite_precond) rp.copyFrom(f, (size_t)num_local_points * sizeof(DType)); // r = f on the points as well
         FDD_CALL(fdd_set_to_value(nu.as<double>(), 0.0, num_local_nodes, 0, fdd::dev().stream));
         FDD_CALL(fdd_set_to_value(nz.as<double>(), 0.0, num_local_nodes, 0, fdd::dev().stream));
 
@@ -883,6 +920,8 @@ class Domain
             // gamma = scalars[0] (kept for beta), theta = scalars[1]: alpha never visits the host
             if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>(), 2);
             FDD_CALL(fdd_dom_solution_and_residual_update_dev(nu.as<double>(), nr1.as<double>(), nr.as<double>(), np.as<double>(), nq.as<double>(), scalars.as<double>(), scalars.as<double>() + 1, nn, stream));
+            if (use_preconditioner and composite_precond) // r+ = r - alpha q on the points too (domain.okl:191), alpha from device memory
+                FDD_CALL(fdd_xmay_ratio_dev(rp.as<double>(), rp.as<double>(), scalars.as<double>(), scalars.as<double>() + 1, q_k.as<double>(), num_local_points, stream));
             node_norm_enqueue(nr1, /*defer_exchange=*/true); // finished inside the preconditioner's exchange
             fcg_norm_pending = true;
             return std::numeric_limits<DType>::quiet_NaN(); // fcg_nodes_norm() has the value
@@ -892,6 +931,7 @@ class Domain
         const DType alpha_k = fcg_gamma_k / values[1];
 
         FDD_CALL(fdd_dom_solution_and_residual_update(nu.as<double>(), nr1.as<double>(), nr.as<double>(), np.as<double>(), nq.as<double>(), alpha_k, nn, stream));
+        if (use_preconditioner and composite_precond) FDD_CALL(fdd_vector_vector_addition(rp.as<double>(), 1.0, rp.as<double>(), -alpha_k, q_k.as<double>(), num_local_points, stream));
 
         node_norm(r_norm, nr1);
         residual_history.push_back(r_norm);

@@ -14,6 +14,14 @@
  *                        GMRES, poisson.cpp:224; PCG is solver_id = 0)
  *     --function ID      manufactured solution id (poisson.cpp:211: 4)
  *     --no-precond       outer solve without the FDD preconditioner
+ *     --no-amg           inner solves without the low-order AMG V-cycle
+ *                        (Subdomain::use_preconditioner = false; the
+ *                        reference's default is true, subdomain.hpp:231,
+ *                        and so is this driver's); --amg says it explicitly
+ *     --block-local      more than one rank: every rank keeps its own
+ *                        elements only (no neighbour rings, no superdomain:
+ *                        block-Jacobi).  The overlap arguments then have no
+ *                        effect and the driver says so.
  *     --write-mesh DIR   write the box mesh as a reference-format file set
  *
  * One process per GPU.  With WORLD_SIZE > 1 in the environment (RANK,
@@ -64,15 +72,23 @@ int main(int argc, char *argv[])
 
     if (size > 1)
     {
-        const char *id_file = getenv("FDD_RCCL_ID_FILE");
-        if (!id_file)
+        const char *id_env = getenv("FDD_RCCL_ID_FILE");
+        if (!id_env)
         {
             fprintf(stderr, "ERROR: WORLD_SIZE > 1 needs FDD_RCCL_ID_FILE\n");
             return EXIT_FAILURE;
         }
+        // keyed by a launcher-supplied job id (or the master port every launcher sets) so that a stale file of an
+        // earlier run under the same path is never read
+        const char *job = getenv("FDD_JOB_ID") ? getenv("FDD_JOB_ID") : getenv("MASTER_PORT");
+        const std::string id_path = std::string(id_env) + (job ? std::string(".") + job : std::string());
+        const char *id_file = id_path.c_str();
+        if (rank == 0) unlink(id_file);
         char id[128];
         if (rank == 0)
         {
+            // a file left by an earlier launch must not be picked up by this launch's other ranks: its name carries
+            // the launcher's job id when one is given (FDD_JOB_ID), and it is removed again once every rank has joined
             if (fddh_comm_rccl_unique_id(id)) die("fddh_comm_rccl_unique_id");
             std::string tmp = std::string(id_file) + ".tmp";
             FILE *f = fopen(tmp.c_str(), "wb");
@@ -96,6 +112,8 @@ int main(int argc, char *argv[])
             fclose(f);
         }
         if (fddh_comm_rccl_init(id, rank, size)) die("fddh_comm_rccl_init");
+        if (fddh_barrier()) die("fddh_barrier"); // every rank has read the id
+        if (rank == 0) unlink(id_file);
     }
     else
     {
@@ -118,6 +136,8 @@ int main(int argc, char *argv[])
     int solver_id = 1;
     int function_id = 4;
     int with_subdomain = 1;
+    int use_amg = 1;     // Subdomain::use_preconditioner, subdomain.hpp:231
+    int block_local = 0;
     const char *write_dir = nullptr;
     for (int a = 6; a < argc; a++)
     {
@@ -134,6 +154,12 @@ int main(int argc, char *argv[])
             function_id = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--no-precond"))
             with_subdomain = 0;
+        else if (!strcmp(argv[a], "--no-amg"))
+            use_amg = 0;
+        else if (!strcmp(argv[a], "--amg"))
+            use_amg = 1;
+        else if (!strcmp(argv[a], "--block-local"))
+            block_local = 1;
         else if (!strcmp(argv[a], "--write-mesh") && a + 1 < argc)
             write_dir = argv[++a];
     }
@@ -146,6 +172,7 @@ int main(int argc, char *argv[])
         printf("- Polynomial reduction: \"%d\"\n", poly_reduction);
         printf("- Subdomain overlap: \"%d\"\n", subdomain_overlap);
         printf("- Superdomain overlap: \"%d\"\n\n", superdomain_overlap);
+        if (block_local && size > 1) printf("NOTE: --block-local: every rank preconditions with its own elements only; the overlap arguments are not used\n\n");
     }
 
     // rank blocks: powers of two go round-robin over x, y, z
@@ -153,6 +180,7 @@ int main(int argc, char *argv[])
     for (int s = size, d = 0; s > 1 && s % 2 == 0; s /= 2, d = (d + 1) % 3) P[d] *= 2;
 
     fddh_problem *problem = nullptr;
+    const int flags = (with_subdomain ? FDDH_WITH_SUBDOMAIN : 0) | (block_local ? FDDH_BLOCK_LOCAL : 0);
     if (box[0] > 0)
     {
         if (write_dir)
@@ -165,7 +193,7 @@ int main(int argc, char *argv[])
                 deg = (deg - poly_reduction >= 1) ? deg - poly_reduction : 1;
             }
         }
-        if (fddh_problem_create_box(&problem, box, P, poly_degree, poly_reduction, with_subdomain)) die("fddh_problem_create_box");
+        if (fddh_problem_create_box_ex(&problem, box, P, poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, flags)) die("fddh_problem_create_box_ex");
     }
     else
     {
@@ -176,8 +204,9 @@ int main(int argc, char *argv[])
             return EXIT_SUCCESS;
         }
         fclose(fp);
-        if (fddh_problem_create_dir(&problem, directory, poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, with_subdomain)) die("fddh_problem_create_dir");
+        if (fddh_problem_create_dir_ex(&problem, directory, poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, flags)) die("fddh_problem_create_dir_ex");
     }
+    if (with_subdomain && fddh_problem_set_flag(problem, "sub_use_preconditioner", use_amg)) die("fddh_problem_set_flag");
 
     long long info[FDDH_INFO_COUNT];
     fddh_problem_info(problem, info, FDDH_INFO_COUNT);
@@ -213,7 +242,15 @@ int main(int argc, char *argv[])
         printf("Function ID: %d\n", function_id);
         printf("Solver data precision: double\n");
         printf("Solver type: \"%s\"\n", (solver_id == 0) ? "FCG" : "GMRES");
-        printf("Preconditioner: %s\n", with_subdomain ? "FDD subdomain solve (own elements, GMRES(4))" : "none");
+        long long sub[FDDH_SUB_INFO_COUNT] = {0};
+        if (with_subdomain) fddh_problem_sub_info(problem, sub, FDDH_SUB_INFO_COUNT);
+        if (!with_subdomain)
+            printf("Preconditioner: none\n");
+        else if (sub[FDDH_SUB_IS_COMPOSITE])
+            printf("Preconditioner: full domain decomposition (%lld + %lld region elements, %lld superdomain dofs of %lld coarse), inner GMRES(4)%s\n", sub[FDDH_SUB_NUM_ELEMS], sub[FDDH_SUB_NUM_EXT_ELEMS] - sub[FDDH_SUB_NUM_ELEMS],
+                   sub[FDDH_SUB_NUM_SUP_DOFS], sub[FDDH_SUB_NUM_COARSE_DOFS], use_amg ? " + low-order AMG V-cycle" : "");
+        else
+            printf("Preconditioner: %s, inner GMRES(4)%s\n", size > 1 ? "block-local subdomain solve (own elements only)" : "subdomain solve (single rank: own elements = whole domain)", use_amg ? " + low-order AMG V-cycle" : "");
         printf("Iterations: %d\n", its);
         printf("Solve wall time: %.6f s\n", seconds);
         printf("max |u - u*| on rank 0: %.3e\n", err);

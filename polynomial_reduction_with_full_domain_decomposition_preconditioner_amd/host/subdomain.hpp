@@ -161,6 +161,14 @@ class Subdomain
     int num_send_points = 0, num_ring_points = 0;
     fdd::memory coarse_all;                    // the all-gathered degree-1 level of every rank, `coarse_pad` values per rank
     int coarse_pad = 0;
+    // dof-space form of the composite (see setup_composite_dofs)
+    bool comp_dofs_ready = false;
+    int n_sup_copies = 0, n_slaves = 0, slave_base = 0, W_len = 0;
+    fdd::memory copy_src;                      // int[n_sup_copies]: the subdomain dof every superdomain-extended dof copies
+    CSR_Matrix<DType> S_slave, St_slave;       // hanging points: their J_cf rows over the subdomain dofs, and the transpose
+    CSR_Matrix<DType> G_unit;                  // boolean gather: rows = subdomain dofs then hanging points, columns = region points
+    CSR_Matrix<DType> A_sup_reg;               // rows of the superdomain operator that belong to its regular dofs
+    fdd::memory slave_vals;                    // gathered values of the hanging points
 
     Math<DType> math;
     int dim = 3;
@@ -412,6 +420,188 @@ class Subdomain
             copy_tail_back(z, work_dev[0]); // :4157
         }
     }
+
+
+    // ------------------------------------------------------------------
+    // The composite in DOF SPACE: what gmres_dofs works on when the region is a composite.
+    //
+    // The reference's inner Krylov vectors are [region points | superdomain dofs] and every step goes through
+    // Qt, QQt_int / Q_int / Qt_int and Q (subdomain.tpp:3969-4004, 4277-4307).  All of that only ever looks at the
+    // UNIQUE dofs (norm_weight is their indicator, QQt_int copies from them), so the iteration is carried on
+    //     U = [ subdomain dofs: regular | interface ][ superdomain regular dofs ]          (num_dofs values)
+    // and the numbering of composite.hpp makes the copies fall into place without index maps:
+    //   - the subdomain's extended dofs are the superdomain's first regular dofs, in the same order:
+    //     U[0 : sub_ext_dofs) IS the vector Q acts on;
+    //   - the superdomain's interface dofs are the subdomain's last dofs: U[sub_dofs - interface : num_dofs) is
+    //     [interface | regular] of the vector A acts on; its extended dofs (copies of subdomain dofs) are gathered
+    //     right behind it: W = [ U | superdomain-extended copies | hanging-point values ].
+    // Non-conforming rows of Q: a hanging point's value is S * U (S = its J_cf row), computed into the tail of W
+    // before the element kernels run, which then read every point through ONE index array (gather-on-load, the
+    // same fused kernel as the conforming path); on the way back the element results are gathered by a boolean
+    // matrix (dofs, then hanging points) and the hanging values are folded in with S^T.
+    // Operator application: indexed copy (small) + S (small) + stiffness per level list + boolean gather + S^T
+    // (small) + the superdomain rows of A (small).  Inner products are plain dots over num_dofs.
+    // ------------------------------------------------------------------
+    void setup_composite_dofs()
+    {
+        const fdd::composite::Composite &c = comp;
+        const int NP = c.num_sub_ext_points, nse = c.sub_num_ext_dofs, ns = c.sub_num_dofs, nI = c.num_interface_dofs, nu = c.sup_num_dofs, nue = c.sup_num_ext_dofs;
+        comp_dofs_ready = false;
+        if (dim != 3) return;
+        for (auto &ll : subdomain_operator.level_lists)
+            if (ll.poly_degree > 15) return;
+        // the layout above needs the subdomain's extended dofs to be the superdomain's leading regular dofs
+        for (int d = ns; d < nse; d++)
+            if (c.Q_int_col[d] != d) return;
+        n_sup_copies = nue - nu;
+        const CSR_Matrix<DType> &Q = subdomain_operator.Q;
+        std::vector<int> index(NP, -1), slave_point;
+        for (int p = 0; p < NP; p++)
+        {
+            if (c.point_dof[p] >= 0)
+                index[p] = c.point_dof[p];
+            else if (Q.ptr_hst[p + 1] > Q.ptr_hst[p])
+                slave_point.push_back(p);
+        }
+        n_slaves = (int)slave_point.size();
+        slave_base = num_dofs + n_sup_copies;
+        W_len = slave_base + n_slaves;
+        {
+            std::vector<int> sp(n_slaves + 1, 0), sc;
+            std::vector<DType> sv;
+            for (int h = 0; h < n_slaves; h++)
+            {
+                const int p = slave_point[h];
+                index[p] = slave_base + h;
+                for (int k = Q.ptr_hst[p]; k < Q.ptr_hst[p + 1]; k++)
+                {
+                    sc.push_back(Q.col_hst[k]);
+                    sv.push_back(Q.val_hst[k]);
+                }
+                sp[h + 1] = (int)sc.size();
+            }
+            if (n_slaves > 0)
+            {
+                S_slave.assemble_from_csr(n_slaves, nse, sp.data(), sc.data(), sv.data());
+                S_slave.transpose(St_slave);
+            }
+            slave_vals = fdd::dev().malloc<DType>(std::max(n_slaves, 1));
+        }
+        // every region point through one index array into W
+        point_dof_dev.free();
+        point_dof_dev = fdd::dev().malloc<int>(std::max(NP, 1));
+        point_dof_dev.copyFrom(index.data(), (size_t)NP * sizeof(int));
+        // boolean gather: row d < nse collects the points of dof d, row nse + h is hanging point h
+        {
+            const int rows = nse + n_slaves;
+            std::vector<int> gp(rows + 1, 0);
+            for (int p = 0; p < NP; p++)
+                if (index[p] >= 0) gp[(index[p] < nse ? index[p] : nse + (index[p] - slave_base)) + 1]++;
+            for (int r = 0; r < rows; r++) gp[r + 1] += gp[r];
+            std::vector<int> gc(gp[rows]), fill(gp.begin(), gp.end() - 1);
+            for (int p = 0; p < NP; p++)
+                if (index[p] >= 0) gc[fill[index[p] < nse ? index[p] : nse + (index[p] - slave_base)]++] = p;
+            std::vector<DType> gv(gc.size(), 1.0);
+            G_unit.assemble_from_csr(rows, NP, gp.data(), gc.data(), gv.data());
+            G_unit.release_host();
+        }
+        {
+            std::vector<int> src(std::max(n_sup_copies, 1), 0);
+            for (int k = 0; k < n_sup_copies; k++) src[k] = c.Q_int_col[(size_t)nse + nu + k];
+            copy_src = fdd::dev().malloc<int>(std::max(n_sup_copies, 1));
+            copy_src.copyFrom(src.data(), src.size() * sizeof(int));
+        }
+        if (nu - nI > 0)
+        {
+            const fdd::low_order::HostCSR &A = c.A_sup;
+            std::vector<int> ap(nu - nI + 1, 0);
+            for (int i = nI; i < nu; i++) ap[i - nI + 1] = ap[i - nI] + (A.ptr[i + 1] - A.ptr[i]);
+            A_sup_reg.assemble_from_csr(nu - nI, nue, ap.data(), A.col.data() + A.ptr[nI], A.val.data() + A.ptr[nI]);
+        }
+        comp_dofs_ready = true;
+    }
+
+    int dof_space_size() const { return is_composite ? num_dofs : subdomain_operator.num_extended_dofs; }
+    int dof_alloc_size() const { return is_composite ? W_len : subdomain_operator.num_extended_dofs; }
+
+    // qa (dofs) = [Qt A_L Q | A_sup] (s x~): the operator of the inner iteration on a dof vector.  x~ is one of the
+    // Krylov vectors; in a composite its allocation carries the copies and hanging values behind the dofs (W).
+    void operator_dofs(fdd::memory &qa_out, fdd::memory &xa, const double *scale_dev = nullptr)
+    {
+        if (not is_composite)
+        {
+            stiffness_from_dofs(q_k, xa, scale_dev);
+            gather_weighted(qa_out, q_k);
+            return;
+        }
+        void *stream = fdd::dev().stream;
+        const int nse = subdomain_operator.num_extended_dofs, ns = subdomain_operator.num_dofs, nI = num_interface_dofs, n_reg = superdomain_operator.num_dofs - nI;
+        if (n_sup_copies > 0) FDD_CALL(fdd_gather_indexed(xa.as<double>() + num_dofs, xa.as<double>(), copy_src.template as<int>(), nullptr, n_sup_copies, stream));
+        if (n_slaves > 0)
+        {
+            fdd::memory slaves = xa.slice(slave_base, n_slaves);
+            S_slave.multiply(slaves, xa);
+        }
+        stiffness_from_dofs(q_k, xa, scale_dev);
+        G_unit.gather_scatter(nullptr, qa_out.as<double>(), q_k.as<double>(), nullptr, nullptr, 0, nse, 1);
+        if (n_slaves > 0)
+        {
+            G_unit.gather_scatter(nullptr, slave_vals.as<double>() - nse, q_k.as<double>(), nullptr, nullptr, nse, nse + n_slaves, 1);
+            St_slave.matvec(qa_out, slave_vals, 1.0, 1.0);
+        }
+        if (n_reg > 0)
+        {
+            fdd::memory out = qa_out.slice(ns, n_reg), in = xa.slice(ns - nI, superdomain_operator.num_extended_dofs);
+            A_sup_reg.multiply(out, in);
+            if (scale_dev) FDD_CALL(fdd_vector_scaling_dev(out.as<double>(), scale_dev, out.as<double>(), n_reg, stream));
+        }
+    }
+
+    // the right-hand side of the composite in dof space from the tree-exchanged composite vector T r (subdomain.tpp:4566-4646)
+    void composite_rhs_dofs(fdd::memory &fa_out, fdd::memory &Tr)
+    {
+        const int nse = subdomain_operator.num_extended_dofs, ns = subdomain_operator.num_dofs, nI = num_interface_dofs, n_reg = superdomain_operator.num_dofs - nI;
+        G_unit.gather_scatter(nullptr, fa_out.as<double>(), Tr.as<double>(), nullptr, nullptr, 0, nse, 1);
+        if (n_slaves > 0)
+        {
+            G_unit.gather_scatter(nullptr, slave_vals.as<double>() - nse, Tr.as<double>(), nullptr, nullptr, nse, nse + n_slaves, 1);
+            St_slave.matvec(fa_out, slave_vals, 1.0, 1.0);
+        }
+        if (n_reg > 0)
+        {
+            fdd::memory dst = fa_out.slice(ns, n_reg);
+            dst.copyFrom(Tr.slice(subdomain_operator.num_points + nI, n_reg), (size_t)n_reg * sizeof(DType));
+        }
+    }
+
+    // u on the rank's own points from the dof-space solution (Q u~ restricted to level 0)
+    void composite_solution_points(fdd::memory &u_l, fdd::memory &ua_in)
+    {
+        if (n_slaves > 0)
+        {
+            fdd::memory slaves = ua_in.slice(slave_base, n_slaves);
+            S_slave.multiply(slaves, ua_in);
+        }
+        FDD_CALL(fdd_gather_indexed(u_l.as<double>(), ua_in.as<double>(), point_dof_dev.template as<int>(), nullptr, own_points, fdd::dev().stream));
+    }
+
+  public:
+    bool composite_dof_space() const { return is_composite and comp_dofs_ready and assembled_inner and device_bookkeeping and num_vectors + 2 <= FDD_MULTI_MAX; }
+    int own_dofs() const { return is_composite ? comp.num_own_dofs : subdomain_operator.num_extended_dofs; }
+
+    // z~ = M^-1 r for the node-space outer solve: r is the outer residual on the rank's own points (the degree tree
+    // and the ring / superdomain exchange start from it), the result the dof-space correction (its leading own_dofs()
+    // entries follow the Domain's node order)
+    void gmres_composite_dofs(fdd::memory &ua_out, fdd::memory &r_pts, bool print_history = true, bool use_relative = false)
+    {
+        if (not fa.ptr()) fa = fdd::dev().malloc<DType>(std::max(dof_alloc_size(), 1));
+        tree_operator(f, r_pts);
+        composite_rhs_dofs(fa, f);
+        gmres_dofs_device(ua_out, fa, print_history, use_relative);
+    }
+    fdd::memory new_dof_vector() { return fdd::dev().malloc<DType>(std::max(dof_alloc_size(), 1)); }
+
+  private:
 
   public:
     const char *data_type = "double";
@@ -917,6 +1107,8 @@ class Subdomain
             for (int w = 0; w < 3; w++) work_dev[w] = fdd::dev().malloc<DType>(W);
         }
 
+        setup_composite_dofs();
+
         // the per-point arrays the solve path no longer needs
         for (int g = 0; g < NUM_GEOM_FACTS; g++) std::vector<double>().swap(comp.G[g]);
         std::vector<int>().swap(comp.Q_row);
@@ -1341,11 +1533,15 @@ class Subdomain
 
     void gmres_assembled(fdd::memory &u_l, fdd::memory &f_l, bool print_history, bool use_relative)
     {
-        const int nd = subdomain_operator.num_extended_dofs;
-        if (not ua.ptr())
+        const int nd = std::max(dof_alloc_size(), 1);
+        if (not ua.ptr()) ua = fdd::dev().malloc<DType>(nd);
+        if (not fa.ptr()) fa = fdd::dev().malloc<DType>(nd);
+        if (is_composite)
         {
-            ua = fdd::dev().malloc<DType>(std::max(nd, 1));
-            fa = fdd::dev().malloc<DType>(std::max(nd, 1));
+            // the composite in dof space (setup_composite_dofs): same iteration, its vectors over the unique dofs
+            gmres_composite_dofs(ua, f_l, print_history, use_relative);
+            composite_solution_points(u_l, ua);
+            return;
         }
         // f~ = Qt T f (the degree tree runs as in the reference; its level-0 part is the right-hand side)
         if (build_tree)
@@ -1371,28 +1567,29 @@ class Subdomain
     // nobody uses and the update takes the columns the reference would have taken.
     void gmres_dofs_device(fdd::memory &ua, fdd::memory &fa, bool print_history, bool use_relative)
     {
-        const int nd = subdomain_operator.num_extended_dofs;
+        const int nd = dof_space_size();         // the unique dofs the iteration runs on
+        const int na = std::max(dof_alloc_size(), 1); // composite: room for the copies / hanging values behind them
         const int m = num_vectors;
         void *stream = fdd::dev().stream;
         if ((int)VA.size() != m + 1)
         {
             for (auto &v : VA) v.free();
             VA.resize(m + 1);
-            for (auto &v : VA) v = fdd::dev().malloc<DType>(std::max(nd, 1));
+            for (auto &v : VA) v = fdd::dev().malloc<DType>(na);
             qa.free();
-            qa = fdd::dev().malloc<DType>(std::max(nd, 1));
+            qa = fdd::dev().malloc<DType>(na);
         }
         if (use_preconditioner and (int)ZA.size() != m)
         {
             for (auto &v : ZA) v.free();
             ZA.resize(m);
-            for (auto &v : ZA) v = fdd::dev().malloc<DType>(std::max(nd, 1));
+            for (auto &v : ZA) v = fdd::dev().malloc<DType>(na);
         }
         if (not gmres_state.ptr()) gmres_state = fdd::dev().malloc<char>(fdd_gmres_state_bytes());
         residual_history.clear();
         double *sc = scalars.as<double>();
         double *ws = reduce_ws.as<double>();
-        const double *nw = norm_weight_is_one ? nullptr : norm_weight.as<double>(); // NULL: unit weights, not read
+        const double *nw = (norm_weight_is_one or is_composite) ? nullptr : norm_weight.as<double>(); // NULL: unit weights, not read (the composite iterates on its unique dofs: all weights 1)
         void *st = gmres_state.ptr();
         const double *y_dev = nullptr, *inv_dev = nullptr;
         FDD_CALL(fdd_gmres_coefficients(st, &y_dev));
@@ -1425,8 +1622,7 @@ class Subdomain
             else
             {
                 // r~ = f~ - Qt A Q u~
-                stiffness_from_dofs(q_k, ua);
-                gather_weighted(qa, q_k);
+                operator_dofs(qa, ua);
                 FDD_CALL(fdd_vector_vector_addition(VA[0].template as<double>(), 1.0, fa.as<double>(), -1.0, qa.as<double>(), nd, stream));
                 Wm[0] = &VA[0];
             }
@@ -1446,11 +1642,10 @@ class Subdomain
                     FDD_CALL(fdd_vector_scaling_dev(fine.f.as<double>(), inv_dev + j, W[j], nd, stream));
                     amg_hierarchy.vcycle();
                     ZA[j].copyFrom(fine.u, (size_t)nd * sizeof(DType));
-                    stiffness_from_dofs(q_k, ZA[j]);
+                    operator_dofs(qa, ZA[j]);
                 }
                 else
-                    stiffness_from_dofs(q_k, *Wm[j], inv_dev + j);
-                gather_weighted(qa, q_k);
+                    operator_dofs(qa, *Wm[j], inv_dev + j);
 
                 double *slot = sc + (j & 1) * FDD_MULTI_MAX;
                 dot_dofs(slot, qa, W.data(), inv_dev, j + 1);
@@ -1693,7 +1888,7 @@ class Subdomain
     // subdomain.tpp:4309-4489
     void generalized_minimum_residual(fdd::memory &u_l, fdd::memory &f_l, bool print_history = true, bool use_relative = false)
     {
-        if (assembled_inner and can_assemble())
+        if ((assembled_inner and can_assemble()) or composite_dof_space())
         {
             gmres_assembled(u_l, f_l, print_history, use_relative);
             return;

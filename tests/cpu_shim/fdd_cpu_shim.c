@@ -538,6 +538,13 @@ int fdd_multi_lincomb_scaled_dev(double *q, int q_is_zero, const double *c, cons
     return fdd_multi_axpy_scaled_dev(q, c, v, vs, m, n, s);
 }
 
+int fdd_xmay_ratio_dev(double *out, const double *x, const double *num, const double *den, const double *y, int n, void *s)
+{
+    (void)s;
+    const double alpha = *num / *den;
+    for (int i = 0; i < n; i++) out[i] = x[i] - alpha * y[i];
+    return 0;
+}
 int fdd_xpby_ratio_dev(double *out, const double *x, const double *num, const double *den, const double *y, int n, void *s)
 {
     (void)s;

@@ -275,6 +275,17 @@ class ArrayMesh(BoxMesh):
         return cls(problem.level_degree(level), problem.info["num_local_elements"], arrays, problem.info.get("dim", 3))
 
 
+class RodMesh(BoxMesh):
+    """BoxMesh with the Dirichlet condition on the two x ends only (natural condition on the lateral faces): a rod.
+    Cut into rank strips along x, the inner strips float (no Dirichlet node of their own), and the coupling along x
+    is global: the configuration that separates a full-domain-decomposition preconditioner from block-Jacobi."""
+
+    def __init__(self, E, N, P=(1, 1, 1), rank=0):
+        super().__init__(E, N, P, rank)
+        on_ends = (np.abs(self.x) < 1e-12) | (np.abs(self.x - 1.0) < 1e-12)
+        self.p_mask = np.where(on_ends, 0.0, 1.0)
+
+
 def rank_grid(num_ranks):
     """Rank blocks for a cube: 1->(1,1,1), 2->(2,1,1), 4->(2,2,1), 8->(2,2,2)."""
     return {1: (1, 1, 1), 2: (2, 1, 1), 3: (3, 1, 1), 4: (2, 2, 1), 6: (6, 1, 1), 8: (2, 2, 2)}[num_ranks]  # as host_api.rank_grid

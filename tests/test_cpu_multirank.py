@@ -31,7 +31,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None, composite=False, overlaps=(1, 1)):
+def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None, composite=False, overlaps=(1, 1), reference_shaped=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -60,6 +60,10 @@ def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None, composite=Fal
             p = H.Problem.box(E, Pg, N, red, with_sub, overlaps[0], overlaps[1], block_local=not composite)
         if with_sub:
             p.set_flag("sub_use_preconditioner", 0)  # the inner solves of this test run without the V-cycle
+        if reference_shaped:
+            # the reference's own launch sequence: point-space Krylov vectors, the Qt / QQt_int / Q SpMV chain, host scalars
+            for flag in ("assembled_inner_solve", "assembled_outer_solve", "restructured_inner_solve", "fused_dssum", "device_bookkeeping"):
+                p.set_flag(flag, 0)
         for lvl in range(p.info["num_levels"]):
             p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
 
@@ -170,6 +174,7 @@ def test_host_layer_multirank_gloo(cpu_host_lib, world, with_sub):
     (4, (8, 8, 4), 4, 2, (1, 1)),    # three levels (4, 2, 1): rings at every degree
     (8, (8, 8, 8), 3, 2, (1, 1)),    # 2x2x2: the scaling run's topology
     (2, (16, 4, 4), 3, 1, (1, 2)),   # reduction 1 (levels 3, 2, 1), superdomain overlap 2
+    (2, (16, 4, 4), 3, 2, (1, 1, "reference-shaped")),  # the same through the reference's launch sequence (point-space vectors, SpMV chain)
 ])
 def test_full_domain_decomposition_composite_gloo(cpu_host_lib, world, E, N, red, overlaps):
     """The composite of SURVEY 8(f) next-1 from the host layer under a gloo group -- neighbour rings at reduced
@@ -178,7 +183,7 @@ def test_full_domain_decomposition_composite_gloo(cpu_host_lib, world, E, N, red
     preconditioned by it (identical iteration counts and histories)."""
     import torch.multiprocessing as mp
 
-    mp.spawn(_worker, args=(world, _free_port(), E, N, red, True, None, True, overlaps), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), E, N, red, True, None, True, overlaps[:2], len(overlaps) > 2), nprocs=world, join=True)
 
 
 def _amg_worker(rank, world, port, E, N, red):
@@ -255,6 +260,71 @@ def test_composite_with_low_order_preconditioner_gloo(cpu_host_lib, world, E, N,
     import torch.multiprocessing as mp
 
     mp.spawn(_amg_worker, args=(world, _free_port(), E, N, red), nprocs=world, join=True)
+
+
+def _rod_worker(rank, world, port, mesh_dir, N, red, w, out_file):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import json
+
+    import torch.distributed as dist
+
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
+
+    lib._host = lib._Lib(HOST_CPU_SO, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H.init(0, use_torch_stream=False)
+        H.set_print(False)
+        if world > 1:
+            H.comm_torch_callbacks(on_gpu=False)
+        else:
+            H.comm_single()
+        E, Pg = (w * world, 2, 2), (world, 1, 1)
+        for deg in S.level_degrees(N, red):
+            S.write_mesh_files(mesh_dir, S.RodMesh(E, deg, Pg, rank), proc_id=rank)
+        dist.barrier()
+        res = {}
+        for name, block_local in (("fdd", False), ("block_local", True)):
+            p = H.Problem.from_directory(mesh_dir, N, red, 1, 1, True, block_local=block_local)  # the reference's defaults otherwise: GMRES(4) + V-cycle inside
+            p.set_options(max_iterations=60)
+            m = S.RodMesh(E, N, Pg, rank)
+            _, f = p.make_rhs_from(np.sin(2 * m.x) + S.seeded_uniform(m.num_local_points, 77 + rank))
+            _, its, hist = p.solve(f, "fcg")
+            res[name] = [its, float(hist[-1] / hist[0])]
+            p.close()
+        if rank == 0:
+            with open(out_file, "w") as fh:
+                json.dump(res, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_full_domain_decomposition_converges_where_block_local_stalls(cpu_host_lib, tmp_path):
+    """Outer PCG iterations to 1e-7 on a rod (Dirichlet ends only) cut into 1, 2, 4, 8 rank strips of 4 elements,
+    degree 2, everything else at the reference's defaults.  Block-local (own elements only) stops converging as
+    soon as a rank's strip floats; the composite (rings at reduced degree + graded superdomain) keeps converging,
+    its count growing slowly with the rod's length.  (On the cube configs with Dirichlet walls and <= 8 ranks both
+    stay within 3-4 iterations: there the composite buys nothing yet.)"""
+    import json
+
+    import torch.multiprocessing as mp
+
+    counts = {}
+    for world in (1, 2, 4, 8):
+        d = tmp_path / ("rod%d" % world)
+        d.mkdir()
+        out = str(tmp_path / ("rod%d.json" % world))
+        mp.spawn(_rod_worker, args=(world, _free_port(), str(d), 2, 1, 4, out), nprocs=world, join=True)
+        counts[world] = json.load(open(out))
+    fdd = [counts[w]["fdd"][0] for w in (1, 2, 4, 8)]
+    blk = [counts[w]["block_local"] for w in (1, 2, 4, 8)]
+    assert fdd[0] == blk[0][0]                      # one rank: the same preconditioner
+    assert all(counts[w]["fdd"][1] < 1e-7 for w in (1, 2, 4, 8))
+    assert fdd[3] <= 6 * fdd[0]                     # 4 -> ~19 over an 8 times longer rod
+    assert blk[2][0] == 60 and blk[2][1] > 1e-3     # 4 ranks: block-local has not converged after 60 iterations
+    assert blk[3][0] == 60 and blk[3][1] > 1e-3
 
 
 def test_single_rank_cpu_shim_equals_oracle(cpu_host_lib):
