@@ -11,7 +11,16 @@ workload: config C2 per GPU -- 3-D Poisson, 32^3 spectral elements of degree
           generalized_minimum_residual, 4 inner iterations, polynomial
           reduction 6) + stitching dssum.  N ranks = N rank blocks of the
           cube (2 -> 64x32x32, 4 -> 64x64x32, 8 -> 64^3 = config C4), one
-          process per GPU: weak scaling.
+          process per GPU: weak scaling.  With N > 1 every rank preconditions
+          with its full-domain-decomposition composite (own elements, rings
+          of neighbour elements at degrees 7 and 1, graded superdomain);
+          --block-local keeps the own elements only.
+headline: `value` is config C2 as BASELINE.json quotes it -- inner GMRES(4)
+          WITHOUT the low-order V-cycle inside.  The reference's default has
+          the V-cycle on (subdomain.hpp:231); the same JSON line carries that
+          configuration in `reference_default` (per step, and time to the
+          reference's 1e-7 stopping tolerance for both), so that the cheap
+          iterations of the headline cannot be read as the faster solver.
 step    : one full outer PCG iteration (operator apply, gamma/theta dots,
           u/r update, assembled residual norm, preconditioner application,
           stitching, flexible dot, search update), vectors resident in HBM.
@@ -47,7 +56,11 @@ def parse():
     ap.add_argument("--reduction", type=int, default=6)
     ap.add_argument("--comm", choices=["torch", "rccl"], default="torch", help="N>1: torch.distributed(nccl=RCCL) callbacks, or RCCL called directly")
     ap.add_argument("--no-precond", action="store_true")
-    ap.add_argument("--amg", action="store_true", help="inner solve preconditioned by the low-order AMG V-cycle (config C5's preconditioner; hierarchy built by the host layer)")
+    ap.add_argument("--amg", action="store_true", help="make the reference's default preconditioner (low-order AMG V-cycle inside every inner GMRES step, config C5) the headline configuration")
+    ap.add_argument("--no-reference-default", action="store_true", help="skip the `reference_default` object (V-cycle on: hierarchy build + solves to tolerance)")
+    ap.add_argument("--no-time-to-tolerance", action="store_true", help="skip the full solves to 1e-7")
+    ap.add_argument("--no-stencil", action="store_true", help="skip the 27-point-stencil SpMV (3.05e8 non-zeros at the default size)")
+    ap.add_argument("--block-local", action="store_true", help="N>1: every rank keeps its own elements only (block-Jacobi) instead of the full-domain-decomposition composite")
     ap.add_argument("--no-amg-fusion", action="store_true", help="with --amg: the smoother's element-wise kernels as separate launches (the reference's sequence) instead of SpMV epilogues")
     ap.add_argument("--amg-precision", type=int, choices=[64, 32], default=64, help="with --amg: the reference's `Float` (AMG/config.hpp:4): V-cycle in double (default) or float")
     ap.add_argument("--no-amg-graph", action="store_true", help="with --amg: launch the V-cycle kernel by kernel (so that --kernel-table shows them) instead of replaying its hipGraph")
@@ -168,19 +181,11 @@ def main():
     N = args.degree
 
     t_setup = time.perf_counter()
-    prob = H.Problem.box(E, P, N, args.reduction, with_subdomain=not args.no_precond)
+    prob = H.Problem.box(E, P, N, args.reduction, with_subdomain=not args.no_precond, block_local=args.block_local)
     _, f = prob.make_rhs(function_id=4, seed=1234 + rank)  # rand()/RAND_MAX u*, poisson.cpp:211
-    amg_levels = 0
-    if args.amg and not args.no_precond:
-        amg_levels = prob.amg_build()
-        prob.set_flag("sub_use_preconditioner", 1)
-        if args.no_amg_graph:
-            prob.set_flag("amg_graph", 0)
-        if args.no_amg_fusion:
-            prob.set_flag("amg_fused_smoother", 0)
-        if args.amg_precision != 64:
-            prob.set_flag("amg_precision", args.amg_precision)
     t_setup = time.perf_counter() - t_setup
+    sub = prob.sub_info() if not args.no_precond else None
+    composite = bool(sub and sub["is_composite"])
 
     def max_over_ranks(x):
         if world == 1:
@@ -189,66 +194,106 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    prob.pcg_begin(f)
-    # Which kernel family dominates is MEASURED during the warm-up (every family timed); the timed region
-    # then records HIP events around that family only -- two event records per launch cost a few
-    # microseconds, ~8 % of a step when all ~35 instrumented launches of a step carry them (--kernel-table).
-    dominant = None
-    if args.warmup > 0 and not args.no_kernel_timing:
-        lib.host().call("fddh_profile_enable", 1)
-        prob.pcg_steps(args.warmup)
-        wbuf = ctypes.create_string_buffer(1 << 16)
-        lib.host().call("fddh_profile_collect", wbuf, len(wbuf))
-        wk = json.loads(wbuf.value.decode())
-        if wk:
-            dominant = max(wk, key=lambda k: wk[k]["ms"])
-    else:
-        prob.pcg_steps(args.warmup)
+    amg_state = {"levels": 0, "setup_s": 0.0}
 
-    lib.host().call("fddh_profile_enable", 0 if args.no_kernel_timing else 1)
-    if dominant and not args.kernel_table:
-        lib.host().call("fddh_profile_only", dominant.encode())
-    H.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    last_res = prob.pcg_steps(args.steps)
-    torch.cuda.synchronize()
-    H.barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    def configure(amg, precision=64):
+        """headline: inner GMRES(4) alone; reference default: the low-order V-cycle inside every inner step"""
+        if args.no_precond:
+            return
+        if amg and amg_state["levels"] == 0:
+            t = time.perf_counter()
+            amg_state["levels"] = prob.amg_build()
+            amg_state["setup_s"] = time.perf_counter() - t
+            if args.no_amg_graph:
+                prob.set_flag("amg_graph", 0)
+            if args.no_amg_fusion:
+                prob.set_flag("amg_fused_smoother", 0)
+        prob.set_flag("sub_use_preconditioner", 1 if amg else 0)
+        if amg:
+            prob.set_flag("amg_precision", precision)
 
-    buf = ctypes.create_string_buffer(1 << 16)
-    lib.host().call("fddh_profile_collect", buf, len(buf))
-    lib.host().call("fddh_profile_enable", 0)
-    kernels = json.loads(buf.value.decode())
+    info0 = prob.refresh()
+    nodes = info0["num_total_nodes"]
 
-    info = prob.refresh()
-    nodes = info["num_total_nodes"]
+    def timed_steps(steps, warmup, kernel_timing):
+        """`warmup` untimed + exactly `steps` timed outer PCG iterations bracketed by barrier + synchronise"""
+        prob.pcg_begin(f)
+        dominant = None
+        if warmup > 0 and kernel_timing:
+            # which kernel family dominates is MEASURED during the warm-up (every family timed); the timed region then
+            # records HIP events around that family only (two records per launch cost a few microseconds)
+            lib.host().call("fddh_profile_enable", 1)
+            prob.pcg_steps(warmup)
+            wbuf = ctypes.create_string_buffer(1 << 16)
+            lib.host().call("fddh_profile_collect", wbuf, len(wbuf))
+            wk = json.loads(wbuf.value.decode())
+            if wk:
+                dominant = max(wk, key=lambda k: wk[k]["ms"])
+        else:
+            prob.pcg_steps(warmup)
+        lib.host().call("fddh_profile_enable", 1 if kernel_timing else 0)
+        if dominant and not args.kernel_table:
+            lib.host().call("fddh_profile_only", dominant.encode())
+        H.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = prob.pcg_steps(steps)
+        torch.cuda.synchronize()
+        H.barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.host().call("fddh_profile_collect", buf, len(buf))
+        lib.host().call("fddh_profile_enable", 0)
+        return dt, last, json.loads(buf.value.decode())
+
+    def to_tolerance():
+        """the reference's own stopping rule: relative residual 1e-7 (domain.hpp:118), clock around the device work"""
+        its, hist, sec = prob.solve_timed(f, "fcg")
+        sec = max_over_ranks(sec)
+        return {"iterations": its, "time_ms": sec * 1e3, "relative_residual": float(hist[-1] / hist[0]) if len(hist) else None, "DOF_updates_per_s": nodes * its / sec if sec > 0 else None}
+
+    # ---------------- headline configuration ----------------
+    configure(args.amg, args.amg_precision)
+    dt, last_res, kernels = timed_steps(args.steps, args.warmup, not args.no_kernel_timing)
     value = nodes * args.steps / dt
 
-    # dominant instrumented kernel family of the timed region
-    roofline = None
+    # the same K steps with a stopping test (one host synchronisation) per step, as a real solve runs them
+    prob.set_flag("lazy_steps", 0)
+    dt_tests, _, _ = timed_steps(args.steps, min(args.warmup, 1), False)
+    prob.set_flag("lazy_steps", 1)
+    headline_tol = None if args.no_time_to_tolerance else to_tolerance()
+
     table = {}
     for name, st in kernels.items():
         avg_ms = st["ms"] / st["count"]
         gbps = st["bytes"] / (st["ms"] * 1e-3) / 1e9
         table[name] = {"launches": st["count"], "avg_us": avg_ms * 1e3, "total_ms": st["ms"], "bytes_per_launch": st["bytes"] / st["count"], "GBps": gbps}
-    # the SpMV half of the metric: Q x and Qt x on this problem's matrices (outside the timed region)
+
+    # ---------------- the SpMV half of the metric (outside the timed region) ----------------
     spmv = {}
+    if not args.no_stencil and world == 1:  # a per-GPU figure: measured in the single-GPU run
+        # the general CSR case, SURVEY 8(d)(ii): 27-point stencil on the C2 node grid (225^3 rows, 3.05e8 non-zeros);
+        # every byte of the formula moves here (values, columns, row pointers, x, y)
+        m = e * N + 1
+        us, nbytes, nnz = H.spmv_stencil_time(m, 10)
+        spmv["27-point stencil, %d^3 rows" % m] = {"frac_moved_of_hbm_peak": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "GBps_moved": nbytes / (us * 1e-6) / 1e9, "bytes_moved": nbytes, "avg_us": us, "nnz": nnz,
+                                                  "kernel": "csr_block_kernel<EpiPlain>"}
     for which, label in ((0, "Q (scatter, 1 nnz/row)"), (1, "Qt (gather, 1-8 nnz/row)")):
         us, nbytes = ctypes.c_double(), ctypes.c_double()
         lib.host().call("fddh_problem_spmv_time", prob.h, which, 20, ctypes.byref(us), ctypes.byref(nbytes))
-        gbps = nbytes.value / (us.value * 1e-6) / 1e9
-        # algorithmic_bytes is SURVEY 8(d)'s CSR formula (12 nnz + 12 rows + 8 cols).  These two matrices are boolean with
-        # one entry per point, and the plan knows: the value array (and for Q the row pointers, ptr[i] = i) are not read, so
-        # fewer bytes move than the formula counts and the formula rate can exceed the HBM peak; bytes_moved is what the
-        # kernels actually read and write (index 4 B + vector entries 8 B, + 4 B row pointers for Qt).
+        # These two matrices are boolean with one entry per point, and the plan knows: the value array (and for Q the row
+        # pointers, ptr[i] = i) are not read.  bytes_moved is what the kernels read and write (index 4 B + vector entries
+        # 8 B, + 4 B row pointers for Qt) and is the figure to hold against the HBM peak; SURVEY 8(d)'s CSR formula
+        # (12 nnz + 12 rows + 8 cols) counts bytes that never move and is kept only as `formula_*`.
         pts, nds = prob.info["num_local_points"], prob.info["num_local_nodes"]
         moved = (12.0 * pts + 8.0 * nds) if which == 0 else (12.0 * pts + 12.0 * nds)
-        spmv[label] = {"avg_us": us.value, "algorithmic_bytes": nbytes.value, "GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
-                       "bytes_moved": moved, "GBps_moved": moved / (us.value * 1e-6) / 1e9, "frac_moved_of_hbm_peak": moved / (us.value * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+        spmv[label] = {"frac_moved_of_hbm_peak": moved / (us.value * 1e-6) / 1e9 / HBM_PEAK_GBPS, "GBps_moved": moved / (us.value * 1e-6) / 1e9, "bytes_moved": moved, "avg_us": us.value,
+                       "formula_bytes": nbytes.value, "formula_GBps": nbytes.value / (us.value * 1e-6) / 1e9}
 
+    roofline = None
     if table:
         dom = max(table, key=lambda k: table[k]["total_ms"])
+        traffic = None if (args.amg or args.no_precond or composite) else pmc_traffic(dom, e, N)  # the committed counters are for the default single-rank workload
         roofline = {
             "bound": "hbm",
             "kernel": dom,
@@ -256,11 +301,40 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": table[dom]["GBps"] / HBM_PEAK_GBPS,
-            "traffic": None if args.amg or args.no_precond else pmc_traffic(dom, e, N),  # the committed counters are for the default workload
+            "traffic": traffic,
+            "traffic_source": None if traffic is None else "profiles/r01_pmc_traffic_c2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)",
             "launches": table[dom]["launches"],
             "avg_launch_us": table[dom]["avg_us"],
             "algorithmic_bytes_per_launch": table[dom]["bytes_per_launch"],
         }
+
+    # ---------------- the reference's default inner preconditioner (V-cycle on), same problem ----------------
+    reference_default = None
+    if not args.no_precond and not args.no_reference_default and not args.amg:
+        reference_default = {"preconditioner": "fdd_gmres4 + low-order AMG V-cycle in every inner step (Subdomain::use_preconditioner = true, subdomain.hpp:231)"}
+        for precision in ((64, 32) if world == 1 else (64,)):
+            configure(True, precision)
+            d, lr, _ = timed_steps(args.steps, min(args.warmup, 2), False)
+            entry = {"ms_per_step": d / args.steps * 1e3, "value": nodes * args.steps / d, "last_residual_norm": lr}
+            if not args.no_time_to_tolerance:
+                entry["to_1e-7"] = to_tolerance()
+            reference_default["f%d" % precision] = entry
+        reference_default["amg_levels"] = amg_state["levels"]
+        reference_default["amg_setup_s"] = amg_state["setup_s"]
+        configure(args.amg, args.amg_precision)
+
+    info = prob.refresh()
+    if args.no_precond:
+        pre_name, pre_text = "none", "no preconditioner"
+    else:
+        pre_name = "fdd_gmres4+amg_vcycle(%d levels, f%d)" % (amg_state["levels"], args.amg_precision) if args.amg else "fdd_gmres4"
+        if composite:
+            pre_text = "full-domain-decomposition preconditioner (per rank: %d own + %d ring/extended elements, %d superdomain dofs of %d coarse; inner GMRES(4), polynomial reduction %d)" % (
+                info["num_local_elements"], sub["num_ext_elems"] - info["num_local_elements"], sub["sup_dofs"], sub["coarse_dofs"], args.reduction)
+        elif world > 1:
+            pre_text = "BLOCK-LOCAL FDD preconditioner (own elements only: no neighbour rings / superdomain; inner GMRES(4), polynomial reduction %d)" % args.reduction
+        else:
+            pre_text = "FDD preconditioner (single subdomain = whole domain, inner GMRES(4), polynomial reduction %d)" % args.reduction
 
     out = {
         "metric": "PCG DOF-updates/sec + SpMV GB/s (%HBM peak), 3D Poisson N=7",
@@ -276,22 +350,28 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"3D Poisson, {E[0]}x{E[1]}x{E[2]} elements ({e}^3 per GPU), N={N}, flexible PCG + FDD preconditioner (own-element subdomain, inner GMRES(4), polynomial reduction {args.reduction})" + ("" if world == 1 else " [block-local FDD: no neighbour rings / superdomain]"),
+            "workload": f"3D Poisson, {E[0]}x{E[1]}x{E[2]} elements ({e}^3 per GPU), N={N}, flexible PCG + " + pre_text,
             "elements": list(E),
             "rank_grid": list(P),
             "poly_degree": N,
             "points_per_gpu": info["num_local_points"],
             "unique_nodes": nodes,
-            "preconditioner": "none" if args.no_precond else ("fdd_gmres4+amg_vcycle(%d levels, f%d)" % (amg_levels, args.amg_precision) if amg_levels else "fdd_gmres4"),
+            "preconditioner": pre_name,
             "comm": "single" if world == 1 else ("gloo-staged rehearsal on one GPU" if args.rehearse_on_one_gpu else args.comm),
         },
         "points_updates_per_s": info["num_local_points"] * world * args.steps / dt,
         "last_residual_norm": last_res,
+        "ms_per_step_with_stopping_tests": dt_tests / args.steps * 1e3,
+        "to_1e-7": headline_tol,
         "setup_s": t_setup,
         "roofline": roofline,
         "spmv": spmv,
+        "reference_default": reference_default,
         "kernels": table,
     }
+    if composite:
+        out["config"]["composite"] = {k: sub[k] for k in ("num_elems", "num_ext_elems", "num_points", "sub_dofs", "sub_ext_dofs", "interface_dofs", "sup_dofs", "sup_ext_dofs", "unique_dofs", "coarse_dofs", "num_peers")}
+        out["config"]["composite"]["superdomain_levels"] = prob.sub_composite_levels()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)

@@ -99,6 +99,12 @@ int fdd_csr_plan_kind(const fdd_csr_plan *plan, int *kind); /* 0 = thread-per-ro
  * Q_int, ...; CSR_Matrix::assemble checks its host values): the kernels then skip the val array --
  * 1.0*x is x, so results are unchanged and 8 of the 12 bytes per non-zero are not moved. */
 int fdd_csr_plan_set_unit_values(fdd_csr_plan *plan, int unit_values);
+/* Give the plan a sliced-ELL copy of the matrix (slices of 64 rows, column-major, padded to the slice's longest row)
+ * when that costs at most max_padding times the stored entries and no row exceeds 64 entries: the form for the
+ * short, even rows of the AMG levels.  *attached = 1: fdd_csr_plan_multiply / _matvec[_to] / fdd_amg_smooth_* of this
+ * plan run on it from now on, same row sums in the same order.  A_ptr_host: host copy of the row pointers; A_ptr,
+ * A_col, A_val: the device arrays (A_val double, or float on a plan of fdd_csr_plan_create_f32). */
+int fdd_csr_plan_attach_sell(fdd_csr_plan *plan, const int *A_ptr_host, const int *A_ptr, const int *A_col, const void *A_val, double max_padding, int *attached, void *stream);
 /* weight may be NULL (multiply) or a device vector of num_rows (multiply_weight) */
 int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const double *weight, void *stream);
 

@@ -191,6 +191,10 @@ int fddh_problem_make_rhs_from(fddh_problem *p, double *u_star_inout, double *f)
  * prints (iteration 0 first). */
 int fddh_problem_solve(fddh_problem *p, int solver_id, const double *f, double *u, double *history, int history_cap, int *num_history, int *num_iterations);
 
+/* The same solve with the right-hand side already uploaded and the clock around the device work only (stream
+ * synchronised before and after): what bench.py reports as time to tolerance.  u may be NULL. */
+int fddh_problem_solve_timed(fddh_problem *p, int solver_id, const double *f, double *u, double *history, int history_cap, int *num_history, int *num_iterations, double *seconds);
+
 /* Subdomain (preconditioner) operations; type 0 = flexible_conjugate_gradient,
  * 1 = generalized_minimum_residual */
 int fddh_problem_precond_apply(fddh_problem *p, int type, const double *r, double *z, double *history, int history_cap, int *num_history);
@@ -203,6 +207,9 @@ int fddh_problem_sub_residual_norm(fddh_problem *p, const double *r, double *nor
  * 12 B per row, 8 B per column) of the assembly SpMVs of csr_matrix.okl on the problem's matrices:
  * which = 0: Q x (scatter), 1: Qt x (gather). */
 int fddh_problem_spmv_time(fddh_problem *p, int which, int iterations, double *avg_us, double *algorithmic_bytes);
+/* The general CSR case of the same metric: the 27-point trilinear stencil on an m^3 node grid
+ * ((3m - 2)^3 non-zeros; m = 225 is the C2 node grid), values and x seeded, y = A x through CSR_Matrix::multiply. */
+int fddh_spmv_stencil_time(int m, int iterations, double *avg_us, double *algorithmic_bytes, long long *num_nnz);
 
 /* Stepwise PCG with vectors resident in HBM (what bench.py times): begin sets
  * u = 0, r = f, z = M^-1 r, p = z; each step is one full outer iteration with

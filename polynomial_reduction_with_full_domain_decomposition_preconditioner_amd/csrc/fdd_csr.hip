@@ -572,6 +572,69 @@ __global__ __launch_bounds__(kBlock) void fold_partials_kernel(double *out, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sliced ELL (slice = one wavefront of 64 rows, stored column-major, padded to the slice's longest row): the
+// form for matrices whose rows are short and of nearly equal length -- the AMG levels of the low-order operator
+// (7 entries per row on a rectilinear mesh, 15 on a deformed one, Galerkin stencils below), their interpolators.
+// One lane per row: entry k of the 64 rows of a slice is one coalesced 256 B (columns) + 512 B (values) read,
+// no row pointers, no LDS, no barrier; a row's products are added in column order (the CSR order), so results
+// equal the row-block kernel's bit for bit (padding adds +0.0 * x[valid column]).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSellSlice = FDD_WAVE;
+
+template <typename T, typename Epi>
+__global__ __launch_bounds__(kBlock) void sell_kernel(T *__restrict__ y, const int *__restrict__ slice_off, const int *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x, Epi epi, int num_rows, int num_slices)
+{
+    const int slice = blockIdx.x * (kBlock / kSellSlice) + threadIdx.x / kSellSlice;
+    if (slice >= num_slices) return;
+    const int lane = threadIdx.x & (kSellSlice - 1);
+    const int row = slice * kSellSlice + lane;
+    const int off = slice_off[slice];
+    const int width = (slice_off[slice + 1] - off) / kSellSlice;
+    const int rs = (row < num_rows) ? row : num_rows - 1;
+    const typename Epi::Opnd opnd = epi.operand(rs, y); // requested with the first entries
+    const int *c = col + off + lane;
+    const T *v = val + off + lane;
+    T acc = T(0);
+    int k = 0;
+    for (; k + 4 <= width; k += 4)
+    {
+        // four entries in flight per lane; the sum stays in column order
+        const int c0 = __builtin_nontemporal_load(c + (k + 0) * kSellSlice), c1 = __builtin_nontemporal_load(c + (k + 1) * kSellSlice);
+        const int c2 = __builtin_nontemporal_load(c + (k + 2) * kSellSlice), c3 = __builtin_nontemporal_load(c + (k + 3) * kSellSlice);
+        const T v0 = __builtin_nontemporal_load(v + (k + 0) * kSellSlice), v1 = __builtin_nontemporal_load(v + (k + 1) * kSellSlice);
+        const T v2 = __builtin_nontemporal_load(v + (k + 2) * kSellSlice), v3 = __builtin_nontemporal_load(v + (k + 3) * kSellSlice);
+        const T x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        acc += v0 * x0;
+        acc += v1 * x1;
+        acc += v2 * x2;
+        acc += v3 * x3;
+    }
+    for (; k < width; k++) acc += __builtin_nontemporal_load(v + k * kSellSlice) * x[__builtin_nontemporal_load(c + k * kSellSlice)];
+    if (row < num_rows) y[row] = epi.finish(acc, opnd, row);
+}
+
+// CSR -> sliced ELL on the device: one wavefront per slice
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sell_fill_kernel(int *__restrict__ scol, T *__restrict__ sval, const int *__restrict__ slice_off, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const T *__restrict__ A_val, int num_rows, int num_slices)
+{
+    const int slice = blockIdx.x * (kBlock / kSellSlice) + threadIdx.x / kSellSlice;
+    if (slice >= num_slices) return;
+    const int lane = threadIdx.x & (kSellSlice - 1);
+    const int row = slice * kSellSlice + lane;
+    const int off = slice_off[slice];
+    const int width = (slice_off[slice + 1] - off) / kSellSlice;
+    const int p0 = (row < num_rows) ? A_ptr[row] : 0;
+    const int len = (row < num_rows) ? A_ptr[row + 1] - p0 : 0;
+    // padding repeats a column the row already reads (any valid column of the matrix for an empty row) with value 0
+    const int pad_col = (len > 0) ? A_col[p0] : 0;
+    for (int k = 0; k < width; k++)
+    {
+        scol[off + k * kSellSlice + lane] = (k < len) ? A_col[p0 + k] : pad_col;
+        sval[off + k * kSellSlice + lane] = (k < len) ? A_val[p0 + k] : T(0);
+    }
+}
+
 } // namespace
 
 struct fdd_csr_plan
@@ -589,7 +652,23 @@ struct fdd_csr_plan
     int num_blocks;
     int *row_blocks_dev; // num_blocks + 1
     std::vector<int> row_blocks_host;
+    // sliced-ELL copy of the matrix (fdd_csr_plan_attach_sell): the SpMV entries then run on it
+    int sell_slices = 0;
+    int *sell_off_dev = nullptr; // sell_slices + 1 entry offsets
+    int *sell_col_dev = nullptr;
+    void *sell_val_dev = nullptr;
+    long long sell_entries = 0;
 };
+
+template <typename T, typename Epi>
+static int sell_launch(const fdd_csr_plan *plan, T *y, const T *x, const Epi &epi, void *stream)
+{
+    const int per_block = kBlock / kSellSlice;
+    const dim3 grid((plan->sell_slices + per_block - 1) / per_block), block(kBlock);
+    hipLaunchKernelGGL((sell_kernel<T, Epi>), grid, block, 0, fdd_stream(stream), y, plan->sell_off_dev, plan->sell_col_dev, (const T *)plan->sell_val_dev, x, epi, plan->num_rows, plan->sell_slices);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
 
 #define FDD_CSR_BLOCK(EPI, UNIT, ...)                                                          \
     do                                                                                         \
@@ -608,6 +687,7 @@ static int plan_launch(const fdd_csr_plan *plan, double *y, const int *A_ptr, co
         fdd_set_error("fp64 SpMV on a plan of fdd_csr_plan_create_f32");
         return 1;
     }
+    if (plan->sell_slices > 0) return sell_launch<double, Epi>(plan, y, x, epi, stream);
     if (plan->one_per_row) return launch_one_per_row(y, A_col, A_val, x, epi, plan->num_rows, stream, plan->unit_values != 0);
     if (plan->kind == 0) return launch_rows(y, A_ptr, A_col, A_val, x, epi, 0, plan->num_rows, stream, plan->unit_values != 0);
     const dim3 grid(plan->num_blocks), block(kBlock);
@@ -628,6 +708,7 @@ static int plan_launch_f32(const fdd_csr_plan *plan, float *y, const int *A_ptr,
         fdd_set_error("f32 SpMV: not a plan of fdd_csr_plan_create_f32");
         return 1;
     }
+    if (plan->sell_slices > 0) return sell_launch<float, Epi>(plan, y, x, epi, stream);
     const dim3 grid(plan->num_blocks), block(kBlock);
     if (plan->block_nnz == kBlockNnzSmall)
         hipLaunchKernelGGL((csr_block_kernel<float, Epi, false, kBlockNnzSmall>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
@@ -762,7 +843,62 @@ int fdd_csr_plan_destroy(fdd_csr_plan *plan)
 {
     if (plan == nullptr) return 0;
     if (plan->row_blocks_dev) (void)hipFree(plan->row_blocks_dev);
+    if (plan->sell_off_dev) (void)hipFree(plan->sell_off_dev);
+    if (plan->sell_col_dev) (void)hipFree(plan->sell_col_dev);
+    if (plan->sell_val_dev) (void)hipFree(plan->sell_val_dev);
     delete plan;
+    return 0;
+}
+
+// Give the plan a sliced-ELL copy of the matrix when its rows are short and even enough for it (padding within
+// `max_padding` of the stored entries, no row longer than 64): 0 = attached, the SpMV entries use it from now on;
+// *attached = 0 and nothing changes otherwise.  A_ptr_host is the host row-pointer array, the others device arrays
+// (values double, or float for a plan of fdd_csr_plan_create_f32).
+int fdd_csr_plan_attach_sell(fdd_csr_plan *plan, const int *A_ptr_host, const int *A_ptr, const int *A_col, const void *A_val, double max_padding, int *attached, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr && attached != nullptr);
+    *attached = 0;
+    if (plan->num_rows == 0 || plan->num_nnz == 0 || plan->unit_values || plan->sell_slices > 0) return 0;
+    if (!fdd_env_int("FDD_TUNE_CSR_SELL", 1)) return 0;
+    FDD_REQUIRE(A_ptr_host != nullptr && A_ptr != nullptr && A_col != nullptr && A_val != nullptr);
+    const int n = plan->num_rows, slices = (n + kSellSlice - 1) / kSellSlice;
+    std::vector<int> off(slices + 1, 0);
+    long long total = 0;
+    for (int s = 0; s < slices; s++)
+    {
+        int w = 0;
+        for (int r = s * kSellSlice; r < n && r < (s + 1) * kSellSlice; r++) w = std::max(w, A_ptr_host[r + 1] - A_ptr_host[r]);
+        if (w > 64) return 0;
+        total += (long long)w * kSellSlice;
+        if (total > 2000000000LL) return 0;
+        off[s + 1] = (int)total;
+    }
+    if ((double)total > max_padding * (double)plan->num_nnz) return 0;
+    const size_t vb = (size_t)plan->value_bytes;
+    hipError_t err = hipMalloc((void **)&plan->sell_off_dev, off.size() * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc((void **)&plan->sell_col_dev, (size_t)total * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&plan->sell_val_dev, (size_t)total * vb);
+    if (err == hipSuccess) err = hipMemcpy(plan->sell_off_dev, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (err != hipSuccess)
+    {
+        fdd_set_error("fdd_csr_plan_attach_sell: %s", hipGetErrorString(err));
+        if (plan->sell_off_dev) (void)hipFree(plan->sell_off_dev);
+        if (plan->sell_col_dev) (void)hipFree(plan->sell_col_dev);
+        if (plan->sell_val_dev) (void)hipFree(plan->sell_val_dev);
+        plan->sell_off_dev = plan->sell_col_dev = nullptr;
+        plan->sell_val_dev = nullptr;
+        return (int)err;
+    }
+    const int per_block = kBlock / kSellSlice;
+    const dim3 grid((slices + per_block - 1) / per_block), block(kBlock);
+    if (vb == 8)
+        hipLaunchKernelGGL((sell_fill_kernel<double>), grid, block, 0, fdd_stream(stream), plan->sell_col_dev, (double *)plan->sell_val_dev, plan->sell_off_dev, A_ptr, A_col, (const double *)A_val, n, slices);
+    else
+        hipLaunchKernelGGL((sell_fill_kernel<float>), grid, block, 0, fdd_stream(stream), plan->sell_col_dev, (float *)plan->sell_val_dev, plan->sell_off_dev, A_ptr, A_col, (const float *)A_val, n, slices);
+    FDD_LAUNCH_CHECK();
+    plan->sell_entries = total;
+    plan->sell_slices = slices; // last: the SpMV entries switch over
+    *attached = 1;
     return 0;
 }
 

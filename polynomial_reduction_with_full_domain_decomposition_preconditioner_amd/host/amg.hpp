@@ -134,10 +134,13 @@ class Hierarchy
         return m;
     }
 
-    static void blocked_plan(fdd_csr_plan **plan, CSR_Matrix<double> &M)
+    // plan of the f32 entries; with short even rows it gets the sliced-ELL copy like the fp64 plans (csr_matrix.hpp)
+    static void blocked_plan(fdd_csr_plan **plan, CSR_Matrix<double> &M, fdd::memory &val32)
     {
         if (M.num_rows == 0 or M.num_cols == 0 or M.ptr_hst.empty()) return;
         FDD_CALL(fdd_csr_plan_create_f32(plan, M.ptr_hst.data(), M.num_rows, M.num_cols, M.num_nnz));
+        int attached = 0;
+        if (M.num_nnz > M.num_rows) FDD_CALL(fdd_csr_plan_attach_sell(*plan, M.ptr_hst.data(), M.ptr.as<int>(), M.col.as<int>(), val32.ptr(), 1.3, &attached, fdd::dev().stream));
     }
 
     void prepare32()
@@ -146,19 +149,19 @@ class Hierarchy
         for (Level &L : levels)
         {
             L.A_val32 = to_f32(L.A.val_hst);
-            blocked_plan(&L.A_plan32, L.A);
+            blocked_plan(&L.A_plan32, L.A, L.A_val32);
             if (L.P.num_rows > 0 and not L.P.ptr_hst.empty())
             {
                 L.P_val32 = to_f32(L.P.val_hst);
                 L.R_val32 = to_f32(L.R.val_hst);
-                blocked_plan(&L.P_plan32, L.P);
-                blocked_plan(&L.R_plan32, L.R);
+                blocked_plan(&L.P_plan32, L.P, L.P_val32);
+                blocked_plan(&L.R_plan32, L.R, L.R_val32);
             }
             L.D_val32 = to_f32(L.D_hst);
             for (fdd::memory *m : {&L.f32, &L.u32, &L.r32, &L.v32, &L.work32}) *m = fdd::dev().malloc<float>(L.n);
         }
         coarse_inverse_val32 = to_f32(coarse_inverse.val_hst);
-        blocked_plan(&coarse_plan32, coarse_inverse);
+        blocked_plan(&coarse_plan32, coarse_inverse, coarse_inverse_val32);
         ready32 = true;
     }
 

@@ -49,6 +49,7 @@ class CSR_Matrix
     int num_nnz = 0;
     bool unit_values = false; // every stored value is exactly 1.0 (boolean gather/scatter matrices)
     bool is_identity = false;
+    int sell = 0; // the plan carries a sliced-ELL copy (short even rows): the kernels named *_kernel<...> below are then sell_kernel
     fdd::memory ptr;
     fdd::memory col;
     fdd::memory val;
@@ -147,7 +148,7 @@ class CSR_Matrix
     {
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
-        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiAxpby>" : "csr_block_kernel<EpiAxpby>", algorithmic_bytes(beta != 0.0));
+        fdd::ProfileScope prof(sell ? "sell_kernel<EpiAxpby>" : plan_kind == 0 ? "csr_row_kernel<EpiAxpby>" : "csr_block_kernel<EpiAxpby>", algorithmic_bytes(beta != 0.0));
         FDD_CALL(fdd_csr_plan_matvec(plan, y.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), x.as<double>(), alpha, beta, fdd::dev().stream));
     }
 
@@ -156,7 +157,7 @@ class CSR_Matrix
     {
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
-        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiAxpby>" : "csr_block_kernel<EpiAxpby>", algorithmic_bytes(beta != 0.0));
+        fdd::ProfileScope prof(sell ? "sell_kernel<EpiAxpby>" : plan_kind == 0 ? "csr_row_kernel<EpiAxpby>" : "csr_block_kernel<EpiAxpby>", algorithmic_bytes(beta != 0.0));
         FDD_CALL(fdd_csr_plan_matvec_to(plan, y.as<double>(), y_in.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), x.as<double>(), alpha, beta, fdd::dev().stream));
     }
 
@@ -166,7 +167,7 @@ class CSR_Matrix
     {
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
-        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiSmoothResidual>" : "csr_block_kernel<EpiSmoothResidual>", algorithmic_bytes(true) + 16.0 * num_rows);
+        fdd::ProfileScope prof(sell ? "sell_kernel<EpiSmoothResidual>" : plan_kind == 0 ? "csr_row_kernel<EpiSmoothResidual>" : "csr_block_kernel<EpiSmoothResidual>", algorithmic_bytes(true) + 16.0 * num_rows);
         FDD_CALL(fdd_amg_smooth_residual_matvec(plan, work.as<double>(), Sr.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), u.as<double>(), f.as<double>(), D.as<double>(), coef, fdd::dev().stream));
     }
 
@@ -175,7 +176,7 @@ class CSR_Matrix
     {
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
-        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiSmoothPoly>" : "csr_block_kernel<EpiSmoothPoly>", algorithmic_bytes(true) + 8.0 * num_rows);
+        fdd::ProfileScope prof(sell ? "sell_kernel<EpiSmoothPoly>" : plan_kind == 0 ? "csr_row_kernel<EpiSmoothPoly>" : "csr_block_kernel<EpiSmoothPoly>", algorithmic_bytes(true) + 8.0 * num_rows);
         FDD_CALL(fdd_amg_smooth_polynomial_matvec(plan, work_out.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), work_in.as<double>(), Sr.as<double>(), D.as<double>(), coef, fdd::dev().stream));
     }
 
@@ -184,7 +185,7 @@ class CSR_Matrix
     {
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
-        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiSmoothUpdate>" : "csr_block_kernel<EpiSmoothUpdate>", algorithmic_bytes(true) + 16.0 * num_rows);
+        fdd::ProfileScope prof(sell ? "sell_kernel<EpiSmoothUpdate>" : plan_kind == 0 ? "csr_row_kernel<EpiSmoothUpdate>" : "csr_block_kernel<EpiSmoothUpdate>", algorithmic_bytes(true) + 16.0 * num_rows);
         FDD_CALL(fdd_amg_smooth_update_matvec(plan, u.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), work_in.as<double>(), Sr.as<double>(), D.as<double>(), coef, fdd::dev().stream));
     }
 
@@ -217,6 +218,9 @@ class CSR_Matrix
         FDD_CALL(fdd_csr_plan_create(&plan, ptr_hst.data(), num_rows, num_cols, num_nnz));
         FDD_CALL(fdd_csr_plan_kind(plan, &plan_kind));
         FDD_CALL(fdd_csr_plan_set_unit_values(plan, unit_values ? 1 : 0));
+        // short, even rows (AMG levels, interpolators): a sliced-ELL copy the SpMV entries then run on
+        sell = 0;
+        if (not unit_values and num_nnz > num_rows) FDD_CALL(fdd_csr_plan_attach_sell(plan, ptr_hst.data(), ptr.as<int>(), col.as<int>(), val.ptr(), 1.3, &sell, fdd::dev().stream));
     }
 
   public:
@@ -312,7 +316,7 @@ class CSR_Matrix
             FDD_CALL(fdd_set_to_value(Au.as<double>(), 0.0, num_rows, 0, fdd::dev().stream));
             return;
         }
-        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiPlain>" : "csr_block_kernel<EpiPlain>", algorithmic_bytes(false));
+        fdd::ProfileScope prof(sell ? "sell_kernel<EpiPlain>" : plan_kind == 0 ? "csr_row_kernel<EpiPlain>" : "csr_block_kernel<EpiPlain>", algorithmic_bytes(false));
         FDD_CALL(fdd_csr_plan_multiply(plan, Au.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), u.as<double>(), nullptr, fdd::dev().stream));
     }
 
@@ -338,7 +342,7 @@ class CSR_Matrix
             FDD_CALL(fdd_set_to_value(Au.as<double>(), 0.0, num_rows, 0, fdd::dev().stream));
             return;
         }
-        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiWeight>" : "csr_block_kernel<EpiWeight>", algorithmic_bytes(true));
+        fdd::ProfileScope prof(sell ? "sell_kernel<EpiWeight>" : plan_kind == 0 ? "csr_row_kernel<EpiWeight>" : "csr_block_kernel<EpiWeight>", algorithmic_bytes(true));
         FDD_CALL(fdd_csr_plan_multiply(plan, Au.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), u.as<double>(), weight.as<double>(), fdd::dev().stream));
     }
 };

@@ -4,6 +4,7 @@
 // in and out of device memory.
 #include "fdd_host.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
@@ -1093,6 +1094,47 @@ int fddh_problem_solve(fddh_problem *p, int solver_id, const double *f, double *
     }
 }
 
+int fddh_problem_solve_timed(fddh_problem *p, int solver_id, const double *f, double *u, double *history, int history_cap, int *num_history, int *num_iterations, double *seconds)
+{
+    try
+    {
+        if (!p || !f || !seconds) return fail("null argument");
+        Domain<SType> &d = p->fine();
+        const size_t bytes = (size_t)d.num_local_points * sizeof(double);
+        p->a.copyFrom(f, bytes);
+        fdd::dev().finish();
+        fdd::comm().barrier();
+        const auto t0 = std::chrono::steady_clock::now();
+        if (p->subdomain)
+        {
+            if (solver_id == 0)
+                d.flexible_conjugate_gradient(p->b, p->a, *p->subdomain);
+            else
+                d.generalized_minimum_residual(p->b, p->a, *p->subdomain);
+        }
+        else
+        {
+            if (solver_id == 0)
+                d.flexible_conjugate_gradient(p->b, p->a, p->none);
+            else
+                d.generalized_minimum_residual(p->b, p->a, p->none);
+        }
+        fdd::dev().finish();
+        *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (u) p->b.copyTo(u, bytes);
+        const int nh = (int)d.residual_history.size();
+        if (history)
+            for (int i = 0; i < nh && i < history_cap; i++) history[i] = d.residual_history[i];
+        if (num_history) *num_history = nh;
+        if (num_iterations) *num_iterations = d.num_iterations;
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return fail("%s", e.what());
+    }
+}
+
 int fddh_problem_precond_apply(fddh_problem *p, int type, const double *r, double *z, double *history, int history_cap, int *num_history)
 {
     try
@@ -1251,6 +1293,88 @@ int fddh_problem_spmv_time(fddh_problem *p, int which, int iterations, double *a
         y.free();
         *avg_us = 1.0e3 * ms / iterations;
         *algorithmic_bytes = A.algorithmic_bytes(false);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return fail("%s", e.what());
+    }
+}
+
+int fddh_spmv_stencil_time(int m, int iterations, double *avg_us, double *algorithmic_bytes, long long *num_nnz)
+{
+    try
+    {
+        if (m < 2 || iterations < 1 || !avg_us || !algorithmic_bytes) return fail("bad argument");
+        const long long n = (long long)m * m * m;
+        if (n > 2000000000LL) return fail("grid too large");
+        // rows in parallel ranges: counts first, then the entries (lexicographic neighbours = ascending columns)
+        std::vector<int> ptr((size_t)n + 1, 0);
+        auto span = [&](int i) { return (i == 0 || i == m - 1) ? 2 : 3; };
+        for (int k = 0; k < m; k++)
+            for (int j = 0; j < m; j++)
+                for (int i = 0; i < m; i++) ptr[(size_t)i + (size_t)m * (j + (size_t)m * k) + 1] = span(i) * span(j) * span(k);
+        long long total = 0;
+        for (long long r = 0; r < n; r++)
+        {
+            total += ptr[r + 1];
+            if (total > 2147483647LL) return fail("more than 2^31 non-zeros");
+            ptr[r + 1] = (int)total;
+        }
+        std::vector<int> col((size_t)total);
+        std::vector<double> val((size_t)total);
+        fdd::low_order::parallel_ranges(n, fdd::low_order::range_parts(n), [&](long long r0, long long r1, int) {
+            for (long long r = r0; r < r1; r++)
+            {
+                const int i = (int)(r % m), j = (int)((r / m) % m), k = (int)(r / ((long long)m * m));
+                size_t at = (size_t)ptr[r];
+                for (int dk = -1; dk <= 1; dk++)
+                    for (int dj = -1; dj <= 1; dj++)
+                        for (int di = -1; di <= 1; di++)
+                        {
+                            const int ii = i + di, jj = j + dj, kk = k + dk;
+                            if (ii < 0 || jj < 0 || kk < 0 || ii >= m || jj >= m || kk >= m) continue;
+                            const long long c = (long long)ii + (long long)m * (jj + (long long)m * kk);
+                            col[at] = (int)c;
+                            // trilinear stiffness stencil weights (8/3, 0, -1/6, -1/12 by neighbour class) times a seeded perturbation
+                            const int cls = (di != 0) + (dj != 0) + (dk != 0);
+                            const double base = (cls == 0) ? 8.0 / 3.0 : (cls == 1) ? -1.0e-3 : (cls == 2) ? -1.0 / 6.0 : -1.0 / 12.0;
+                            val[at] = base * (1.0 + 1.0e-3 * (double)((r * 31 + c * 17) % 97));
+                            at++;
+                        }
+            }
+        });
+        CSR_Matrix<SType> A;
+        A.assemble_from_csr((int)n, (int)n, ptr.data(), col.data(), val.data());
+        std::vector<int>().swap(col);
+        std::vector<double>().swap(val);
+        A.release_host();
+        fdd::memory x = fdd::dev().malloc<double>((size_t)n);
+        fdd::memory y = fdd::dev().malloc<double>((size_t)n);
+        {
+            std::vector<double> hx((size_t)n);
+            for (long long r = 0; r < n; r++) hx[r] = 0.5 + 1.0e-3 * (double)((r * 7919) % 1009);
+            x.copyFrom(hx.data(), (size_t)n * sizeof(double));
+        }
+        void *e0 = nullptr, *e1 = nullptr;
+        FDD_CALL(fdd_event_create(&e0));
+        FDD_CALL(fdd_event_create(&e1));
+        for (int i = 0; i < 3; i++) A.multiply(y, x);
+        FDD_CALL(fdd_event_record(e0, fdd::dev().stream));
+        for (int i = 0; i < iterations; i++) A.multiply(y, x);
+        FDD_CALL(fdd_event_record(e1, fdd::dev().stream));
+        float ms = 0.0f;
+        FDD_CALL(fdd_event_elapsed_ms(&ms, e0, e1));
+        FDD_CALL(fdd_event_destroy(e0));
+        FDD_CALL(fdd_event_destroy(e1));
+        *avg_us = 1.0e3 * ms / iterations;
+        *algorithmic_bytes = A.algorithmic_bytes(false);
+        if (num_nnz) *num_nnz = total;
+        x.free();
+        y.free();
+        A.ptr.free();
+        A.col.free();
+        A.val.free();
         return 0;
     }
     catch (const std::exception &e)

@@ -409,6 +409,10 @@ struct Options
     double upper_factor = 1.1;
     int power_iterations = 25;
     bool smooth_prolongator = true;
+    int double_aggregation_levels = 0; // > 0: the finest levels aggregate TWICE (aggregates of aggregates, through the tentative Galerkin graph)
+                                       // before the interpolator is smoothed: ~70 rows per aggregate on a 7-point stencil instead of ~6, operator
+                                       // complexity 2.4 -> 1.1, V-cycle about half the time -- and 5 outer iterations instead of 3 (10^3 elements,
+                                       // N = 7): measured, not the default
 };
 
 struct Level
@@ -541,7 +545,27 @@ inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = fal
         if (not last)
         {
             std::vector<int> agg;
-            const int nc = aggregate(A, o.strength * std::pow(0.5, l), agg); // Galerkin operators spread: weaker threshold per level
+            int nc = aggregate(A, o.strength * std::pow(0.5, l), agg); // Galerkin operators spread: weaker threshold per level
+            static const int double_levels_env = getenv("FDD_TUNE_AMG_DOUBLE_AGG") ? atoi(getenv("FDD_TUNE_AMG_DOUBLE_AGG")) : -1; // development override
+            if (l < (double_levels_env >= 0 ? double_levels_env : o.double_aggregation_levels) and nc > 0 and nc < n)
+            {
+                // aggregates of aggregates: the graph of the tentative coarse operator T^T A T, aggregated again
+                HostCSR T;
+                T.rows = n;
+                T.cols = nc;
+                T.ptr.resize(n + 1);
+                T.col.assign(agg.begin(), agg.end());
+                T.val.assign(n, 1.0);
+                for (int i = 0; i <= n; i++) T.ptr[i] = i;
+                HostCSR C = multiply(transpose(T), multiply(A, T));
+                std::vector<int> agg2;
+                const int nc2 = aggregate(C, o.strength * 0.5, agg2);
+                if (nc2 > 0 and nc2 < nc)
+                {
+                    for (int i = 0; i < n; i++) agg[i] = agg2[agg[i]];
+                    nc = nc2;
+                }
+            }
             if (nc >= n or nc == 0)
                 last = true;
             else

@@ -356,6 +356,15 @@ class Problem:
         _H().call("fddh_problem_solve", self.h, 0 if method == "fcg" else 1, _dp(np.ascontiguousarray(f)), _dp(u), _dp(hist), cap, ctypes.byref(nh), ctypes.byref(its))
         return u, its.value, hist[: min(nh.value, cap)].copy()
 
+    def solve_timed(self, f, method="fcg", want_solution=False):
+        """(iterations, history, seconds): the solve with the clock around the device work only"""
+        u = np.zeros(self.n) if want_solution else None
+        cap = 4096
+        hist = np.zeros(cap)
+        nh, its, sec = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        _H().call("fddh_problem_solve_timed", self.h, 0 if method == "fcg" else 1, _dp(np.ascontiguousarray(f)), _dp(u), _dp(hist), cap, ctypes.byref(nh), ctypes.byref(its), ctypes.byref(sec))
+        return its.value, hist[: min(nh.value, cap)].copy(), sec.value
+
     def precond_apply(self, r, method="gmres"):
         z = np.zeros(self.n)
         hist = np.zeros(64)
@@ -450,6 +459,13 @@ class Problem:
         u = np.zeros(self.n)
         _H().call("fddh_problem_pcg_solution", self.h, _dp(u))
         return u
+
+
+def spmv_stencil_time(m, iterations=10):
+    """(avg_us, algorithmic_bytes, nnz) of the 27-point-stencil SpMV on an m^3 node grid"""
+    us, nbytes, nnz = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+    _H().call("fddh_spmv_stencil_time", int(m), int(iterations), ctypes.byref(us), ctypes.byref(nbytes), ctypes.byref(nnz))
+    return us.value, nbytes.value, nnz.value
 
 
 def sync():

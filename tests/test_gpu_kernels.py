@@ -347,6 +347,25 @@ def run_csr_case(gpu, ptr, col, val, ncols, expect_kind=None, exact=True):
         same(host(out), ref)
         k("fdd_csr_plan_multiply", plan, out, dptr, dcol, dval, du, dw)
         same(host(out), refw)
+        if len(val) and not np.all(val == 1.0) and expect_kind == 1:
+            # short even rows: the sliced-ELL copy of the matrix (one lane per row, column-major slices of 64 rows);
+            # same products added in the same order as the row-block kernel: same bits
+            attached = ctypes.c_int(0)
+            k("fdd_csr_plan_attach_sell", plan, P(ptr), dptr, dcol, dval, ctypes.c_double(1.5), ctypes.byref(attached))
+            widths = np.diff(ptr)
+            padded = sum(int(widths[i:i + 64].max()) * 64 for i in range(0, rows, 64))
+            assert attached.value == int(widths.max() <= 64 and padded <= 1.5 * len(val))
+            if attached.value:
+                out.fill_(7.0)
+                k("fdd_csr_plan_multiply", plan, out, dptr, dcol, dval, du, None)
+                same(host(out), ref)
+                k("fdd_csr_plan_multiply", plan, out, dptr, dcol, dval, du, dw)
+                same(host(out), refw)
+                yy = rnd(rows, 63)
+                dyy = dev(yy, gpu)
+                L.orc_amg_matvec(P(yy), P(ptr), P(col), P(val), P(u), ctypes.c_double(-1.0), ctypes.c_double(0.5), rows)
+                k("fdd_csr_plan_matvec", plan, dyy, dptr, dcol, dval, du, -1.0, 0.5)
+                same(host(dyy), yy)
         if len(val) and np.all(val == 1.0):
             # boolean matrix: the plan may skip the val array, same bits
             lib.hip().call("fdd_csr_plan_set_unit_values", plan, 1)

@@ -7,9 +7,9 @@ root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --kernel-table "$@" > $out/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o run -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o run -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $out/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-reference-default --no-time-to-tolerance --no-stencil --kernel-table "$@" > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o run -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-reference-default --no-time-to-tolerance --no-stencil "$@" > $out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o run -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-reference-default --no-time-to-tolerance --no-stencil "$@" > $out/pmc_write.log 2>&1
 cd $root
 python3 tools/rocprof_summary.py stats $out/stats $out/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --kernel-table $*"
 python3 tools/rocprof_summary.py pmc $out/pmc_fetch $out/pmc_write $out/pmc_traffic.json
