@@ -277,6 +277,17 @@ int fdd_vector_scaling_dev(double *au, const double *scale_dev, const double *u,
 int fdd_multi_lincomb_scaled_dev(double *q, int q_is_zero, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream); /* fdd_multi_axpy_scaled_dev; q_is_zero: q is taken to be 0 and is not read (it need not have been cleared) */
 int fdd_multi_lincomb_limited_dev(double *q, int q_is_zero, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, const double *last_dev, int m, int n, void *stream); /* only vectors 0..(int)*last_dev enter (NULL: all m) */
 int fdd_sqrt_sum_dev(double *out, const double *parts_dev, int nparts, void *stream); /* out[0] = sqrt(sum parts): a residual norm appended to a device-side history */
+/* ---- single-precision preconditioner (the reference's PTYPE = Float = float, config.hpp:19-20, poisson.cpp:206): the
+ * kernels of the dof-space inner solve on float vectors.  Device-resident scalars and reduction accumulators stay double. ---- */
+int fdd_sub_stiffness_matrix_gather_scaled_f32(float *Au, const float *v, const double *v_scale_dev, const int *point_dof, const float *D_hat, const float *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
+int fdd_multi_inner_product_scaled_f32(double *out, double *ws, const float *a, const float *const *b, const double *b_scale_dev, int m, int n, void *stream); /* out[k] = sum a * (s_k b_k), k < m <= 8 */
+int fdd_multi_axpy_norm2_scaled_dev_f32(double *out, double *ws, float *dst, const float *y, const double *coeffs_dev, double sign, const float *const *x, const double *x_scale_dev, int m, int n, void *stream); /* dst = y + sign sum c_k (s_k x_k); out = |dst|^2 */
+int fdd_vector_scaling_dev_f32(float *au, const double *scale_dev, const float *u, int n, void *stream);
+int fdd_vector_vector_addition_f32(float *uv, float alpha, const float *u, float beta, const float *v, int n, void *stream);
+int fdd_multi_lincomb_limited_dev_f32(float *q, int q_is_zero, const double *coeffs_dev, const float *const *v, const double *v_scale_dev, const double *last_dev, int m, int n, void *stream); /* q (+)= sum_{k <= *last} c_k (s_k v_k); last_dev NULL: all m */
+int fdd_gather_rows_f32(float *t, const int *ptr, const int *col, const float *u, int row_lo, int row_hi, void *stream); /* t[row] = sum of u over the row's entries (boolean gather) */
+int fdd_gather_indexed_f32(float *out, const float *in, const int *index, int n, void *stream);         /* out[i] = in[index[i]], 0 where index[i] < 0 */
+int fdd_gather_indexed_f32_f64(double *out, const float *in, const int *index, int n, void *stream);    /* the same, cast up (subdomain.okl:276-282 at the solve's exit) */
 int fdd_xmay_ratio_dev(double *out, const double *x, const double *num_dev, const double *den_dev, const double *y, int n, void *stream); /* out = x - (*num / *den) * y (domain.okl:191: r+ = r - alpha q with alpha on the device; out may be x) */
 int fdd_xpby_ratio_dev(double *out, const double *x, const double *num_dev, const double *den_dev, const double *y, int n, void *stream); /* out = x + (*num / *den) * y (domain.okl:226: p = z + beta p; out may be y) */
 /* out[0] = sum_nodes s*s*w with s = (Qt u)[node]*w[node]: Subdomain::residual_norm

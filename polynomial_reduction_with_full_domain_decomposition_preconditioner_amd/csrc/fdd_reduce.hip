@@ -391,6 +391,110 @@ __global__ __launch_bounds__(kBlock) void gather_norm2_kernel(double *ws, const 
     block_reduce_store<1>(a, ws, FDD_REDUCE_MAX_BLOCKS);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Single-precision preconditioner (the reference's PTYPE = Float, config.hpp:19-20): the same two reductions on
+// float vectors.  Storage is float; products and sums are carried in double (the partial sums of a 10^7-term float
+// dot would lose half their digits in float), the Gram-Schmidt update is rounded to float where it is stored.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 ld2f(const float *p, long long i) { return reinterpret_cast<const float2 *>(p)[i]; }
+
+template <int M>
+struct MultiDotOpF
+{
+    static constexpr int NV = M;
+    const float *a;
+    const float *b[M];
+    const double *bs;
+    __device__ void vec2(long long i, Acc<M> &acc) const
+    {
+        const float2 aa = ld2f(a, i);
+#pragma unroll
+        for (int k = 0; k < M; k++)
+        {
+            const float2 bb = (b[k] == a) ? aa : ld2f(b[k], i);
+            const double sk = bs ? bs[k] : 1.0;
+            acc.v[k] += (double)aa.x * (sk * (double)bb.x);
+            acc.v[k] += (double)aa.y * (sk * (double)bb.y);
+        }
+    }
+    __device__ void one(long long i, Acc<M> &acc) const
+    {
+#pragma unroll
+        for (int k = 0; k < M; k++) acc.v[k] += (double)a[i] * ((bs ? bs[k] : 1.0) * (double)b[k][i]);
+    }
+};
+
+template <int M>
+int launch_multi_dot_f32(double *out, double *ws, const float *a, const float *const *b, const double *b_scale_dev, int n, void *stream)
+{
+    MultiDotOpF<M> op;
+    op.a = a;
+    op.bs = b_scale_dev;
+    bool al = (((uintptr_t)a) & 7) == 0;
+    for (int k = 0; k < M; k++)
+    {
+        op.b[k] = b[k];
+        al = al && ((((uintptr_t)b[k]) & 7) == 0);
+    }
+    return launch_reduce(op, out, ws, n, al, stream);
+}
+
+template <int M>
+struct MultiAxpyNormOpF
+{
+    static constexpr int NV = 1;
+    float *dst;
+    const float *y;
+    const float *x[M];
+    const double *c;  // coefficients on the device
+    const double *xs; // optional scales of the x_k
+    double sign;
+    __device__ void vec2(long long i, Acc<1> &acc) const
+    {
+        const float2 yy = ld2f(y, i);
+        double v0 = yy.x, v1 = yy.y;
+#pragma unroll
+        for (int k = 0; k < M; k++)
+        {
+            const float2 b = ld2f(x[k], i);
+            const double ck = sign * c[k] * (xs ? xs[k] : 1.0);
+            v0 += ck * (double)b.x;
+            v1 += ck * (double)b.y;
+        }
+        const float2 r = make_float2((float)v0, (float)v1);
+        reinterpret_cast<float2 *>(dst)[i] = r;
+        acc.v[0] += (double)r.x * (double)r.x;
+        acc.v[0] += (double)r.y * (double)r.y;
+    }
+    __device__ void one(long long i, Acc<1> &acc) const
+    {
+        double v = y[i];
+#pragma unroll
+        for (int k = 0; k < M; k++) v += sign * c[k] * (xs ? xs[k] : 1.0) * (double)x[k][i];
+        const float r = (float)v;
+        dst[i] = r;
+        acc.v[0] += (double)r * (double)r;
+    }
+};
+
+template <int M>
+int launch_multi_axpy_norm_f32(double *out, double *ws, float *dst, const float *y, const double *c, double sign, const float *const *x, const double *x_scale_dev, int n, void *stream)
+{
+    MultiAxpyNormOpF<M> op;
+    op.dst = dst;
+    op.y = y;
+    op.c = c;
+    op.xs = x_scale_dev;
+    op.sign = sign;
+    bool al = ((((uintptr_t)y) | ((uintptr_t)dst)) & 7) == 0;
+    for (int k = 0; k < M; k++)
+    {
+        op.x[k] = x[k];
+        al = al && ((((uintptr_t)x[k]) & 7) == 0);
+    }
+    return launch_reduce(op, out, ws, n, al, stream);
+}
+
 } // namespace
 
 extern "C" {
@@ -520,5 +624,38 @@ int fdd_gather_weighted_norm2(double *out, double *ws, const int *Qt_ptr, const 
     FDD_LAUNCH_CHECK();
     return 0;
 }
+
+#define FDD_M_SWITCH(CALL)                                                          \
+    switch (m)                                                                      \
+    {                                                                               \
+    case 1: return CALL(1);                                                         \
+    case 2: return CALL(2);                                                         \
+    case 3: return CALL(3);                                                         \
+    case 4: return CALL(4);                                                         \
+    case 5: return CALL(5);                                                         \
+    case 6: return CALL(6);                                                         \
+    case 7: return CALL(7);                                                         \
+    case 8: return CALL(8);                                                         \
+    default: fdd_set_error("at most 8 vectors per multi-vector reduction"); return FDD_ERR_INVALID_ARGUMENT; \
+    }
+
+int fdd_multi_inner_product_scaled_f32(double *out, double *ws, const float *a, const float *const *b, const double *b_scale_dev, int m, int n, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && ws != nullptr && m >= 1 && n >= 0);
+    FDD_REQUIRE(n == 0 || (a != nullptr && b != nullptr));
+#define FDD_CALL_DOT(M_) launch_multi_dot_f32<M_>(out, ws, a, b, b_scale_dev, n, stream)
+    FDD_M_SWITCH(FDD_CALL_DOT)
+#undef FDD_CALL_DOT
+}
+
+int fdd_multi_axpy_norm2_scaled_dev_f32(double *out, double *ws, float *dst, const float *y, const double *coeffs_dev, double sign, const float *const *x, const double *x_scale_dev, int m, int n, void *stream)
+{
+    FDD_REQUIRE(out != nullptr && ws != nullptr && m >= 1 && n >= 0);
+    FDD_REQUIRE(n == 0 || (dst != nullptr && y != nullptr && x != nullptr && coeffs_dev != nullptr));
+#define FDD_CALL_AN(M_) launch_multi_axpy_norm_f32<M_>(out, ws, dst, y, coeffs_dev, sign, x, x_scale_dev, n, stream)
+    FDD_M_SWITCH(FDD_CALL_AN)
+#undef FDD_CALL_AN
+}
+#undef FDD_M_SWITCH
 
 } // extern "C"

@@ -28,6 +28,12 @@ namespace
 
 constexpr int kBlock = 256;
 
+template <typename T>
+struct GPtrsT
+{
+    const T *g[FDD_NUM_GEOM_FACTS];
+};
+
 struct GPtrs
 {
     const double *g[FDD_NUM_GEOM_FACTS];
@@ -249,8 +255,9 @@ __device__ __forceinline__ void element_sync()
 
 // kGather: u is read through point_dof (u[e,i,j,k] = v[point_dof[...]], 0 where
 // the point has no dof): the boolean scatter Q of Subdomain fused into the load.
-template <int n, bool kGather, bool kNTStore>
-__global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ u_scale, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
+// T: double, or float for the single-precision preconditioner (the reference's PTYPE = Float, config.hpp:19-20)
+template <typename T, int n, bool kGather, bool kNTStore>
+__global__ __launch_bounds__(kBlock) void fused_stiffness_kernel_t(T *__restrict__ Au, const T *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ u_scale, const T *__restrict__ D_hat, GPtrsT<T> G, const int *__restrict__ elem_offset, int num_elements)
 {
     using C = FusedCfg<n>;
     constexpr int nn = C::nn;
@@ -261,9 +268,9 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
     constexpr bool kDReg = (n <= 8);
     constexpr int nd = kDReg ? n : 1;
 
-    __shared__ double s_D[n * n];
-    __shared__ double s_u[C::epb][n * C::slab];   // the element, rows padded; slab k is reused for Au_1 + Au_2 once consumed
-    __shared__ double s_g[2][2][C::epb][C::slab]; // GDu_1 / GDu_2 of the slab, double buffered: one sync per slab
+    __shared__ T s_D[n * n];
+    __shared__ T s_u[C::epb][n * C::slab];   // the element, rows padded; slab k is reused for Au_1 + Au_2 once consumed
+    __shared__ T s_g[2][2][C::epb][C::slab]; // GDu_1 / GDu_2 of the slab, T buffered: one sync per slab
 
     // n = 8: the element index is the wavefront index.  Telling the compiler so
     // (readfirstlane) keeps the element base, the `active` test and all array
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
     if (active) base = elem_offset ? (size_t)elem_offset[elem] : (size_t)elem * n3;
 
     const int el = active ? e_loc : 0;
-    double *su = s_u[el];
+    T *su = s_u[el];
     const int lpos = i + j * C::ld;
 
     // this lane's k-column of u: registers for the z contraction, LDS for x and y;
@@ -289,13 +296,13 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
     // k + kPF is requested as soon as slab k's are consumed).  All of it is in
     // flight before D_hat is staged.
     constexpr int kPF = 1; // slabs of geometric factors in flight (2 measured no faster at n = 8: the kernel is not latency-bound)
-    double r_u[n], r_3[n], gq[kPF][FDD_NUM_GEOM_FACTS];
+    T r_u[n], r_3[n], gq[kPF][FDD_NUM_GEOM_FACTS];
 #pragma unroll
-    for (int k = 0; k < n; k++) r_u[k] = 0.0;
+    for (int k = 0; k < n; k++) r_u[k] = T(0);
 #pragma unroll
     for (int s = 0; s < kPF; s++)
 #pragma unroll
-        for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) gq[s][f] = 0.0;
+        for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) gq[s][f] = T(0);
     if (active)
     {
         if (kGather)
@@ -309,17 +316,17 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
 #pragma unroll
             for (int k = 0; k < n; k++) r_u[k] = u[d[k] < 0 ? 0 : d[k]];
 #pragma unroll
-            for (int k = 0; k < n; k++) r_u[k] = (d[k] < 0) ? 0.0 : r_u[k];
+            for (int k = 0; k < n; k++) r_u[k] = (d[k] < 0) ? T(0) : r_u[k];
             if (u_scale) // v stands for (*u_scale) * v: a Krylov vector kept unnormalised (math.okl:29-35 applied on load)
             {
-                const double sc = *u_scale;
+                const T sc = (T)(*u_scale);
 #pragma unroll
                 for (int k = 0; k < n; k++) r_u[k] = sc * r_u[k];
             }
         }
         else
         {
-            const double *up = u + base;
+            const T *up = u + base;
 #pragma unroll
             for (int k = 0; k < n; k++) r_u[k] = __builtin_nontemporal_load(up + (ij + k * nn));
         }
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
     for (int t = tid; t < n * n; t += kBlock) s_D[t] = D_hat[t];
 
 #pragma unroll
-    for (int k = 0; k < n; k++) r_3[k] = 0.0;
+    for (int k = 0; k < n; k++) r_3[k] = T(0);
     if (active)
     {
 #pragma unroll
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
 
     __syncthreads(); // s_D (written across elements) and s_u
 
-    double D_i[nd], D_j[nd], Dt_i[nd], Dt_j[nd];
+    T D_i[nd], D_j[nd], Dt_i[nd], Dt_j[nd];
     if (kDReg)
     {
 #pragma unroll
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
             const int k = k0 + s;
             if ((n % kPF != 0) && k >= n) continue;
             // this slot's factors move to g; slab k + kPF is requested into the slot
-            double g[FDD_NUM_GEOM_FACTS];
+            T g[FDD_NUM_GEOM_FACTS];
 #pragma unroll
             for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) g[f] = gq[s][f];
             if (active && k + kPF < n)
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
             }
 
             // row k of D_hat: wave-uniform address -> scalar loads, lives in SGPRs
-            double Dk[n];
+            T Dk[n];
 #pragma unroll
             for (int p = 0; p < n; p++) Dk[p] = D_hat[p + k * n];
 
@@ -388,24 +395,24 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
             int io = i, jo = j;
             if (!kDReg) asm volatile("" : "+v"(io), "+v"(jo));
 
-            const double *suk = su + k * C::slab;
-            double Du_1 = 0.0, Du_2 = 0.0, Du_3 = 0.0;
+            const T *suk = su + k * C::slab;
+            T Du_1 = T(0), Du_2 = T(0), Du_3 = T(0);
 #pragma unroll
             for (int p = 0; p < n; p++)
             {
-                const double di = kDReg ? D_i[kDReg ? p : 0] : s_D[p + io * n];
-                const double dj = kDReg ? D_j[kDReg ? p : 0] : s_D[p + jo * n];
+                const T di = kDReg ? D_i[kDReg ? p : 0] : s_D[p + io * n];
+                const T dj = kDReg ? D_j[kDReg ? p : 0] : s_D[p + jo * n];
                 Du_1 += di * suk[p + j * C::ld];
                 Du_2 += dj * suk[i + p * C::ld];
                 Du_3 += Dk[p] * r_u[p];
             }
 
-            const double GDu_1 = g[0] * Du_1 + g[3] * Du_2 + g[4] * Du_3;
-            const double GDu_2 = g[3] * Du_1 + g[1] * Du_2 + g[5] * Du_3;
-            const double GDu_3 = g[4] * Du_1 + g[5] * Du_2 + g[2] * Du_3;
+            const T GDu_1 = g[0] * Du_1 + g[3] * Du_2 + g[4] * Du_3;
+            const T GDu_2 = g[3] * Du_1 + g[1] * Du_2 + g[5] * Du_3;
+            const T GDu_3 = g[4] * Du_1 + g[5] * Du_2 + g[2] * Du_3;
 
-            double *sg1 = s_g[k & 1][0][el];
-            double *sg2 = s_g[k & 1][1][el];
+            T *sg1 = s_g[k & 1][0][el];
+            T *sg2 = s_g[k & 1][1][el];
             if (active)
             {
                 sg1[lpos] = GDu_1;
@@ -413,12 +420,12 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
             }
             element_sync<kWaveLocal>();
 
-            double Au_1 = 0.0, Au_2 = 0.0;
+            T Au_1 = T(0), Au_2 = T(0);
 #pragma unroll
             for (int p = 0; p < n; p++)
             {
-                const double dti = kDReg ? Dt_i[kDReg ? p : 0] : s_D[io + p * n];
-                const double dtj = kDReg ? Dt_j[kDReg ? p : 0] : s_D[jo + p * n];
+                const T dti = kDReg ? Dt_i[kDReg ? p : 0] : s_D[io + p * n];
+                const T dtj = kDReg ? Dt_j[kDReg ? p : 0] : s_D[jo + p * n];
                 Au_1 += dti * sg1[p + j * C::ld];
                 Au_2 += dtj * sg2[i + p * C::ld];
             }
@@ -435,11 +442,11 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
     if (active)
     {
         // the s_u slots are read back by the lane that wrote them
-        double *Aup = Au + base;
+        T *Aup = Au + base;
 #pragma unroll
         for (int k = 0; k < n; k++)
         {
-            const double v = su[lpos + k * C::slab] + r_3[k];
+            const T v = su[lpos + k * C::slab] + r_3[k];
             if (kNTStore)
                 __builtin_nontemporal_store(v, Aup + (ij + k * nn));
             else
@@ -448,22 +455,68 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel(double *__restr
     }
 }
 
-template <int n>
-int launch_fused(double *Au, const double *u, const int *point_dof, const double *u_scale, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
+template <typename T, int n>
+int launch_fused_t(T *Au, const T *u, const int *point_dof, const double *u_scale, const T *D_hat, const GPtrsT<T> &G, const int *elem_offset, int num_elements, void *stream)
 {
     using C = FusedCfg<n>;
     const int grid = (num_elements + C::epb - 1) / C::epb;
     static const bool nt_store = fdd_env_int("FDD_TUNE_STIFFNESS_NT_STORE", 1) != 0;
     if (point_dof and nt_store)
-        hipLaunchKernelGGL((fused_stiffness_kernel<n, true, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((fused_stiffness_kernel_t<T, n, true, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
     else if (point_dof)
-        hipLaunchKernelGGL((fused_stiffness_kernel<n, true, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((fused_stiffness_kernel_t<T, n, true, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
     else if (nt_store)
-        hipLaunchKernelGGL((fused_stiffness_kernel<n, false, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((fused_stiffness_kernel_t<T, n, false, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
     else
-        hipLaunchKernelGGL((fused_stiffness_kernel<n, false, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((fused_stiffness_kernel_t<T, n, false, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
     FDD_LAUNCH_CHECK();
     return 0;
+}
+
+template <int n>
+int launch_fused(double *Au, const double *u, const int *point_dof, const double *u_scale, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
+{
+    GPtrsT<double> g;
+    for (int k = 0; k < FDD_NUM_GEOM_FACTS; k++) g.g[k] = G.g[k];
+    return launch_fused_t<double, n>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+}
+
+// the single-precision form: gather-on-load only (the preconditioner's dof-space solve)
+int fused_dispatch_f32(float *Au, const float *u, const int *point_dof, const double *u_scale, const float *D_hat, const float *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    FDD_REQUIRE(num_elements >= 0);
+    if (num_elements == 0) return 0;
+    FDD_REQUIRE(Au != nullptr && u != nullptr && D_hat != nullptr && G != nullptr);
+    GPtrsT<float> g;
+    for (int k = 0; k < FDD_NUM_GEOM_FACTS; k++)
+    {
+        FDD_REQUIRE(G[k] != nullptr);
+        g.g[k] = G[k];
+    }
+    switch (poly_degree + 1)
+    {
+#define FDD_F32_CASE(N_) \
+    case N_: return launch_fused_t<float, N_>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+        FDD_F32_CASE(2)
+        FDD_F32_CASE(3)
+        FDD_F32_CASE(4)
+        FDD_F32_CASE(5)
+        FDD_F32_CASE(6)
+        FDD_F32_CASE(7)
+        FDD_F32_CASE(8)
+        FDD_F32_CASE(9)
+        FDD_F32_CASE(10)
+        FDD_F32_CASE(11)
+        FDD_F32_CASE(12)
+        FDD_F32_CASE(13)
+        FDD_F32_CASE(14)
+        FDD_F32_CASE(15)
+        FDD_F32_CASE(16)
+#undef FDD_F32_CASE
+    default:
+        fdd_set_error("fused stiffness kernel supports poly_degree 1..15, got %d", poly_degree);
+        return FDD_ERR_UNSUPPORTED;
+    }
 }
 
 int fused_dispatch(double *Au, const double *u, const int *point_dof, const double *u_scale, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
@@ -570,6 +623,12 @@ int fdd_sub_stiffness_matrix_gather_scaled(double *Au, const double *v, const do
 {
     FDD_REQUIRE(point_dof != nullptr);
     return fused_dispatch(Au, v, point_dof, v_scale_dev, D_hat, G, elem_offset, num_elements, poly_degree, stream);
+}
+
+int fdd_sub_stiffness_matrix_gather_scaled_f32(float *Au, const float *v, const double *v_scale_dev, const int *point_dof, const float *D_hat, const float *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    FDD_REQUIRE(point_dof != nullptr);
+    return fused_dispatch_f32(Au, v, point_dof, v_scale_dev, D_hat, G, elem_offset, num_elements, poly_degree, stream);
 }
 
 int fdd_sub_stiffness_matrix_1(double *const GDu[3], const double *u, const double *const *D_hat_ptr, const int *offset, const int *vert, const int *level, const int *poly_degree, int num_levels, const double *const G[FDD_NUM_GEOM_FACTS], int num_points, int dim, void *stream)

@@ -195,7 +195,7 @@ class Hierarchy
     {
         const int nl = (int)levels.size();
         void *s = fdd::dev().stream;
-        FDD_CALL(fdd_sub_copy_f32_f64(levels[0].f32.as<float>(), levels[0].f.as<double>(), levels[0].n, s));
+        if (not f32_io) FDD_CALL(fdd_sub_copy_f32_f64(levels[0].f32.as<float>(), levels[0].f.as<double>(), levels[0].n, s));
         FDD_CALL(fdd_amg_vector_set_to_value_f32(levels[0].u32.as<float>(), 0.0f, levels[0].n, s));
         for (int iter = 0; iter < num_vcycles; iter++)
         {
@@ -215,7 +215,7 @@ class Hierarchy
                 smooth32(l - 1, false);
             }
         }
-        FDD_CALL(fdd_sub_copy_f64_f32(levels[0].u.as<double>(), levels[0].u32.as<float>(), levels[0].n, s));
+        if (not f32_io) FDD_CALL(fdd_sub_copy_f64_f32(levels[0].u.as<double>(), levels[0].u32.as<float>(), levels[0].n, s));
     }
 
   public:
@@ -224,6 +224,24 @@ class Hierarchy
     bool use_graph = true; // AMG/config.hpp:6 USE_CUDA_GRAPH
     bool fused_smoother = true; // element-wise smoother kernels as SpMV epilogues (false: the reference's launch sequence)
     int precision = 64;         // AMG/config.hpp:4 `Float`: 64 = double, 32 = float (set_precision)
+    bool f32_io = false;        // precision 32 with a caller that works in float itself (the single-precision inner solve): the right-hand
+                                // side is given in levels[0].f32, the correction is read from levels[0].u32, no casts at the two ends
+
+    void set_f32_io(bool on)
+    {
+        if (on != f32_io and graph != nullptr)
+        {
+            (void)fdd_graph_destroy(graph);
+            graph = nullptr;
+        }
+        f32_io = on;
+    }
+    fdd::memory &rhs32()
+    {
+        prepare32();
+        return levels[0].f32;
+    }
+    fdd::memory &solution32() { return levels[0].u32; }
 
     // 32 needs the fused sequence with a Chebyshev order of at least 2; a captured graph belongs to one precision
     bool set_precision(int bits)

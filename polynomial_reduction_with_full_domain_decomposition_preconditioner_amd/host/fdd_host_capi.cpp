@@ -793,6 +793,12 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
         {
             if (p->subdomain) p->subdomain->amg_hierarchy.fused_smoother = value != 0;
         }
+        else if (s == "preconditioner_precision")
+        {
+            // the reference's PTYPE = Float (config.hpp:19-20): 64 or 32 for the whole inner solve (Krylov vectors, element
+            // stiffness, gather, V-cycle)
+            if (p->subdomain and not p->subdomain->set_precision(value)) return fail("preconditioner_precision is 64 or 32 (32: 3-D regions on the dof-space inner solve, Chebyshev order >= 2)");
+        }
         else if (s == "amg_precision")
         {
             // AMG/config.hpp:4 `Float`: 64 (double) or 32 (float)

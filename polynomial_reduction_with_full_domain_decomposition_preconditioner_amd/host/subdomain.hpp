@@ -41,6 +41,7 @@
 #define FDD_SUBDOMAIN_HPP
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <map>
 #include <unordered_map>
@@ -584,6 +585,271 @@ class Subdomain
         }
         FDD_CALL(fdd_gather_indexed(u_l.as<double>(), ua_in.as<double>(), point_dof_dev.template as<int>(), nullptr, own_points, fdd::dev().stream));
     }
+
+
+    // ------------------------------------------------------------------
+    // Single-precision preconditioner: the reference instantiates Subdomain<PTYPE> with PTYPE = Float
+    // (config.hpp:19-20, poisson.cpp:206; run.py:157 sweeps Float = float), i.e. the WHOLE inner solve -- element
+    // stiffness, gather, Krylov vectors, V-cycle -- on float data, with the casts of subdomain.okl:268-282 at its two
+    // ends.  Here the same switch is taken at run time (set_precision(32)): the dof-space inner GMRES below works on
+    // float copies of the geometric factors, D_hat, the hanging-point rows and the superdomain operator, its vectors
+    // are float, its V-cycle is the f32 cycle of amg.hpp entered and left in float.  Device-resident scalars
+    // (Hessenberg column, Givens state, 1/norm scales) and the accumulators of the dots stay double.
+    // ------------------------------------------------------------------
+    struct SinglePrecision
+    {
+        bool ready = false;
+        std::vector<std::array<fdd::memory, NUM_GEOM_FACTS>> G; // per level list
+        std::vector<fdd::memory> D_hat;                          // per level
+        fdd::memory S_val, St_val, Asup_val;
+        fdd_csr_plan *S_plan = nullptr, *St_plan = nullptr, *Asup_plan = nullptr;
+        std::vector<fdd::memory> VA, ZA;
+        fdd::memory qa, ua, fa, q_pts, slaves;
+    } sp;
+
+    static fdd::memory to_float(const std::vector<double> &v)
+    {
+        std::vector<float> t(v.begin(), v.end());
+        fdd::memory m = fdd::dev().malloc<float>(std::max<size_t>(t.size(), 1));
+        if (not t.empty()) m.copyFrom(t.data(), t.size() * sizeof(float));
+        return m;
+    }
+
+    void prepare_single_precision()
+    {
+        if (sp.ready) return;
+        void *stream = fdd::dev().stream;
+        sp.G.resize(subdomain_operator.level_lists.size());
+        for (size_t k = 0; k < subdomain_operator.level_lists.size(); k++)
+        {
+            auto &ll = subdomain_operator.level_lists[k];
+            const size_t np = (size_t)ll.num_elements * (size_t)std::lround(std::pow(ll.poly_degree + 1, dim));
+            for (int g = 0; g < NUM_GEOM_FACTS; g++)
+            {
+                sp.G[k][g] = fdd::dev().malloc<float>(std::max<size_t>(np, 1));
+                FDD_CALL(fdd_sub_copy_f32_f64(sp.G[k][g].template as<float>(), ll.G[g], (int)np, stream));
+            }
+        }
+        sp.D_hat.resize(num_levels);
+        for (int l = 0; l < num_levels; l++) sp.D_hat[l] = to_float(D_hat[l].first);
+        auto plan32 = [](fdd_csr_plan **plan, CSR_Matrix<DType> &M, fdd::memory &val32) {
+            if (M.num_rows == 0 or M.num_nnz == 0) return;
+            val32 = to_float(M.val_hst);
+            FDD_CALL(fdd_csr_plan_create_f32(plan, M.ptr_hst.data(), M.num_rows, M.num_cols, M.num_nnz));
+        };
+        if (is_composite)
+        {
+            plan32(&sp.S_plan, S_slave, sp.S_val);
+            plan32(&sp.St_plan, St_slave, sp.St_val);
+            plan32(&sp.Asup_plan, A_sup_reg, sp.Asup_val);
+        }
+        const int na = std::max(dof_alloc_size(), 1);
+        sp.qa = fdd::dev().malloc<float>(na);
+        sp.ua = fdd::dev().malloc<float>(na);
+        sp.fa = fdd::dev().malloc<float>(na);
+        sp.q_pts = fdd::dev().malloc<float>(std::max(subdomain_operator.num_points, 1));
+        sp.slaves = fdd::dev().malloc<float>(std::max(n_slaves, 1));
+        sp.ready = true;
+    }
+
+    static void matvec32(fdd_csr_plan *plan, CSR_Matrix<DType> &M, fdd::memory &val32, float *y, const float *y_in, const float *x, float alpha, float beta)
+    {
+        if (plan == nullptr) return;
+        FDD_CALL(fdd_csr_plan_matvec_to_f32(plan, y, y_in, M.ptr.template as<int>(), M.col.template as<int>(), val32.template as<float>(), x, alpha, beta, fdd::dev().stream));
+    }
+
+    // operator_dofs on float vectors
+    void operator_dofs_f32(fdd::memory &qa_out, fdd::memory &xa, const double *scale_dev = nullptr)
+    {
+        void *stream = fdd::dev().stream;
+        float *x = xa.as<float>(), *q = sp.q_pts.template as<float>(), *y = qa_out.as<float>();
+        if (is_composite)
+        {
+            if (n_sup_copies > 0) FDD_CALL(fdd_gather_indexed_f32(x + num_dofs, x, copy_src.template as<int>(), n_sup_copies, stream));
+            if (n_slaves > 0) matvec32(sp.S_plan, S_slave, sp.S_val, x + slave_base, nullptr, x, 1.0f, 0.0f);
+        }
+        for (size_t k = 0; k < subdomain_operator.level_lists.size(); k++)
+        {
+            auto &ll = subdomain_operator.level_lists[k];
+            const double n3 = (double)(ll.poly_degree + 1) * (ll.poly_degree + 1) * (ll.poly_degree + 1);
+            fdd::ProfileScope prof("fused_stiffness_kernel<gather,f32>", (32.0 * n3) * ll.num_elements + 4.0 * subdomain_operator.num_extended_dofs);
+            const float *Gs[NUM_GEOM_FACTS];
+            for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = sp.G[k][g].template as<float>();
+            FDD_CALL(fdd_sub_stiffness_matrix_gather_scaled_f32(q + ll.first_offset, x, scale_dev, point_dof_dev.template as<int>() + ll.first_offset, sp.D_hat[ll.level].template as<float>(), Gs, nullptr, ll.num_elements, ll.poly_degree, stream));
+        }
+        if (not is_composite)
+        {
+            CSR_Matrix<DType> &Qt = subdomain_operator.Qt;
+            FDD_CALL(fdd_gather_rows_f32(y, Qt.ptr.template as<int>(), Qt.col.template as<int>(), q, 0, subdomain_operator.num_extended_dofs, stream));
+            return;
+        }
+        const int nse = subdomain_operator.num_extended_dofs, ns = subdomain_operator.num_dofs, nI = num_interface_dofs, n_reg = superdomain_operator.num_dofs - nI;
+        FDD_CALL(fdd_gather_rows_f32(y, G_unit.ptr.template as<int>(), G_unit.col.template as<int>(), q, 0, nse, stream));
+        if (n_slaves > 0)
+        {
+            float *sl = sp.slaves.template as<float>();
+            FDD_CALL(fdd_gather_rows_f32(sl - nse, G_unit.ptr.template as<int>(), G_unit.col.template as<int>(), q, nse, nse + n_slaves, stream));
+            matvec32(sp.St_plan, St_slave, sp.St_val, y, y, sl, 1.0f, 1.0f);
+        }
+        if (n_reg > 0)
+        {
+            matvec32(sp.Asup_plan, A_sup_reg, sp.Asup_val, y + ns, nullptr, x + (ns - nI), 1.0f, 0.0f);
+            if (scale_dev) FDD_CALL(fdd_vector_scaling_dev_f32(y + ns, scale_dev, y + ns, n_reg, stream));
+        }
+    }
+
+    // gmres_dofs_device on float vectors (same recurrences, same device bookkeeping); fa / ua stay double at the interface
+    void gmres_dofs_device_f32(fdd::memory &ua_out, fdd::memory &fa_in, bool print_history, bool use_relative)
+    {
+        prepare_single_precision();
+        const int nd = dof_space_size();
+        const int na = std::max(dof_alloc_size(), 1);
+        const int m = num_vectors;
+        void *stream = fdd::dev().stream;
+        if ((int)sp.VA.size() != m + 1)
+        {
+            for (auto &v : sp.VA) v.free();
+            sp.VA.resize(m + 1);
+            for (auto &v : sp.VA) v = fdd::dev().malloc<float>(na);
+        }
+        if (use_preconditioner and (int)sp.ZA.size() != m)
+        {
+            for (auto &v : sp.ZA) v.free();
+            sp.ZA.resize(m);
+            for (auto &v : sp.ZA) v = fdd::dev().malloc<float>(na);
+        }
+        if (not gmres_state.ptr()) gmres_state = fdd::dev().malloc<char>(fdd_gmres_state_bytes());
+        residual_history.clear();
+        double *sc = scalars.as<double>();
+        double *ws = reduce_ws.as<double>();
+        void *st = gmres_state.ptr();
+        const double *y_dev = nullptr, *inv_dev = nullptr;
+        FDD_CALL(fdd_gmres_coefficients(st, &y_dev));
+        FDD_CALL(fdd_gmres_scales(st, &inv_dev));
+
+        FDD_CALL(fdd_sub_copy_f32_f64(sp.fa.template as<float>(), fa_in.as<double>(), nd, stream)); // copy_from_domain_data, subdomain.okl:268-274
+
+        auto dot = [&](double *out_dev, fdd::memory &a, const float *const *b, const double *b_scale, int count) {
+            fdd::ProfileScope prof("reduce_vec2_kernel<MultiDotF32>", 4.0 * nd * (count + 1));
+            FDD_CALL(fdd_multi_inner_product_scaled_f32(out_dev, ws, a.template as<float>(), b, b_scale, count, nd, stream));
+        };
+
+        if (use_preconditioner)
+        {
+            amg_checked();
+            if (amg_hierarchy.precision != 32 and not amg_hierarchy.set_precision(32))
+            {
+                fprintf(stderr, "ERROR: the single-precision preconditioner needs a Chebyshev order of at least 2\n");
+                exit(EXIT_FAILURE);
+            }
+            amg_hierarchy.set_f32_io(true);
+        }
+
+        int iter = 0;
+        bool first_cycle = true;
+        history_pending = false;
+        const bool lazy = lazy_history and max_iterations <= m and fdd::globals().pstdout_file == nullptr;
+        std::vector<const float *> W(m + 1), ptrs(m + 1);
+        std::vector<fdd::memory *> Wm(m + 1);
+        std::vector<double> hist(FDD_MULTI_MAX + 1);
+
+        while (iter < max_iterations)
+        {
+            if (first_cycle)
+                Wm[0] = &sp.fa;
+            else
+            {
+                operator_dofs_f32(sp.qa, sp.ua);
+                FDD_CALL(fdd_vector_vector_addition_f32(sp.VA[0].template as<float>(), 1.0f, sp.fa.template as<float>(), -1.0f, sp.qa.template as<float>(), nd, stream));
+                Wm[0] = &sp.VA[0];
+            }
+            W[0] = Wm[0]->template as<float>();
+            {
+                const float *self[1] = {W[0]};
+                dot(sc, *Wm[0], self, nullptr, 1);
+            }
+            FDD_CALL(fdd_gmres_begin_dev(st, sc, first_cycle ? 1 : 0, stream));
+
+            for (int j = 0; j < m; j++)
+            {
+                if (use_preconditioner)
+                {
+                    fdd::memory &rhs = amg_hierarchy.rhs32();
+                    FDD_CALL(fdd_vector_scaling_dev_f32(rhs.template as<float>(), inv_dev + j, W[j], nd, stream));
+                    amg_hierarchy.vcycle();
+                    sp.ZA[j].copyFrom(amg_hierarchy.solution32(), (size_t)nd * sizeof(float));
+                    operator_dofs_f32(sp.qa, sp.ZA[j]);
+                }
+                else
+                    operator_dofs_f32(sp.qa, *Wm[j], inv_dev + j);
+
+                double *slot = sc + (j & 1) * FDD_MULTI_MAX;
+                dot(slot, sp.qa, W.data(), inv_dev, j + 1);
+                {
+                    fdd::ProfileScope prof("reduce_vec2_kernel<MultiAxpyNormF32>", 4.0 * nd * (j + 3));
+                    FDD_CALL(fdd_multi_axpy_norm2_scaled_dev_f32(slot + (j + 1), ws, sp.VA[j + 1].template as<float>(), sp.qa.template as<float>(), slot, -1.0, W.data(), inv_dev, j + 1, nd, stream));
+                }
+                Wm[j + 1] = &sp.VA[j + 1];
+                W[j + 1] = sp.VA[j + 1].template as<float>();
+                FDD_CALL(fdd_gmres_step_dev(st, slot, j, iter, max_iterations, tolerance, use_relative ? 1 : 0, stream));
+            }
+            FDD_CALL(fdd_gmres_finish_dev(st, m, stream));
+
+            for (int i = 0; i < m; i++) ptrs[i] = use_preconditioner ? sp.ZA[i].template as<float>() : W[i];
+            const double *scales = use_preconditioner ? nullptr : inv_dev;
+            if (lazy)
+            {
+                const double *last_dev = nullptr;
+                FDD_CALL(fdd_gmres_last_column(st, &last_dev));
+                FDD_CALL(fdd_multi_lincomb_limited_dev_f32(sp.ua.template as<float>(), 1, y_dev, ptrs.data(), scales, last_dev, m, nd, stream));
+                history_pending = true;
+                iter = std::min(m, max_iterations);
+                break;
+            }
+
+            int nh = 0, j_last = -1, steps = 0, converged = 0;
+            FDD_CALL(fdd_gmres_fetch(st, nullptr, hist.data(), &nh, &j_last, &steps, &converged, stream));
+            if (first_cycle)
+            {
+                residual_history.push_back(hist[0]);
+                if (print_history) pstdout("- Iter %3d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", 0, hist[0], 1.0);
+            }
+            for (int k = 1; k < nh; k++)
+            {
+                residual_history.push_back(hist[k]);
+                if (print_history) pstdout("- Iter %3d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", iter + k, hist[k], hist[k] / residual_history[0]);
+            }
+            iter += steps;
+            if (j_last >= 0)
+                FDD_CALL(fdd_multi_lincomb_limited_dev_f32(sp.ua.template as<float>(), first_cycle ? 1 : 0, y_dev, ptrs.data(), scales, nullptr, j_last + 1, nd, stream));
+            else if (first_cycle)
+                FDD_CALL(fdd_amg_vector_set_to_value_f32(sp.ua.template as<float>(), 0.0f, nd, stream));
+            first_cycle = false;
+            if (converged) break;
+        }
+        FDD_CALL(fdd_sub_copy_f64_f32(ua_out.as<double>(), sp.ua.template as<float>(), nd, stream)); // copy_to_domain_data, subdomain.okl:276-282
+        num_iterations += iter;
+    }
+
+  public:
+    int precision = 64; // the reference's PTYPE / Float: 64 = double, 32 = float (set_precision)
+
+    // 32: the dof-space inner solve and its V-cycle run in float; 64: double (the V-cycle's own precision can still be
+    // lowered alone through amg_hierarchy.set_precision, AMG/config.hpp:4)
+    bool set_precision(int bits)
+    {
+        if (bits != 64 and bits != 32) return false;
+        if (bits == 32 and not(dim == 3 and device_bookkeeping and ((assembled_inner and can_assemble()) or composite_dof_space()))) return false;
+        precision = bits;
+        if (amg_hierarchy.ready())
+        {
+            amg_hierarchy.set_f32_io(false);
+            if (not amg_hierarchy.set_precision(bits)) return false;
+        }
+        return true;
+    }
+
+  private:
 
   public:
     bool composite_dof_space() const { return is_composite and comp_dofs_ready and assembled_inner and device_bookkeeping and num_vectors + 2 <= FDD_MULTI_MAX; }
@@ -1567,6 +1833,12 @@ class Subdomain
     // nobody uses and the update takes the columns the reference would have taken.
     void gmres_dofs_device(fdd::memory &ua, fdd::memory &fa, bool print_history, bool use_relative)
     {
+        if (precision == 32)
+        {
+            gmres_dofs_device_f32(ua, fa, print_history, use_relative);
+            return;
+        }
+        if (use_preconditioner and amg_hierarchy.f32_io) amg_hierarchy.set_f32_io(false);
         const int nd = dof_space_size();         // the unique dofs the iteration runs on
         const int na = std::max(dof_alloc_size(), 1); // composite: room for the copies / hanging values behind them
         const int m = num_vectors;

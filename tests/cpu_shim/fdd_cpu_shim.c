@@ -719,3 +719,93 @@ int fdd_amg_vector_set_to_value_f32(float *data, float value, int n, void *s)
     for (int i = 0; i < n; i++) data[i] = value;
     return 0;
 }
+
+/* ---- single-precision preconditioner entries: float storage, emulated through the double kernels (test shim only) ---- */
+int fdd_sub_stiffness_matrix_gather_scaled_f32(float *Au, const float *v, const double *vscale, const int *pd, const float *D, const float *const G[6], const int *eo, int ne, int N, void *s)
+{
+    int n = N + 1, n3 = n * n * n, maxd = -1;
+    size_t maxp = 0;
+    for (int e = 0; e < ne; e++)
+    {
+        size_t o = eo ? (size_t)eo[e] : (size_t)e * n3;
+        if (o + n3 > maxp) maxp = o + n3;
+        for (int q = 0; q < n3; q++)
+            if (pd[o + q] > maxd) maxd = pd[o + q];
+    }
+    double *vd = (double *)malloc(sizeof(double) * (size_t)(maxd + 2));
+    double *Dd = (double *)malloc(sizeof(double) * (size_t)(n * n));
+    double *Ad = (double *)calloc(maxp + 1, sizeof(double));
+    double *Gd[6];
+    const float sc = vscale ? (float)*vscale : 1.0f;
+    for (int i = 0; i <= maxd; i++) vd[i] = (double)(sc * v[i]);
+    for (int i = 0; i < n * n; i++) Dd[i] = (double)D[i];
+    for (int g = 0; g < 6; g++)
+    {
+        Gd[g] = (double *)malloc(sizeof(double) * (maxp + 1));
+        for (size_t i = 0; i < maxp; i++) Gd[g][i] = (double)G[g][i];
+    }
+    int rc = fdd_sub_stiffness_matrix_gather(Ad, vd, pd, Dd, (const double *const *)Gd, eo, ne, N, s);
+    for (int e = 0; e < ne; e++)
+    {
+        size_t o = eo ? (size_t)eo[e] : (size_t)e * n3;
+        for (int q = 0; q < n3; q++) Au[o + q] = (float)Ad[o + q];
+    }
+    for (int g = 0; g < 6; g++) free(Gd[g]);
+    free(vd);
+    free(Dd);
+    free(Ad);
+    return rc;
+}
+int fdd_multi_inner_product_scaled_f32(double *out, double *ws, const float *a, const float *const *b, const double *bs, int m, int n, void *s)
+{
+    (void)ws; (void)s;
+    for (int k = 0; k < m; k++)
+    {
+        double acc = 0.0;
+        for (int i = 0; i < n; i++) acc += (double)a[i] * ((bs ? bs[k] : 1.0) * (double)b[k][i]);
+        out[k] = acc;
+    }
+    return 0;
+}
+int fdd_multi_axpy_norm2_scaled_dev_f32(double *out, double *ws, float *dst, const float *y, const double *c, double sign, const float *const *x, const double *xs, int m, int n, void *s)
+{
+    (void)ws; (void)s;
+    double acc = 0.0;
+    for (int i = 0; i < n; i++)
+    {
+        double v = y[i];
+        for (int k = 0; k < m; k++) v += sign * c[k] * (xs ? xs[k] : 1.0) * (double)x[k][i];
+        dst[i] = (float)v;
+        acc += (double)dst[i] * (double)dst[i];
+    }
+    out[0] = acc;
+    return 0;
+}
+int fdd_vector_scaling_dev_f32(float *au, const double *sc, const float *u, int n, void *s) { (void)s; const float f = (float)*sc; for (int i = 0; i < n; i++) au[i] = f * u[i]; return 0; }
+int fdd_vector_vector_addition_f32(float *uv, float a, const float *u, float b, const float *v, int n, void *s) { (void)s; for (int i = 0; i < n; i++) uv[i] = a * u[i] + b * v[i]; return 0; }
+int fdd_multi_lincomb_limited_dev_f32(float *q, int q_is_zero, const double *c, const float *const *v, const double *vs, const double *last, int m, int n, void *s)
+{
+    (void)s;
+    int use = last ? (int)*last + 1 : m;
+    if (use > m) use = m;
+    for (int i = 0; i < n; i++)
+    {
+        double acc = q_is_zero ? 0.0 : (double)q[i];
+        for (int k = 0; k < use; k++) acc += c[k] * (vs ? vs[k] : 1.0) * (double)v[k][i];
+        q[i] = (float)acc;
+    }
+    return 0;
+}
+int fdd_gather_rows_f32(float *t, const int *ptr, const int *col, const float *u, int lo, int hi, void *s)
+{
+    (void)s;
+    for (int r = lo; r < hi; r++)
+    {
+        float acc = 0.0f;
+        for (int j = ptr[r]; j < ptr[r + 1]; j++) acc += u[col[j]];
+        t[r] = acc;
+    }
+    return 0;
+}
+int fdd_gather_indexed_f32(float *out, const float *in, const int *idx, int n, void *s) { (void)s; for (int i = 0; i < n; i++) out[i] = idx[i] < 0 ? 0.0f : in[idx[i]]; return 0; }
+int fdd_gather_indexed_f32_f64(double *out, const float *in, const int *idx, int n, void *s) { (void)s; for (int i = 0; i < n; i++) out[i] = idx[i] < 0 ? 0.0 : (double)in[idx[i]]; return 0; }

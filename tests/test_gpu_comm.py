@@ -124,6 +124,15 @@ def _two_rank_worker(rank, world, port, E, N, red, composite=False):
             assert its == oits, (method, its, oits)
             assert np.abs(hist - ohist).max() <= 1e-8 * ohist[0]
             assert np.abs(u - ou[rank]).max() <= 1e-8 * np.abs(ou[rank]).max()
+        if composite:
+            # the composite in single precision (PTYPE = Float = float): float copies of the hanging-point rows and of the
+            # superdomain operator next to the float element kernels; same iteration count, single-precision agreement
+            u64, its64, _ = p.solve(f, "fcg")
+            p.set_flag("preconditioner_precision", 32)
+            u32, its32, h32 = p.solve(f, "fcg")
+            assert abs(its32 - its64) <= 1 and h32[-1] <= 1e-7 * h32[0] * 1.0001
+            assert np.abs(u32 - u64).max() <= 1e-5 * np.abs(u64).max()
+            p.set_flag("preconditioner_precision", 64)
         # the stepwise interface bench.py drives
         p.pcg_begin(f)
         last = p.pcg_steps(3)

@@ -420,3 +420,37 @@ def test_poisson_driver_binary(setup, tmp_path):
         assert 0 < its < 30 and err < 1e-4, out.stdout  # outer tolerance 1e-7 on the residual (domain.hpp:113)
         runs.append((its, err))
     assert runs[0][0] == runs[1][0]
+
+
+def test_single_precision_preconditioner(gpu):
+    """The reference's PTYPE = Float = float (config.hpp:19-20, poisson.cpp:206; run.py:157): the whole inner solve --
+    element stiffness, gather, Krylov vectors, V-cycle -- on float data.  Checked against the double path (itself
+    held to the oracle): the preconditioner's output to single-precision rounding (1e-5 of its max norm, written
+    here), the same outer iteration counts, the same solution to the outer tolerance; switching back is bit-exact."""
+    H.comm_single()
+    for amg, (E, N, red) in ((0, ((4, 4, 4), 3, 2)), (1, ((4, 4, 4), 3, 2)), (1, ((6, 6, 6), 7, 6))):
+        p = H.Problem.box(E, (1, 1, 1), N, red, True)
+        p.set_flag("sub_use_preconditioner", amg)
+        if amg:
+            p.amg_build(coarsest_size=40)
+        _, f = p.make_rhs_from(S.seeded_uniform(p.n, 1234))
+        r = S.seeded_uniform(p.n, 5) - 0.5
+        z64, h64 = p.precond_apply(r, "gmres")
+        u64, its64, hist64 = p.solve(f, "fcg")
+        p.set_flag("preconditioner_precision", 32)
+        z32, h32 = p.precond_apply(r, "gmres")
+        u32, its32, hist32 = p.solve(f, "fcg")
+        assert np.abs(z32 - z64).max() <= 1e-5 * np.abs(z64).max()
+        assert not np.array_equal(z32, z64)  # it really ran in float
+        assert np.abs(h32 - h64).max() <= 1e-5 * h64[0]
+        assert abs(its32 - its64) <= 1, (its32, its64)
+        assert hist32[-1] <= 1e-7 * hist32[0] * 1.0001
+        assert np.abs(u32 - u64).max() <= 1e-5 * np.abs(u64).max()
+        # the stepwise interface bench.py drives (lazy: no host synchronisation inside the inner solves)
+        p.pcg_begin(f)
+        last32 = p.pcg_steps(2)
+        assert abs(last32 - hist32[2]) <= 1e-5 * hist32[0]
+        p.set_flag("preconditioner_precision", 64)
+        z64b, _ = p.precond_apply(r, "gmres")
+        assert np.array_equal(z64b, z64)
+        p.close()
