@@ -111,26 +111,31 @@ def cpu_baseline(args):
     }
 
 
+PMC_FILE = "profiles/r02_pmc_traffic_c2.json"
+
+
 def pmc_traffic(kernel_key, elements, degree):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
     (tools/profile_bench.sh: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this
     same command; FETCH_SIZE doubled on gfx950 per MI355X_MICROARCH.md).  None when the
     committed counters are for another workload or kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_c2.json")
+    path = os.path.join(ROOT, PMC_FILE)
     if not os.path.exists(path):
         return None
     with open(path) as fh:
         pmc = json.load(fh)
     if pmc.get("workload") != {"elements_per_gpu": elements, "degree": degree}:
         return None
-    family, variant = kernel_key.split("<")[0], "true" if "<gather>" in kernel_key else "false"
+    family, gather = kernel_key.split("<")[0], "<gather" in kernel_key
     best = None
     for name, st in pmc["kernels"].items():
-        if not name.startswith(family + "<"):
+        if not name.startswith(family):
             continue
-        targs = [a.strip() for a in name[len(family) + 1:].rstrip(">").split(",")]
-        if family == "fused_stiffness_kernel" and (len(targs) < 2 or targs[1] != variant):  # <n, kGather, kNTStore>
-            continue
+        targs = [a.strip() for a in name[name.index("<") + 1:].rstrip("> ").split(",")]
+        if family == "fused_stiffness_kernel":
+            # fused_stiffness_kernel_t<T, n, kGather, kNTStore>: the double instance with the same gather flag
+            if len(targs) < 3 or targs[0] != "double" or (targs[2] == "true") != gather:
+                continue
         if best is None or st["launches"] > best["launches"]:
             best = st
     return None if best is None else best["hbm_bytes_per_launch"]
@@ -313,7 +318,7 @@ def main():
             "unit": "GB/s",
             "frac": table[dom]["GBps"] / HBM_PEAK_GBPS,
             "traffic": traffic,
-            "traffic_source": None if traffic is None else "profiles/r01_pmc_traffic_c2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)",
+            "traffic_source": None if traffic is None else PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)",
             "launches": table[dom]["launches"],
             "avg_launch_us": table[dom]["avg_us"],
             "algorithmic_bytes_per_launch": table[dom]["bytes_per_launch"],

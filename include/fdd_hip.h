@@ -170,6 +170,11 @@ int fdd_sub_stiffness_matrix_2(double *Au, const double *const GDu[3], const dou
  * that level's elements; elem_offset[e] (device) is the first point of element
  * e in u / Au / G (NULL => e * (N+1)^3). */
 int fdd_sub_stiffness_matrix(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
+/* 2-D form of the fused kernel (the DIM == 2 branches of domain.okl:20-33 and :69-80 in one launch, 40 B/point):
+ * elements of (poly_degree+1)^2 points, G[0] = G11, G[1] = G22, G[2] = G12 (the other three are not read);
+ * elem_offset as in fdd_sub_stiffness_matrix (nullptr: element e starts at e*(poly_degree+1)^2).  Au may alias u.
+ * Bit-identical to fdd_dom_stiffness_matrix_1 + _2 with dim = 2. */
+int fdd_stiffness_matrix_2d(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
 /* The same with the boolean scatter Q of the subdomain fused into the load: u[p] = v[point_dof[p]]
  * (0 where point_dof[p] < 0), v a vector over the subdomain's dofs (Q v then A, subdomain.tpp:3977-3981 + 3942-3967). */
 int fdd_sub_stiffness_matrix_gather(double *Au, const double *v, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);

@@ -3,8 +3,8 @@
 // degree with per-point indirection).
 //
 // (1) Reference two-launch form (stiffness_matrix_1 / _2, one lane per point,
-//     global scratch GDu): kept for API parity, for 2-D and for any degree.
-//     112 B/point of HBM traffic.
+//     global scratch GDu): kept for API parity and for degrees above 15.
+//     112 B/point of HBM traffic (72 in 2-D).
 //
 // (2) Fused kernel (fdd_dom_stiffness_matrix / fdd_sub_stiffness_matrix):
 //     64 B/point (u 8 + six geometric factors 48 + Au 8).  An element of
@@ -554,6 +554,181 @@ int fused_dispatch(double *Au, const double *u, const int *point_dof, const doub
     }
 }
 
+// ---------------------------------------------------------------------------
+// (2') fused kernel, 2-D, n = N+1 in [2, 16]: domain.okl:20-33 / :69-80 (the DIM == 2 branches)
+// ---------------------------------------------------------------------------
+// 40 B/point (u 8 + three geometric factors 24 + Au 8) against the two-launch form's 72.  One lane per point,
+// floor(256 / n^2) elements per workgroup; the element and then G*Du go through LDS (rows padded by one double).
+// Same operation order as the reference per point, so the result is bit-identical to the two-launch form.
+template <int n, int kGroups, bool kNTStore>
+__global__ __launch_bounds__(kBlock) void fused_stiffness_2d_kernel(double *__restrict__ Au, const double *__restrict__ u, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
+{
+    constexpr int nn = n * n;
+    constexpr int epb = kBlock / nn;
+    constexpr int ld = n + 1;
+    static_assert(epb >= 1, "an element must fit a workgroup");
+    constexpr bool kWaveLocal = (64 % nn == 0); // an element never straddles a wavefront: no workgroup barrier between its LDS phases
+    constexpr bool kDReg = (n <= 8);            // the four D_hat rows/columns of a lane in registers
+    constexpr int nd = kDReg ? n : 1;
+
+    __shared__ double s_D[nn];
+    __shared__ double s_u[epb][n * ld];
+    __shared__ double s_g[2][epb][n * ld];
+
+    const int tid = threadIdx.x;
+    const int e_loc = tid / nn;
+    const int ij = tid - e_loc * nn;
+    const int j = ij / n;
+    const int i = ij - j * n;
+    const int el = (e_loc < epb) ? e_loc : 0;
+    const int lpos = i + j * ld;
+
+    for (int t = tid; t < nn; t += kBlock) s_D[t] = D_hat[t];
+    __syncthreads();
+    double D_i[nd], D_j[nd], Dt_i[nd], Dt_j[nd];
+    if (kDReg)
+    {
+#pragma unroll
+        for (int k = 0; k < nd; k++)
+        {
+            D_i[k] = s_D[k + i * n];
+            D_j[k] = s_D[k + j * n];
+            Dt_i[k] = s_D[i + k * n];
+            Dt_j[k] = s_D[j + k * n];
+        }
+    }
+
+    // A workgroup takes kGroups consecutive groups of epb elements and requests all of their u and factors before it
+    // computes the first: one point per lane and group is 32 B, too little in flight to cover the HBM latency.
+    const int first = blockIdx.x * kGroups;
+    bool active[kGroups];
+    size_t at[kGroups];
+    double r_u[kGroups], g0[kGroups], g1[kGroups], g2[kGroups];
+#pragma unroll
+    for (int q = 0; q < kGroups; q++)
+    {
+        const int elem = (first + q) * epb + e_loc;
+        active[q] = (e_loc < epb) && (elem < num_elements);
+        at[q] = 0;
+        r_u[q] = g0[q] = g1[q] = g2[q] = 0.0;
+        if (active[q])
+        {
+            at[q] = (elem_offset ? (size_t)elem_offset[elem] : (size_t)elem * nn) + ij;
+            r_u[q] = __builtin_nontemporal_load(u + at[q]);
+            g0[q] = __builtin_nontemporal_load(G.g[0] + at[q]);
+            g1[q] = __builtin_nontemporal_load(G.g[1] + at[q]);
+            g2[q] = __builtin_nontemporal_load(G.g[2] + at[q]);
+        }
+    }
+
+    double *su = s_u[el];
+    double *sg1 = s_g[0][el];
+    double *sg2 = s_g[1][el];
+#pragma unroll
+    for (int q = 0; q < kGroups; q++)
+    {
+        if (active[q]) su[lpos] = r_u[q];
+        element_sync<kWaveLocal>();
+
+        int io = i, jo = j;
+        if (!kDReg) asm volatile("" : "+v"(io), "+v"(jo));
+        double Du_1 = 0.0, Du_2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < n; k++)
+        {
+            const double di = kDReg ? D_i[kDReg ? k : 0] : s_D[k + io * n];
+            const double dj = kDReg ? D_j[kDReg ? k : 0] : s_D[k + jo * n];
+            Du_1 += di * su[k + j * ld];
+            Du_2 += dj * su[i + k * ld];
+        }
+        if (active[q])
+        {
+            sg1[lpos] = g0[q] * Du_1 + g2[q] * Du_2;
+            sg2[lpos] = g2[q] * Du_1 + g1[q] * Du_2;
+        }
+        element_sync<kWaveLocal>();
+
+        double Au_1 = 0.0, Au_2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < n; k++)
+        {
+            const double dti = kDReg ? Dt_i[kDReg ? k : 0] : s_D[io + k * n];
+            const double dtj = kDReg ? Dt_j[kDReg ? k : 0] : s_D[jo + k * n];
+            Au_1 += dti * sg1[k + j * ld];
+            Au_2 += dtj * sg2[i + k * ld];
+        }
+        if (active[q])
+        {
+            if (kNTStore)
+                __builtin_nontemporal_store(Au_1 + Au_2, Au + at[q]);
+            else
+                Au[at[q]] = Au_1 + Au_2;
+        }
+    }
+}
+
+template <int n>
+int launch_fused_2d(double *Au, const double *u, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
+{
+    constexpr int epb = kBlock / (n * n);
+    const int groups = (num_elements + epb - 1) / epb;
+    static const bool nt_store = fdd_env_int("FDD_TUNE_STIFFNESS_NT_STORE", 1) != 0;
+    static const int per_block = fdd_env_int("FDD_TUNE_STIFFNESS_2D_GROUPS", 4);
+#define FDD_2D_LAUNCH(K_) \
+    do \
+    { \
+        const int grid = (groups + K_ - 1) / K_; \
+        if (nt_store) \
+            hipLaunchKernelGGL((fused_stiffness_2d_kernel<n, K_, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, D_hat, G, elem_offset, num_elements); \
+        else \
+            hipLaunchKernelGGL((fused_stiffness_2d_kernel<n, K_, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, D_hat, G, elem_offset, num_elements); \
+    } while (0)
+    // few elements: one group per workgroup keeps more workgroups in the launch
+    if (per_block >= 4 && groups >= 4 * 2048)
+        FDD_2D_LAUNCH(4);
+    else if (per_block >= 2 && groups >= 2 * 2048)
+        FDD_2D_LAUNCH(2);
+    else
+        FDD_2D_LAUNCH(1);
+#undef FDD_2D_LAUNCH
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fused_dispatch_2d(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    FDD_REQUIRE(num_elements >= 0);
+    if (num_elements == 0) return 0;
+    FDD_REQUIRE(Au != nullptr && u != nullptr && D_hat != nullptr && G != nullptr);
+    GPtrs g;
+    for (int k = 0; k < FDD_NUM_GEOM_FACTS; k++) g.g[k] = G[k]; // 2-D reads G[0] = G11, G[1] = G22, G[2] = G12 only
+    FDD_REQUIRE(g.g[0] != nullptr && g.g[1] != nullptr && g.g[2] != nullptr);
+    switch (poly_degree + 1)
+    {
+#define FDD_2D_CASE(N_) \
+    case N_: return launch_fused_2d<N_>(Au, u, D_hat, g, elem_offset, num_elements, stream);
+        FDD_2D_CASE(2)
+        FDD_2D_CASE(3)
+        FDD_2D_CASE(4)
+        FDD_2D_CASE(5)
+        FDD_2D_CASE(6)
+        FDD_2D_CASE(7)
+        FDD_2D_CASE(8)
+        FDD_2D_CASE(9)
+        FDD_2D_CASE(10)
+        FDD_2D_CASE(11)
+        FDD_2D_CASE(12)
+        FDD_2D_CASE(13)
+        FDD_2D_CASE(14)
+        FDD_2D_CASE(15)
+        FDD_2D_CASE(16)
+#undef FDD_2D_CASE
+    default:
+        fdd_set_error("fused 2-D stiffness kernel supports poly_degree 1..15, got %d (use the two-launch form)", poly_degree);
+        return FDD_ERR_UNSUPPORTED;
+    }
+}
+
 int fill_level_table(LevelTable &T, const double *const *D_hat_ptr, const int *poly_degree, int num_levels)
 {
     FDD_REQUIRE(D_hat_ptr != nullptr && poly_degree != nullptr && num_levels >= 1 && num_levels <= 16);
@@ -611,6 +786,11 @@ int fdd_dom_stiffness_matrix(double *Au, const double *u, const double *D_hat, c
 int fdd_sub_stiffness_matrix(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
 {
     return fused_dispatch(Au, u, nullptr, nullptr, D_hat, G, elem_offset, num_elements, poly_degree, stream);
+}
+
+int fdd_stiffness_matrix_2d(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    return fused_dispatch_2d(Au, u, D_hat, G, elem_offset, num_elements, poly_degree, stream);
 }
 
 int fdd_sub_stiffness_matrix_gather(double *Au, const double *v, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)

@@ -635,6 +635,11 @@ class Domain
             fdd::ProfileScope prof("fused_stiffness_kernel", 64.0 * num_local_points);
             FDD_CALL(fdd_dom_stiffness_matrix(Au.as<double>(), u.as<double>(), D_hat.as<double>(), G_ptrs, num_local_elements, poly_degree, fdd::dev().stream));
         }
+        else if (mesh.dim == 2 and poly_degree <= 15)
+        {
+            fdd::ProfileScope prof("fused_stiffness_2d_kernel", 40.0 * num_local_points);
+            FDD_CALL(fdd_stiffness_matrix_2d(Au.as<double>(), u.as<double>(), D_hat.as<double>(), G_ptrs, nullptr, num_local_elements, poly_degree, fdd::dev().stream));
+        }
         else
         {
             double *GDu[3] = {work_dev[0].as<double>(), work_dev[1].as<double>(), work_dev[2].as<double>()};

@@ -1464,9 +1464,24 @@ class Subdomain
                     FDD_CALL(fdd_sub_stiffness_matrix(Au_sub_l.as<double>(), u_sub_l.as<double>(), subdomain_operator.D_hat[ll.level].template as<double>(), subdomain_operator.G_ptrs, ll.elem_offset.template as<int>(), ll.num_elements, ll.poly_degree, fdd::dev().stream));
                 }
             }
+            else if (dim == 2 and ll.poly_degree <= 15)
+            {
+                const double n2 = (double)(ll.poly_degree + 1) * (ll.poly_degree + 1);
+                fdd::ProfileScope prof("fused_stiffness_2d_kernel", 40.0 * n2 * ll.num_elements);
+                if (ll.contiguous)
+                {
+                    const double *Gs[NUM_GEOM_FACTS];
+                    for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = ll.G[g];
+                    FDD_CALL(fdd_stiffness_matrix_2d(Au_sub_l.as<double>() + ll.first_offset, u_sub_l.as<double>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), Gs, nullptr, ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                }
+                else
+                {
+                    FDD_CALL(fdd_stiffness_matrix_2d(Au_sub_l.as<double>(), u_sub_l.as<double>(), subdomain_operator.D_hat[ll.level].template as<double>(), subdomain_operator.G_ptrs, ll.elem_offset.template as<int>(), ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                }
+            }
             else
             {
-                // 2-D / very high degree: reference two-launch form on the contiguous list
+                // degree above 15: reference two-launch form on the contiguous list
                 const int npts = ll.num_elements * (int)std::lround(std::pow(ll.poly_degree + 1, dim));
                 double *GDu[3] = {work_dev[0].as<double>(), work_dev[1].as<double>(), work_dev[2].as<double>()};
                 const double *Gs[NUM_GEOM_FACTS];

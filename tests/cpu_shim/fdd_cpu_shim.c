@@ -118,6 +118,22 @@ static int fused(double *Au, const double *u, const double *D, const double *con
 }
 int fdd_dom_stiffness_matrix(double *Au, const double *u, const double *D, const double *const G[6], int ne, int N, void *s) { (void)s; return fused(Au, u, D, G, NULL, ne, N); }
 int fdd_sub_stiffness_matrix(double *Au, const double *u, const double *D, const double *const G[6], const int *eo, int ne, int N, void *s) { (void)s; return fused(Au, u, D, G, eo, ne, N); }
+int fdd_stiffness_matrix_2d(double *Au, const double *u, const double *D, const double *const G[6], const int *eo, int ne, int N, void *s)
+{
+    (void)s;
+    int n2 = (N + 1) * (N + 1);
+    double *w[3] = {(double *)malloc(sizeof(double) * (size_t)n2), (double *)malloc(sizeof(double) * (size_t)n2), NULL};
+    for (int e = 0; e < ne; e++)
+    {
+        size_t o = eo ? (size_t)eo[e] : (size_t)e * n2;
+        const double *Ge[6];
+        for (int g = 0; g < 6; g++) Ge[g] = G[g] ? G[g] + o : NULL;
+        orc_dom_stiffness_matrix_1(w, u + o, D, Ge, n2, N, 2);
+        orc_dom_stiffness_matrix_2(Au + o, (const double *const *)w, D, n2, N, 2);
+    }
+    free(w[0]); free(w[1]);
+    return 0;
+}
 int fdd_sub_stiffness_matrix_gather(double *Au, const double *v, const int *pd, const double *D, const double *const G[6], const int *eo, int ne, int N, void *s)
 {
     (void)s;

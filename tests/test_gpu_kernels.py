@@ -508,6 +508,28 @@ def test_stiffness_fused_bit_exact(gpu, N):
         assert np.array_equal(host(dAu), Au), (N, E)
 
 
+@pytest.mark.parametrize("N", list(range(1, 16)))
+def test_stiffness_fused_two_dimensional_bit_exact(gpu, N):
+    """The fused 2-D kernel (domain.okl's DIM == 2 branches in one launch) == the oracle's two-kernel arithmetic,
+    bit for bit; element counts that do not fill the last workgroup, an offset list in reverse order, in place."""
+    n2 = (N + 1) ** 2
+    # the last size makes every workgroup walk 8 groups of elements (launch_fused_2d), the last one ragged
+    walking = [(256 // n2) * (8 * 4096 + 3) + 1] if N in (1, 3, 7, 10, 15) else []
+    for E in [1, 9, 1030] + walking:
+        u, G, D = stiffness_inputs(E, N, 490 + N, 2)
+        Au, _ = oracle_stiffness(u, G, D, N, 2)
+        dG = [dev(g, gpu) for g in G]
+        dAu = torch.full((len(u),), 3.0, dtype=torch.float64, device=gpu)
+        k("fdd_stiffness_matrix_2d", dAu, dev(u, gpu), dev(D, gpu), dG, None, E, N)
+        assert np.array_equal(host(dAu), Au), (N, E)
+        eo = (np.arange(E)[::-1] * n2).astype(np.int32)
+        du = dev(u, gpu)
+        k("fdd_stiffness_matrix_2d", du, du, dev(D, gpu), dG, dev(eo, gpu), E, N)
+        assert np.array_equal(host(du), Au), (N, E)
+    with pytest.raises(lib.FddError):
+        k("fdd_stiffness_matrix_2d", dAu, dev(u, gpu), dev(D, gpu), dG, None, 1, 16)
+
+
 @pytest.mark.parametrize("N", [1, 2, 3, 4, 6, 7, 9, 15])
 def test_stiffness_fused_gather_on_load(gpu, N):
     """fdd_sub_stiffness_matrix_gather: u[p] = v[point_dof[p]] (0 where the point

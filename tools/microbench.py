@@ -175,6 +175,15 @@ def main():
             k("fdd_dom_stiffness_matrix_2", Au, GDu, Dh, P, N, 3)
 
         report(f"stiffness.two_launch N={N} (112 B/pt)", 112 * P, timeit(two, iters=5), results)
+        # the same buffers read as 2-D elements of (N+1)^2 points: fused 2-D kernel (40 B/pt) against its two-launch form (72 B/pt)
+        E2 = P // (n * n)
+        report(f"stiffness.fused_2d N={N}", 40 * P, timeit(lambda: k("fdd_stiffness_matrix_2d", Au, u, Dh, G, None, E2, N)), results)
+
+        def two_2d():
+            k("fdd_dom_stiffness_matrix_1", GDu, u, Dh, G, P, N, 2)
+            k("fdd_dom_stiffness_matrix_2", Au, GDu, Dh, P, N, 2)
+
+        report(f"stiffness.two_launch_2d N={N} (72 B/pt)", 72 * P, timeit(two_2d, iters=5), results)
         del G
 
     if want("csr"):
