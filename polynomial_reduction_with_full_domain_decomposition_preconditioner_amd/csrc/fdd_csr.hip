@@ -37,14 +37,18 @@ constexpr int kBlockNnzSmall = FDD_CSR_BLOCK_NNZ / 2;
 
 // Row epilogues.  apply() = operand() + finish(): the block kernel loads the operands of all its rows up front
 // (unconditionally, with its other loads) and finishes once the row sums are known.
+// kFreeOrder: the entry stands in for cusparseSpMV (AMG/csr_matrix.cpp:129-131), whose summation order is not
+// defined: wide rows may be summed by several lanes.  The csr_matrix.okl replacements keep the column order.
 struct EpiPlain
 {
+    static constexpr bool kFreeOrder = false;
     typedef double Opnd;
     __device__ double operand(int, const double *) const { return 0.0; }
     __device__ double finish(double s, double, int) const { return s; }
 };
 struct EpiWeight
 {
+    static constexpr bool kFreeOrder = false;
     typedef double Opnd;
     const double *weight;
     __device__ double operand(int row, const double *) const { return weight[row]; }
@@ -53,6 +57,7 @@ struct EpiWeight
 template <typename T>
 struct EpiAxpbyT // AMG/csr_matrix.cpp:112-134
 {
+    static constexpr bool kFreeOrder = true;
     typedef T Opnd;
     T alpha, beta;
     const T *y_in; // optional: y = alpha*A*x + beta*y_in with y_in another vector (f - A u without copying f first)
@@ -79,6 +84,7 @@ struct Opnd3
 template <typename T>
 struct EpiSmoothResidualT
 {
+    static constexpr bool kFreeOrder = true;
     typedef Opnd2<T> Opnd;
     const T *f, *D;
     T *r; // Sr
@@ -97,6 +103,7 @@ struct EpiSmoothResidualT
 template <typename T>
 struct EpiSmoothPolyT
 {
+    static constexpr bool kFreeOrder = true;
     typedef Opnd2<T> Opnd;
     const T *r, *D;
     T coef;
@@ -112,6 +119,7 @@ struct EpiSmoothPolyT
 template <typename T>
 struct EpiSmoothUpdateT
 {
+    static constexpr bool kFreeOrder = true;
     typedef Opnd3<T> Opnd;
     const T *r, *D;
     T coef;
@@ -168,7 +176,7 @@ __device__ __forceinline__ float wave_sum(float v)
 
 // T: the value type of the matrix and of both vectors (double everywhere except the Float = float V-cycle, AMG/config.hpp:4)
 template <typename T, typename Epi, bool UNIT, int kBlockNnz>
-__global__ __launch_bounds__(kBlock) void csr_block_kernel(T *__restrict__ Au, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const T *__restrict__ A_val, const T *__restrict__ u, Epi epi, const int *__restrict__ row_blocks, int xcd_chunked)
+__global__ __launch_bounds__(kBlock) void csr_block_kernel(T *__restrict__ Au, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const T *__restrict__ A_val, const T *__restrict__ u, Epi epi, const int *__restrict__ row_blocks, int xcd_chunked, int split_rows)
 {
     __shared__ T prod[kBlockNnz];
     // Matrices with short rows (the small block size) have hundreds of rows per block: their row pointers and
@@ -225,9 +233,16 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(T *__restrict__ Au, c
                 opnd[it] = epi.operand(r0 + rs, Au);
             }
         }
+        // wide rows, free summation order: `lanes` (a power of two, as many as the block's rows leave room for) add one
+        // row together -- with a lane per row a block of 2048 non-zeros in rows of 50 keeps 40 of its 256 lanes
+        // busy with 50 dependent additions each
+        int lanes = 1;
+        if (Epi::kFreeOrder && !kStageRows && split_rows)
+            while (lanes < 16 && nrows * lanes * 2 <= kBlock) lanes *= 2;
+        const int my_row = threadIdx.x / lanes; // lanes == 1: the lane's first row
         // wide rows: the lane's first row (the only one, unless the block is full of short rows) has its
         // pointers and epilogue operand requested here, so that nothing is loaded from HBM after the barrier
-        const int rs0 = (threadIdx.x < nrows) ? threadIdx.x : 0;
+        const int rs0 = (my_row < nrows) ? my_row : 0;
         const int first_j0 = kStageRows ? 0 : A_ptr[r0 + rs0] - base;
         const int first_j1 = kStageRows ? 0 : A_ptr[r0 + rs0 + 1] - base;
         const typename Epi::Opnd first_opnd = epi.operand(r0 + rs0, Au); // unused (and dropped) when the rows are staged
@@ -265,6 +280,31 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(T *__restrict__ Au, c
                     Au[r0 + r] = epi.finish(Au_i, opnd[it], r0 + r);
                 }
             }
+        }
+        else if (lanes > 1)
+        {
+            // all rows of the block in one pass (nrows * lanes <= 256); lane s of a row adds its entries s, s + lanes, ...
+            // (adjacent lanes read adjacent products), then the partial sums are folded by a shuffle tree
+            const int s = threadIdx.x & (lanes - 1);
+            const bool on = my_row < nrows;
+            T acc = T(0);
+            if (on)
+            {
+                for (int j = first_j0 + s; j < first_j1; j += 4 * lanes)
+                {
+                    const int j1 = j + lanes, j2 = j + 2 * lanes, j3 = j + 3 * lanes;
+                    const T p0 = prod[j];
+                    const T p1 = prod[(j1 < kBlockNnz) ? j1 : j];
+                    const T p2 = prod[(j2 < kBlockNnz) ? j2 : j];
+                    const T p3 = prod[(j3 < kBlockNnz) ? j3 : j];
+                    acc += p0;
+                    acc += (j1 < first_j1) ? p1 : T(0);
+                    acc += (j2 < first_j1) ? p2 : T(0);
+                    acc += (j3 < first_j1) ? p3 : T(0);
+                }
+            }
+            for (int off = lanes >> 1; off > 0; off >>= 1) acc += __shfl_down(acc, off, FDD_WAVE);
+            if (on && s == 0) Au[r0 + my_row] = epi.finish(acc, first_opnd, r0 + my_row);
         }
         else
         {
@@ -691,10 +731,11 @@ static int plan_launch(const fdd_csr_plan *plan, double *y, const int *A_ptr, co
     if (plan->one_per_row) return launch_one_per_row(y, A_col, A_val, x, epi, plan->num_rows, stream, plan->unit_values != 0);
     if (plan->kind == 0) return launch_rows(y, A_ptr, A_col, A_val, x, epi, 0, plan->num_rows, stream, plan->unit_values != 0);
     const dim3 grid(plan->num_blocks), block(kBlock);
+    static const int split_rows = fdd_env_int("FDD_TUNE_CSR_SPLIT_ROWS", 1);
     if (plan->unit_values)
-        FDD_CSR_BLOCK(Epi, true, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
+        FDD_CSR_BLOCK(Epi, true, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked, split_rows);
     else
-        FDD_CSR_BLOCK(Epi, false, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
+        FDD_CSR_BLOCK(Epi, false, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked, split_rows);
     FDD_LAUNCH_CHECK();
     return 0;
 }
@@ -710,10 +751,11 @@ static int plan_launch_f32(const fdd_csr_plan *plan, float *y, const int *A_ptr,
     }
     if (plan->sell_slices > 0) return sell_launch<float, Epi>(plan, y, x, epi, stream);
     const dim3 grid(plan->num_blocks), block(kBlock);
+    static const int split_rows = fdd_env_int("FDD_TUNE_CSR_SPLIT_ROWS", 1);
     if (plan->block_nnz == kBlockNnzSmall)
-        hipLaunchKernelGGL((csr_block_kernel<float, Epi, false, kBlockNnzSmall>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
+        hipLaunchKernelGGL((csr_block_kernel<float, Epi, false, kBlockNnzSmall>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked, split_rows);
     else
-        hipLaunchKernelGGL((csr_block_kernel<float, Epi, false, kBlockNnzMax>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked);
+        hipLaunchKernelGGL((csr_block_kernel<float, Epi, false, kBlockNnzMax>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked, split_rows);
     FDD_LAUNCH_CHECK();
     return 0;
 }
@@ -1031,16 +1073,16 @@ int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr
     if (plan->unit_values)
     {
         if (weight)
-            FDD_CSR_BLOCK(EpiWeight, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev, plan->xcd_chunked);
+            FDD_CSR_BLOCK(EpiWeight, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev, plan->xcd_chunked, 0);
         else
-            FDD_CSR_BLOCK(EpiPlain, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev, plan->xcd_chunked);
+            FDD_CSR_BLOCK(EpiPlain, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev, plan->xcd_chunked, 0);
     }
     else
     {
         if (weight)
-            FDD_CSR_BLOCK(EpiWeight, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev, plan->xcd_chunked);
+            FDD_CSR_BLOCK(EpiWeight, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev, plan->xcd_chunked, 0);
         else
-            FDD_CSR_BLOCK(EpiPlain, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev, plan->xcd_chunked);
+            FDD_CSR_BLOCK(EpiPlain, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev, plan->xcd_chunked, 0);
     }
     FDD_LAUNCH_CHECK();
     return 0;

@@ -1087,16 +1087,22 @@ def test_csr_plan_matvec_axpby(gpu, shape):
             y_in = np.full(rows, np.nan) if beta == 0.0 else y0
             dy = dev(y_in, gpu)
             k("fdd_csr_plan_matvec", plan, dy, dev(ptr, gpu), dev(col, gpu), dev(val, gpu), dev(x, gpu), alpha, beta)
-            assert np.array_equal(host(dy), ref), (shape, alpha, beta)
+            # the entry stands in for cusparseSpMV, whose summation order is undefined: row blocks with few, wide rows
+            # are summed by several lanes per row (boolean short-row matrices keep the column order)
+            if shape == "boolean":
+                assert np.array_equal(host(dy), ref), (shape, alpha, beta)
+            else:
+                assert np.allclose(host(dy), ref, rtol=1e-12, atol=1e-13), (shape, alpha, beta)
     finally:
         lib.hip().call("fdd_csr_plan_destroy", plan)
 
 
 @pytest.mark.parametrize("shape", ["boolean", "stencil", "dense", "long_row"])
 def test_amg_smoother_fused_into_spmv(gpu, shape):
-    """The Chebyshev smoother's element-wise kernels as SpMV epilogues: bit-identical to
-    the oracle's unfused sequence matvec -> scaled_residual / polynomial_evaluation /
-    update_field -> vector_multiplication (subdomain.tpp:19-83), on every plan kind."""
+    """The Chebyshev smoother's element-wise kernels as SpMV epilogues: the oracle's unfused
+    sequence matvec -> scaled_residual / polynomial_evaluation / update_field ->
+    vector_multiplication (subdomain.tpp:19-83), on every plan kind; bit-identical where the
+    row sums keep the column order."""
     L = S.oracle()
     rng = np.random.default_rng(90)
     if shape == "boolean":
@@ -1126,8 +1132,9 @@ def test_amg_smoother_fused_into_spmv(gpu, shape):
         val = rng.uniform(-1, 1, len(col))
     u, f, D, w_in = rnd(n, 92), rnd(n, 93), rnd(n, 94) + 1.5, rnd(n, 95)
     coef = -0.37
-    # a row longer than a block is summed by the whole workgroup (shuffle tree): same values, other order
-    same = (lambda a, b: np.allclose(a, b, rtol=1e-12, atol=1e-13)) if shape == "long_row" else np.array_equal
+    # a row longer than a block is summed by the whole workgroup (shuffle tree) and the rows of a block with few, wide
+    # rows by several lanes each: same values, other order (the reference's cusparseSpMV defines none)
+    same = np.array_equal if shape == "boolean" else (lambda a, b: np.allclose(a, b, rtol=1e-12, atol=1e-13))
     c = ctypes.c_double
     plan = vp()
     lib.hip().call("fdd_csr_plan_create", ctypes.byref(plan), vp(ptr.ctypes.data), n, n, len(col))
