@@ -300,3 +300,74 @@ def test_fdd_preconditioner_cuts_iterations():
     assert gold["gmres+gmres"]["iterations"] < gold["gmres+none"]["iterations"] / 2
     h = gold["precond_gmres"]["history"]
     assert all(h[i + 1] <= h[i] for i in range(len(h) - 1))  # GMRES residual estimate is monotone
+
+
+# --------------------------------------------------------------------------
+# The full-domain-decomposition composite (oracle/fdd_oracle_composite.c): properties the construction of
+# subdomain.tpp:86-2747 must have whatever hierarchy grades the superdomain.  The reference holds no fixture for it
+#  and its own grading needs HYPRE; these pin the restatement independently of the product.
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("Pg,E,N,red", [((2, 1, 1), (8, 4, 4), 3, 2), ((2, 2, 1), (8, 8, 4), 4, 2), ((2, 2, 2), (8, 8, 8), 3, 1)])
+def test_composite_structure_properties(Pg, E, N, red):
+    F = S.OracleFdd(E, N, red, Pg)
+    try:
+        for r in range(F.R):
+            info = F.info[r]
+            ids, lv = F.region(r)
+            # region = own elements at level 0, then rings at non-decreasing level; every global element at most once
+            assert len(set(ids.tolist())) == len(ids) and np.all(np.diff(lv[: info["sub_elems"]]) >= 0)
+            assert len(set(lv.tolist())) == len(F.deg)
+            # the non-conforming Q is conforming in the sense that matters: dof values sampled from a trilinear function
+            # (a member of every degree's space on these affine elements) are reproduced at EVERY region point, also at
+            # the hanging ones that the J_cf rows interpolate (subdomain.tpp:1179-1585); Dirichlet points get 0
+            x, y, z = (F.region_points(r, a) for a in "xyz")
+            mask = F.region_points(r, "p_mask")
+            fun = (1 + 2 * x - y + 0.5 * z + x * y - 0.3 * y * z + 0.7 * x * z + 0.2 * x * y * z) * mask
+            Q = F.matrix(r, "Q")
+            pd = F.point_dofs(r)
+            assert Q.shape == (info["points"], info["sub_ext_dofs"])
+            dof_val = np.full(info["sub_ext_dofs"], np.nan)
+            dof_val[pd[pd >= 0]] = fun[pd >= 0]
+            assert not np.isnan(dof_val).any()  # every dof sits on some point
+            # rows are partitions of unity, except that Dirichlet dofs are not stored: a hanging point next to the
+            # boundary keeps only the weights of its interior parents
+            rowsum = Q.sum(axis=1).A1
+            full = np.abs(rowsum - 1.0) <= 1e-13
+            assert np.all(full[pd >= 0]) and np.all(rowsum[mask == 0] == 0)
+            hanging = full & (pd < 0)
+            assert hanging.sum() > 0 and (Q[hanging] != 0).sum(axis=1).max() >= 2
+            assert np.abs(Q @ dof_val - fun)[full].max() <= 1e-13
+            assert (F.matrix(r, "Qt") != Q.T).nnz == 0
+            # copy-from-owner over interface and extended dofs (subdomain.tpp:2653-2729) is a projection
+            M = F.matrix(r, "QQt_int")
+            assert abs(M @ M - M).max() <= 1e-15 and abs(F.matrix(r, "Q_int") @ F.matrix(r, "Qt_int") - M).max() <= 1e-15
+            # norm_weight marks each unique dof exactly once (subdomain.tpp:2731-2747)
+            w = F.norm_weight(r)
+            assert set(np.unique(w).tolist()) <= {0.0, 1.0} and int(w.sum()) == info["unique_dofs"]
+            # superdomain operator: symmetric, rows of the interpolator's transpose non-negative
+            A = F.matrix(r, "A_sup")
+            assert abs(A - A.T).max() <= 1e-12 * abs(A).max()
+            assert F.composite_levels(r)[0] >= info["sup_dofs"] > 0
+    finally:
+        F.close()
+
+
+def test_uncoarsened_degree_one_composite_is_the_global_operator():
+    """N = 1 and a superdomain overlap wider than the mesh: nothing is interpolated and nothing aggregated, so every
+    rank's composite is the assembled global operator and a converged inner solve returns the global solution on the
+    rank's own points -- rings, ring pull, coarse all-gather, Qt_coarse, Pt, A_sup and the interface maps all have to
+    be right for that."""
+    E, Pg = (4, 4, 4), (2, 2, 1)
+    F = S.OracleFdd(E, 1, 1, Pg, 1, 100)
+    meshes = [S.BoxMesh(E, 1, Pg, r) for r in range(F.R)]
+    W = S.OracleWorld(meshes, 1)
+    try:
+        us = [(np.sin(3 * m.x + 1) * np.cos(2 * m.y) + m.z * m.x) * m.p_mask for m in meshes]
+        r = W.stiffness(us)  # element-local A u*: its assembly Qt r is the global right-hand side of u*
+        z, hist = F.precondition(r, "gmres", num_vectors=60, max_iterations=60, tolerance=1e-14)
+        for k in range(F.R):
+            assert hist[k][-1] <= 1e-12 * hist[k][0]
+            assert np.abs(z[k] - us[k]).max() <= 1e-10 * np.abs(us[k]).max(), k
+    finally:
+        W.close()
+        F.close()
