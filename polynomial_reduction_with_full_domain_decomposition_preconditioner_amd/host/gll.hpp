@@ -3,7 +3,7 @@
  * Lagrange interpolants.  The reference takes these from Nek5000's Fortran
  * speclib (special_functions.f: ZWGLL :108, DGLL :781, HGLL :816, PNLEG :856,
  * PNDLEG :888); this is an independent C++ implementation of the same
- * formulas.  tests/test_gll.py pins it against tables produced by the
+ * formulas.  tests/test_cpu_oracle.py pins it against tables produced by the
  * reference's own Fortran (tests/golden/gll_tables.json).
  */
 #ifndef FDD_GLL_HPP
