@@ -111,7 +111,7 @@ def cpu_baseline(args):
     }
 
 
-PMC_FILE = "profiles/r02_pmc_traffic_c2.json"
+PMC_FILES = ["profiles/r02_pmc_traffic_c2.json", "profiles/r02_pmc_traffic_c3.json"]  # one per profiled workload
 
 
 def pmc_traffic(kernel_key, elements, degree):
@@ -119,13 +119,18 @@ def pmc_traffic(kernel_key, elements, degree):
     (tools/profile_bench.sh: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this
     same command; FETCH_SIZE doubled on gfx950 per MI355X_MICROARCH.md).  None when the
     committed counters are for another workload or kernel."""
-    path = os.path.join(ROOT, PMC_FILE)
-    if not os.path.exists(path):
-        return None
-    with open(path) as fh:
-        pmc = json.load(fh)
-    if pmc.get("workload") != {"elements_per_gpu": elements, "degree": degree}:
-        return None
+    pmc = source = None
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as fh:
+            cand = json.load(fh)
+        if cand.get("workload") == {"elements_per_gpu": elements, "degree": degree}:
+            pmc, source = cand, name
+            break
+    if pmc is None:
+        return None, None
     family, gather = kernel_key.split("<")[0], "<gather" in kernel_key
     best = None
     for name, st in pmc["kernels"].items():
@@ -136,9 +141,11 @@ def pmc_traffic(kernel_key, elements, degree):
             # fused_stiffness_kernel_t<T, n, kGather, kNTStore>: the double instance with the same gather flag
             if len(targs) < 3 or targs[0] != "double" or (targs[2] == "true") != gather:
                 continue
+        if family == "mfma_stiffness_kernel" and (len(targs) < 2 or (targs[1] == "true") != gather):
+            continue  # mfma_stiffness_kernel<n, kGather>
         if best is None or st["launches"] > best["launches"]:
             best = st
-    return None if best is None else best["hbm_bytes_per_launch"]
+    return (None, None) if best is None else (best["hbm_bytes_per_launch"], source)
 
 
 def main():
@@ -309,7 +316,7 @@ def main():
     roofline = None
     if table:
         dom = max(table, key=lambda k: table[k]["total_ms"])
-        traffic = None if (args.amg or args.no_precond or composite) else pmc_traffic(dom, e, N)  # the committed counters are for the default single-rank workload
+        traffic, traffic_file = (None, None) if (args.amg or args.no_precond or composite) else pmc_traffic(dom, e, N)  # the committed counters are for the single-rank workloads
         roofline = {
             "bound": "hbm",
             "kernel": dom,
@@ -318,7 +325,7 @@ def main():
             "unit": "GB/s",
             "frac": table[dom]["GBps"] / HBM_PEAK_GBPS,
             "traffic": traffic,
-            "traffic_source": None if traffic is None else PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)",
+            "traffic_source": None if traffic is None else traffic_file + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)",
             "launches": table[dom]["launches"],
             "avg_launch_us": table[dom]["avg_us"],
             "algorithmic_bytes_per_launch": table[dom]["bytes_per_launch"],

@@ -119,3 +119,35 @@ def test_mfma_path_properties_and_solve(problem15):
     x, its, hist = p.solve(f, "fcg")
     assert 0 < its < 500 and hist[-1] <= 1e-7 * hist[0] * 1.0001, (its, hist[-1] / hist[0])
     assert np.abs(x - u_star).max() <= 1e-3 * np.abs(u_star).max()  # 1e-7 on the residual of an operator of condition ~1e4
+
+
+# ---- BASELINE config C3 at full size: 32^3 elements of degree 15 (134 M points, 1.07 GB per point vector) ----
+def test_c3_full_size_matrix_core_path(gpu):
+    """The configuration the fp64-MFMA kernel exists for, at the size BASELINE.json quotes it on: the same
+    size-independent properties as above (no oracle run at this size) and the FDD-preconditioned flexible PCG down to
+    the reference's tolerance.  One problem, built and torn down inside the test (about 30 GB of HBM)."""
+    H.init(0)
+    H.comm_single()
+    H.set_print(False)
+    p = H.Problem.box((32, 32, 32), (1, 1, 1), 15, RED, True)
+    try:
+        p.set_flag("sub_use_preconditioner", 0)
+        assert p.n == 32**3 * 16**3 and p.info["num_total_nodes"] == 481**3
+        scale = np.abs(p.stiffness(S.seeded_uniform(p.n, 3))).max()
+        assert np.abs(p.stiffness(np.full(p.n, 2.5))).max() <= 1e-11 * scale  # constants are annihilated
+        u, v = S.seeded_uniform(p.n, 11) - 0.5, S.seeded_uniform(p.n, 12) - 0.5
+        us, vs = p.dssum(u, True, True), p.dssum(v, True, True)
+        Aus, Avs = p.stiffness(us, dssum=True), p.stiffness(vs, dssum=True)
+        wgt = 1.0 / p.mesh_array("node_degree")
+        uAv, vAu, uAu = np.dot(us * wgt, Avs), np.dot(vs * wgt, Aus), np.dot(us * wgt, Aus)
+        assert uAu > 0 and abs(uAv - vAu) <= 1e-11 * uAu  # symmetric positive on the assembled space
+        lin = p.stiffness(us + 0.5 * vs, dssum=True)
+        assert np.abs(lin - (Aus + 0.5 * Avs)).max() <= 1e-11 * np.abs(Aus).max()  # linear
+        del u, v, vs, Avs, lin
+        u_star, f = p.make_rhs_from(S.seeded_uniform(p.n, 1234))
+        x, its, hist = p.solve(f, "fcg")
+        assert 0 < its < 1000 and hist[-1] <= 1e-7 * hist[0] * 1.0001, (its, hist[-1] / hist[0])
+        # 1e-7 on the residual; the operator's condition number grows with the degree and the element count (measured 1.0e-3 here)
+        assert np.abs(x - u_star).max() <= 5e-3 * np.abs(u_star).max()
+    finally:
+        p.close()

@@ -65,7 +65,8 @@ def pmc(fetch_dir, write_dir, out, filters):
         rd = 2.0 * 1024.0 * fs / nf  # gfx950: FETCH_SIZE counts half
         wr = 1024.0 * ws / nw
         res[k] = {"launches": nf, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
-    json.dump({"workload": {"elements_per_gpu": 32, "degree": 7}, "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)", "kernels": res}, open(out, "w"), indent=1)
+    workload = {"elements_per_gpu": int(os.environ.get("FDD_PROFILE_ELEMENTS", "32")), "degree": int(os.environ.get("FDD_PROFILE_DEGREE", "7"))}
+    json.dump({"workload": workload, "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)", "kernels": res}, open(out, "w"), indent=1)
     for k, v in res.items():
         print("%-60s n=%4d read %.1f MB write %.1f MB" % (k, v["launches"], v["read_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6))
 
