@@ -192,19 +192,37 @@ def main():
     E = tuple(e * p for p in P)
     N = args.degree
 
-    t_setup = time.perf_counter()
-    prob = H.Problem.box(E, P, N, args.reduction, with_subdomain=not args.no_precond, block_local=args.block_local)
-    _, f = prob.make_rhs(function_id=4, seed=1234 + rank)  # rand()/RAND_MAX u*, poisson.cpp:211
-    t_setup = time.perf_counter() - t_setup
-    sub = prob.sub_info() if not args.no_precond else None
-    composite = bool(sub and sub["is_composite"])
-
     def max_over_ranks(x):
         if world == 1:
             return x
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    t_setup = time.perf_counter()
+    block_local, composite_error = args.block_local, None
+    if world > 1 and not args.no_precond and not block_local:
+        # The composite needs the point-to-point exchange (grouped send / receive) at setup and in every preconditioner
+        # application.  If that fails on this system the ranks agree on it and the run continues block-local, labelled.
+        prob = None
+        try:
+            prob = H.Problem.box(E, P, N, args.reduction, with_subdomain=True)
+            prob.sub_op("tree", np.zeros(prob.n))  # the solve-time ring pull and coarse all-gather, once
+        except Exception as exc:  # a failure all ranks see (an unsupported collective); a one-sided one cannot be caught here
+            composite_error = str(exc)
+        if max_over_ranks(1.0 if composite_error else 0.0) > 0:
+            composite_error = composite_error or "the composite failed on another rank"
+            if prob is not None:
+                prob.close()
+            block_local = True
+            if rank == 0:
+                print("bench.py: full-domain-decomposition composite unavailable (%s); continuing block-local" % composite_error, file=sys.stderr, flush=True)
+    if world == 1 or args.no_precond or block_local:
+        prob = H.Problem.box(E, P, N, args.reduction, with_subdomain=not args.no_precond, block_local=block_local)
+    _, f = prob.make_rhs(function_id=4, seed=1234 + rank)  # rand()/RAND_MAX u*, poisson.cpp:211
+    t_setup = time.perf_counter() - t_setup
+    sub = prob.sub_info() if not args.no_precond else None
+    composite = bool(sub and sub["is_composite"])
 
     amg_state = {"levels": 0, "setup_s": 0.0}
 
@@ -393,6 +411,8 @@ def main():
         "reference_default": reference_default,
         "kernels": table,
     }
+    if composite_error:
+        out["config"]["composite_unavailable"] = composite_error
     if composite:
         out["config"]["composite"] = {k: sub[k] for k in ("num_elems", "num_ext_elems", "num_points", "sub_dofs", "sub_ext_dofs", "interface_dofs", "sup_dofs", "sup_ext_dofs", "unique_dofs", "coarse_dofs", "num_peers")}
         out["config"]["composite"]["superdomain_levels"] = prob.sub_composite_levels()
