@@ -327,6 +327,67 @@ def test_full_domain_decomposition_converges_where_block_local_stalls(cpu_host_l
     assert blk[3][0] == 60 and blk[3][1] > 1e-3
 
 
+def _island_meshes(N):
+    """Three ranks: ranks 0 and 1 share a cut box; rank 2 owns a separate piece that touches nobody (a mesh-file
+    partition with a disconnected component), so its boundary-node prefix is EMPTY while its peers' is not."""
+    a, b = S.BoxMesh((4, 2, 2), N, (2, 1, 1), 0), S.BoxMesh((4, 2, 2), N, (2, 1, 1), 1)
+    c = S.BoxMesh((2, 2, 2), N)
+    c.glo_num = np.where(c.glo_num > 0, c.glo_num + 10**6, c.glo_num)
+    c.x = c.x + 2.0
+    return [a, b, c]
+
+
+def _island_worker(rank, world, port, mesh_dir, N):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
+
+    lib._host = lib._Lib(HOST_CPU_SO, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H.init(0, use_torch_stream=False)
+        H.set_print(False)
+        H.comm_torch_callbacks(on_gpu=False)
+        meshes = _island_meshes(N)
+        S.write_mesh_files(mesh_dir, meshes[rank], proc_id=rank)
+        dist.barrier()
+        p = H.Problem.from_directory(mesh_dir, N, 2, 1, 1, with_subdomain=False)
+        p.set_D_hat(0, S.gll(N)[2])
+        W = S.OracleWorld(meshes, N)
+        assert p.info["num_bdary_nodes"] == W.num_bdary(rank) and (p.info["num_bdary_nodes"] == 0) == (rank == 2)
+        assert p.info["num_interface_slots"] == W.L.orc_world_num_interface_slots(W.w) > 0
+        us = [np.sin(3 * m.x + 1) * np.cos(2 * m.y) + m.z * m.x for m in meshes]
+        # every path that exchanges the interface: initial function, stiffness with dssum, residual norm, both outer solvers
+        o_f = W.stiffness(W.dssum(us, True, True))
+        _, f = p.make_rhs_from(us[rank])
+        assert np.abs(f - o_f[rank]).max() <= 1e-13 * max(np.abs(o_f[r]).max() for r in range(world))
+        for flag in (1, 0):
+            p.set_flag("fused_dssum", flag)
+            d = p.dssum(us[rank], True, True)
+            assert np.abs(d - W.dssum(us, True, True)[rank]).max() <= 1e-14
+        p.set_flag("fused_dssum", 1)
+        for method in ("fcg", "gmres"):
+            u, its, hist = p.solve(f, method)
+            ou, oits, ohist = W.solve(o_f, method)
+            assert its == oits and np.abs(hist - ohist).max() <= 1e-8 * ohist[0], method
+            assert np.abs(u - ou[rank]).max() <= 1e-8 * max(np.abs(ou[r]).max() for r in range(world))
+        p.close()
+        W.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_without_shared_nodes_issues_the_same_collectives(cpu_host_lib, tmp_path):
+    """A rank whose partition touches no other rank still has to enter every interface all-reduce its peers enter
+    (domain.tpp:590-594 calls gs on every rank); a mismatch would hang this test."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_island_worker, args=(3, _free_port(), str(tmp_path / "islands"), 3), nprocs=3, join=True)
+
+
 def test_single_rank_cpu_shim_equals_oracle(cpu_host_lib):
     """The shim-backed host layer reproduces the oracle's C1 golden histories
     bit for bit (same kernels, same reduction tree): a check of the host
