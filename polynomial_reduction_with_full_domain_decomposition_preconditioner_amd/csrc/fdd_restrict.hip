@@ -161,6 +161,93 @@ __global__ __launch_bounds__(kBlock) void restriction_fused_kernel(double *__res
     }
 }
 
+// Fine elements of at most 512 points (n_f <= 8: every level pair below degree 8, e.g. 7 -> 1 of config C2): one
+// WAVEFRONT per element, four elements per workgroup in flight, no workgroup barrier inside the loop (the LDS executes
+// a wave's instructions in order), the element's 8 loads per lane issued together with non-temporal loads.  Same
+// sums in the same order as restriction_1/2/3.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NF, int NC> // compile-time sizes (index arithmetic by constants, unrolled sums); 0, 0: sizes from the arguments
+__global__ __launch_bounds__(kBlock) void restriction_wave_kernel(double *__restrict__ u_c, const double *__restrict__ J_cf, const double *__restrict__ u_f, int num_elements, int n_f_arg, int n_c_arg)
+{
+    const int n_f = NF > 0 ? NF : n_f_arg;
+    const int n_c = NC > 0 ? NC : n_c_arg;
+    constexpr int kWaves = kBlock / FDD_WAVE;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int nf2 = n_f * n_f;
+    const int nf3 = nf2 * n_f;
+    const int nc2 = n_c * n_c;
+    const int nc3 = nc2 * n_c;
+    const int s1 = n_c * nf2; // after x
+    const int s2 = nc2 * n_f; // after y
+    const int wave = threadIdx.x / FDD_WAVE, lane = threadIdx.x % FDD_WAVE;
+    double *sJ = smem;                                   // n_f * n_c
+    double *sA = sJ + n_f * n_c + wave * (nf3 + s1);     // this wave's u, later the y-contracted tensor
+    double *sB = sA + nf3;                               // this wave's x-contracted tensor
+
+    for (int t = threadIdx.x; t < n_f * n_c; t += kBlock) sJ[t] = J_cf[t];
+    __syncthreads();
+
+    for (int e = blockIdx.x * kWaves + wave; e < num_elements; e += gridDim.x * kWaves)
+    {
+        const double *ue = u_f + (size_t)e * nf3;
+        double r[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+        {
+            const int t = lane + q * FDD_WAVE;
+            r[q] = __builtin_nontemporal_load(ue + (t < nf3 ? t : 0)); // slots past the element re-read its first point
+        }
+        wave_lds_sync(); // the previous element's readers of sA are done
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+        {
+            const int t = lane + q * FDD_WAVE;
+            if (t < nf3) sA[t] = r[q];
+        }
+        wave_lds_sync();
+
+        for (int v = lane; v < s1; v += FDD_WAVE) // restriction_1: (l, j, k) -> (i, j, k), i < n_c
+        {
+            const int i = v % n_c;
+            const int j = (v / n_c) % n_f;
+            const int k = v / (n_c * n_f);
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < n_f; l++) s += sJ[i + l * n_c] * sA[l + j * n_f + k * nf2];
+            sB[i + j * n_c + k * (n_c * n_f)] = s;
+        }
+        wave_lds_sync();
+
+        for (int v = lane; v < s2; v += FDD_WAVE) // restriction_2: (i, l, k) -> (i, j, k), j < n_c
+        {
+            const int i = v % n_c;
+            const int j = (v / n_c) % n_c;
+            const int k = v / nc2;
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < n_f; l++) s += sJ[j + l * n_c] * sB[i + l * n_c + k * (n_c * n_f)];
+            sA[i + j * n_c + k * nc2] = s;
+        }
+        wave_lds_sync();
+
+        for (int v = lane; v < nc3; v += FDD_WAVE) // restriction_3: (i, j, l) -> (i, j, k), k < n_c
+        {
+            const int i = v % n_c;
+            const int j = (v / n_c) % n_c;
+            const int k = v / nc2;
+            double s = 0.0;
+            for (int l = 0; l < n_f; l++) s += sJ[k + l * n_c] * sA[i + j * n_c + l * nc2];
+            u_c[(size_t)e * nc3 + v] = s;
+        }
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -209,6 +296,37 @@ int fdd_sub_restriction(double *u_c, const double *J_cf, const double *u_f, int 
     FDD_REQUIRE(num_elements >= 0 && n_f >= 1 && n_c >= 1 && n_c <= n_f && n_f <= 16);
     if (num_elements == 0) return 0;
     FDD_REQUIRE(u_c != nullptr && J_cf != nullptr && u_f != nullptr);
+    static const int wave_form = fdd_env_int("FDD_TUNE_RESTRICTION_WAVE", 1);
+    if (n_f <= 8 && wave_form)
+    {
+        constexpr int kWaves = kBlock / FDD_WAVE;
+        const size_t lds_w = sizeof(double) * ((size_t)n_f * n_c + (size_t)kWaves * ((size_t)n_f * n_f * n_f + (size_t)n_c * n_f * n_f));
+        const int groups = (num_elements + kWaves - 1) / kWaves;
+        const int grid_w = groups < 16 * FDD_CU_COUNT ? groups : 16 * FDD_CU_COUNT;
+#define FDD_RESTRICT_CASE(NF_, NC_) \
+    case NF_ * 16 + NC_: hipLaunchKernelGGL((restriction_wave_kernel<NF_, NC_>), dim3(grid_w), dim3(kBlock), lds_w, fdd_stream(stream), u_c, J_cf, u_f, num_elements, n_f, n_c); break;
+        switch (n_f * 16 + n_c)
+        {
+            // the level pairs of the reference's degree lists N, N-r, ..., 1 below degree 8
+            FDD_RESTRICT_CASE(8, 2)
+            FDD_RESTRICT_CASE(8, 6)
+            FDD_RESTRICT_CASE(8, 5)
+            FDD_RESTRICT_CASE(8, 4)
+            FDD_RESTRICT_CASE(8, 7)
+            FDD_RESTRICT_CASE(7, 2)
+            FDD_RESTRICT_CASE(7, 5)
+            FDD_RESTRICT_CASE(6, 2)
+            FDD_RESTRICT_CASE(6, 4)
+            FDD_RESTRICT_CASE(5, 2)
+            FDD_RESTRICT_CASE(5, 3)
+            FDD_RESTRICT_CASE(4, 2)
+            FDD_RESTRICT_CASE(3, 2)
+        default: hipLaunchKernelGGL((restriction_wave_kernel<0, 0>), dim3(grid_w), dim3(kBlock), lds_w, fdd_stream(stream), u_c, J_cf, u_f, num_elements, n_f, n_c);
+        }
+#undef FDD_RESTRICT_CASE
+        FDD_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = sizeof(double) * ((size_t)n_f * n_c + (size_t)n_f * n_f * n_f + (size_t)n_c * n_f * n_f);
     const int grid = num_elements < 8 * FDD_CU_COUNT ? num_elements : 8 * FDD_CU_COUNT;
     if (lds > 48 * 1024)

@@ -669,7 +669,7 @@ def test_sub_stiffness_mixed_degree(gpu):
 
 
 # ---------------------------------------------------------- restriction
-@pytest.mark.parametrize("Nf,Nc", [(7, 1), (7, 5), (5, 3), (3, 1), (15, 9), (15, 1), (2, 1)])
+@pytest.mark.parametrize("Nf,Nc", [(7, 1), (7, 5), (7, 4), (6, 3), (5, 3), (3, 1), (15, 9), (15, 1), (2, 1)])
 def test_restriction(gpu, Nf, Nc):
     L = S.oracle()
     E = 53

@@ -186,6 +186,20 @@ def main():
         report(f"stiffness.two_launch_2d N={N} (72 B/pt)", 72 * P, timeit(two_2d, iters=5), results)
         del G
 
+    if want("restriction"):
+        # the degree tree of tree_operator (subdomain.tpp:4593-4607): degree N elements restricted to degree 1 and N-2
+        from_nodes = np.asarray(gll(N)[0])
+        for Nc in (1, max(N - 2, 1)):
+            to_nodes = np.asarray(gll(Nc)[0])
+            # J_cf[i + l*n_c]: value at fine node l of the coarse Lagrange polynomial i (tests/support.py:J_cf)
+            J = np.zeros((N + 1, Nc + 1))
+            for i in range(Nc + 1):
+                for l in range(N + 1):
+                    J[l, i] = np.prod([(from_nodes[l] - to_nodes[m]) / (to_nodes[i] - to_nodes[m]) for m in range(Nc + 1) if m != i])
+            Jd = torch.tensor(J.reshape(-1), dtype=torch.float64, device=dev)
+            uc = torch.empty(E**3 * (Nc + 1) ** 3, dtype=torch.float64, device=dev)
+            report(f"restriction.fused N={N}->{Nc}", 8 * (P + uc.numel()), timeit(lambda: k("fdd_sub_restriction", uc, Jd, a, E**3, N + 1, Nc + 1)), results)
+
     if want("csr"):
         (qp, qc, qv), (tp, tc, tv), Pq, nodes = box_Q(E, N, dev)
         x_nodes = torch.rand(nodes, dtype=torch.float64, device=dev)
