@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-reference-default", action="store_true", help="skip the `reference_default` object (V-cycle on: hierarchy build + solves to tolerance)")
     ap.add_argument("--no-time-to-tolerance", action="store_true", help="skip the full solves to 1e-7")
     ap.add_argument("--no-stencil", action="store_true", help="skip the 27-point-stencil SpMV (3.05e8 non-zeros at the default size)")
+    ap.add_argument("--force-composite", action="store_true", help="N=1 diagnostic: run the one-rank problem through the composite code path (no rings, no superdomain) to see what that path costs on identical work")
     ap.add_argument("--block-local", action="store_true", help="N>1: every rank keeps its own elements only (block-Jacobi) instead of the full-domain-decomposition composite")
     ap.add_argument("--no-amg-fusion", action="store_true", help="with --amg: the smoother's element-wise kernels as separate launches (the reference's sequence) instead of SpMV epilogues")
     ap.add_argument("--amg-precision", type=int, choices=[64, 32], default=64, help="the reference's `Float` (config.hpp:19-20, AMG/config.hpp:4): the preconditioner (inner Krylov solve and V-cycle) in double (default) or float")
@@ -218,7 +219,7 @@ def main():
             if rank == 0:
                 print("bench.py: full-domain-decomposition composite unavailable (%s); continuing block-local" % composite_error, file=sys.stderr, flush=True)
     if world == 1 or args.no_precond or block_local:
-        prob = H.Problem.box(E, P, N, args.reduction, with_subdomain=not args.no_precond, block_local=block_local)
+        prob = H.Problem.box(E, P, N, args.reduction, with_subdomain=not args.no_precond, block_local=block_local, force_composite=args.force_composite and world == 1)
     _, f = prob.make_rhs(function_id=4, seed=1234 + rank)  # rand()/RAND_MAX u*, poisson.cpp:211
     t_setup = time.perf_counter() - t_setup
     sub = prob.sub_info() if not args.no_precond else None

@@ -175,6 +175,9 @@ def test_host_layer_multirank_gloo(cpu_host_lib, world, with_sub):
     (8, (8, 8, 8), 3, 2, (1, 1)),    # 2x2x2: the scaling run's topology
     (2, (16, 4, 4), 3, 1, (1, 2)),   # reduction 1 (levels 3, 2, 1), superdomain overlap 2
     (2, (16, 4, 4), 3, 2, (1, 1, "reference-shaped")),  # the same through the reference's launch sequence (point-space vectors, SpMV chain)
+    (2, (16, 4, 4), 3, 2, (2, 1)),   # two rings per polynomial level
+    (2, (16, 4, 4), 3, 2, (2, 2)),   # both overlaps 2
+    (3, (12, 4, 4), 3, 2, (1, 1)),   # a rank count that is not a power of two: the middle rank has two neighbours
 ])
 def test_full_domain_decomposition_composite_gloo(cpu_host_lib, world, E, N, red, overlaps):
     """The composite of SURVEY 8(f) next-1 from the host layer under a gloo group -- neighbour rings at reduced
