@@ -31,7 +31,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None, composite=False, overlaps=(1, 1), reference_shaped=False):
+def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None, composite=False, overlaps=(1, 1), reference_shaped=False, curved=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -50,10 +50,15 @@ def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None, composite=Fal
         lib.host().call("fddh_comm_selftest", 1000)  # all-reduce sum/max, all-gather, all-gatherv, grouped send/receive, barrier
 
         Pg = S.rank_grid(world)
+
+        def mesh_of(deg, r):
+            # curved: an isoparametric deformation with all six geometric factors non-zero (sampled per degree, as a Nek5000 export is)
+            return S.DeformedMesh(E, deg, 0.05, Pg, r) if curved else S.BoxMesh(E, deg, Pg, r)
+
         if mesh_dir:
             # the reference's per-rank input files (<dir>/lx1_<N+1>/<name>_<rank>.<N>.dat), one set per level degree
             for deg in (S.level_degrees(N, red) if with_sub else [N]):
-                S.write_mesh_files(mesh_dir, S.BoxMesh(E, deg, Pg, rank), proc_id=rank)
+                S.write_mesh_files(mesh_dir, mesh_of(deg, rank), proc_id=rank)
             dist.barrier()
             p = H.Problem.from_directory(mesh_dir, N, red, overlaps[0], overlaps[1], with_subdomain=with_sub, block_local=not composite)
         else:
@@ -68,7 +73,7 @@ def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None, composite=Fal
             p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
 
         # oracle: all ranks simulated in this process, from the numpy mesh statement
-        meshes = [S.BoxMesh(E, N, Pg, r) for r in range(world)]
+        meshes = [mesh_of(N, r) for r in range(world)]
         W = S.OracleWorld(meshes, N)
         mine = meshes[rank]
 
@@ -102,7 +107,7 @@ def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None, composite=Fal
         if with_sub and composite:
             # the full-domain-decomposition composite of every rank against the oracle's R-rank world
             # (oracle/fdd_oracle_composite.c): region, sizes, operators on composite vectors, the tree exchange
-            F = S.OracleFdd(E, N, red, Pg, overlaps[0], overlaps[1])
+            F = S.OracleFdd(E, N, red, Pg, overlaps[0], overlaps[1], meshes=[[mesh_of(d, r) for d in S.level_degrees(N, red)] for r in range(world)])
             si, oi = p.sub_info(), F.info[rank]
             assert si["is_composite"] == 1
             assert si["num_peers"] >= 1
@@ -187,6 +192,15 @@ def test_full_domain_decomposition_composite_gloo(cpu_host_lib, world, E, N, red
     import torch.multiprocessing as mp
 
     mp.spawn(_worker, args=(world, _free_port(), E, N, red, True, None, True, overlaps[:2], len(overlaps) > 2), nprocs=world, join=True)
+
+
+def test_composite_on_a_curved_mesh_from_files(cpu_host_lib, tmp_path):
+    """The composite on a deformed mesh read from the reference's per-rank files: ring elements bring their owners'
+    six geometric factors, the hanging rows interpolate in reference space, the superdomain operator is assembled from
+    deformed degree-1 elements."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker, args=(2, _free_port(), (8, 4, 4), 3, 2, True, str(tmp_path / "curved"), True, (1, 1), False, True), nprocs=2, join=True)
 
 
 def _amg_worker(rank, world, port, E, N, red):
