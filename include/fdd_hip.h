@@ -313,6 +313,10 @@ int fdd_dssum_gather(double *t, const int *Qt_ptr, const int *Qt_col, const doub
 int fdd_dssum_scatter(double *QQtu, const double *t, const int *Qt_ptr, const int *Qt_col, const double *point_mask, int node_start, int node_end, void *stream);  /* out = (Q t) .* mask on a node range */
 int fdd_fill_indexed(double *out, const int *idx, double value, int n, void *stream); /* out[idx[i]] = value (points without a dof) */
 int fdd_gather_indexed(double *out, const double *in, const int *index, const double *scale, int n, void *stream); /* out[i] = in[index[i]] * scale[i] (0 where index[i] < 0; scale may be NULL) */
+/* The same (no scale) from a vector whose head [0, split) lives in `lo` and whose tail lives in `hi` (indexed by the
+ * same, unshifted index): out[i] = (index[i] < split ? lo : hi)[index[i]].  Packs the ring data of tree_operator's
+ * pull (subdomain.tpp:4626) from the caller's level-0 vector and the restricted levels without copying the former. */
+int fdd_gather_indexed_split(double *out, const double *lo, const double *hi, int split, const int *index, int n, void *stream);
 /* The same three operations on the row blocks of Qt's SpMV plan (unit-value plans only): entries are
  * staged through LDS so that no global access depends on a row length.  mode 0 = gather + scatter,
  * 1 = gather only (t out), 2 = scatter only (t in); nodes [row_lo, row_hi).  Same bits as above. */

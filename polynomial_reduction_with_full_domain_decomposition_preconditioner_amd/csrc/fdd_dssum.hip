@@ -159,6 +159,21 @@ __global__ __launch_bounds__(kBlock) void fill_indexed_kernel(double *__restrict
     const int stride = gridDim.x * kBlock;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[idx[i]] = value;
 }
+// out[i] = (index[i] < split ? lo : hi)[index[i]], 0 where index[i] < 0: a gather from a vector whose head [0, split)
+// lives in another buffer than its tail (the degree tree's level 0 is the caller's vector, the lower levels a
+// work buffer: Subdomain::tree_exchange packs the peers' ring data from both)
+__global__ __launch_bounds__(kBlock) void gather_indexed_split_kernel(double *__restrict__ out, const double *__restrict__ lo, const double *__restrict__ hi, int split, const int *__restrict__ index, int n)
+{
+    const int stride = gridDim.x * kBlock;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const int s = index[i];
+        const int t = s < 0 ? 0 : s;
+        const double v = (t < split) ? lo[t] : hi[t];
+        out[i] = (s >= 0) ? v : 0.0;
+    }
+}
+
 // out[i] = in[index[i]] * scale[i], 0 where index[i] < 0: renumbering between two
 // assembled numberings (domain nodes <-> subdomain dofs) with the stitching weight folded in
 __global__ __launch_bounds__(kBlock) void gather_indexed_kernel(double *__restrict__ out, const double *__restrict__ in, const int *__restrict__ index, const double *__restrict__ scale, int n)
@@ -223,6 +238,16 @@ int fdd_gather_indexed(double *out, const double *in, const int *index, const do
     if (n == 0) return 0;
     FDD_REQUIRE(out != nullptr && in != nullptr && index != nullptr && out != in);
     hipLaunchKernelGGL(gather_indexed_kernel, dim3(fdd_stream_grid((n + 3) / 4, kBlock)), dim3(kBlock), 0, fdd_stream(stream), out, in, index, scale, n);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fdd_gather_indexed_split(double *out, const double *lo, const double *hi, int split, const int *index, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0 && split >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(out != nullptr && lo != nullptr && hi != nullptr && index != nullptr);
+    hipLaunchKernelGGL(gather_indexed_split_kernel, dim3(fdd_stream_grid(n, kBlock)), dim3(kBlock), 0, fdd_stream(stream), out, lo, hi, split, index, n);
     FDD_LAUNCH_CHECK();
     return 0;
 }

@@ -53,6 +53,7 @@ struct NoPreconditioner
     bool composite_dof_space() const { return false; }
     int own_dofs() const { return 0; }
     fdd::memory new_dof_vector() { return fdd::dev().malloc<double>(1); }
+    fdd::memory tree_points() { return fdd::dev().malloc<double>(1); }
     void gmres_composite_dofs(fdd::memory &, fdd::memory &, bool = true, bool = false) {}
 };
 
@@ -739,7 +740,7 @@ class Domain
         dof_of_node.copyFrom(d_of_n.data(), (size_t)num_local_nodes * sizeof(int));
         sub_f = fdd::dev().malloc<DType>(std::max(nd, 1));
         sub_u = subdomain.new_dof_vector(); // a composite keeps copies / hanging values behind its dofs
-        if (composite_precond and not rp.ptr()) rp = fdd::dev().malloc<DType>(std::max(num_local_points, 1));
+        if (composite_precond and not rp.ptr()) rp = subdomain.tree_points(); // lives in the Subdomain's tree vector: level 0 is read in place
         nodes_sub_dofs = nd;
     }
 

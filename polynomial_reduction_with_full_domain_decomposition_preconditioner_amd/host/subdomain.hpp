@@ -214,8 +214,10 @@ class Subdomain
     // subdomain.tpp:4566-4646
     void tree_operator(fdd::memory &Tu, fdd::memory &u)
     {
+        // Level 0 of the tree is the caller's vector (copy_from_domain_data, subdomain.tpp:4571).  The composite reads it
+        // where it lies (first restriction, ring packing, own part of the result); the other paths keep the copy.
         timer.start("subdomain.tree_construction.gpu_to_gpu");
-        FDD_CALL(fdd_sub_copy_f64_f64(work_dev[0].as<double>(), u.as<double>(), levels[0].num_points, fdd::dev().stream));
+        if (not is_composite) FDD_CALL(fdd_sub_copy_f64_f64(work_dev[0].as<double>(), u.as<double>(), levels[0].num_points, fdd::dev().stream));
         timer.stop("subdomain.tree_construction.gpu_to_gpu");
 
         timer.start("subdomain.tree_construction.subdomain");
@@ -226,7 +228,7 @@ class Subdomain
                 const int n_f = levels[l].poly_degree + 1;
                 const int n_c = levels[l + 1].poly_degree + 1;
                 fdd::memory &J = J_cf[std::pair<int, int>(levels[l + 1].poly_degree, levels[l].poly_degree)].second;
-                fdd::memory u_f = work_dev[0].slice(levels[l].offset, levels[l].num_points);
+                fdd::memory u_f = (l == 0 and is_composite) ? u.slice(0, levels[0].num_points) : work_dev[0].slice(levels[l].offset, levels[l].num_points);
                 fdd::memory u_c = work_dev[0].slice(levels[l + 1].offset, levels[l + 1].num_points);
 
                 if (dim == 3)
@@ -247,7 +249,7 @@ class Subdomain
 
         if (is_composite)
         {
-            tree_exchange(Tu);
+            tree_exchange(Tu, u);
             return;
         }
 
@@ -274,13 +276,15 @@ class Subdomain
     //                 whose regions overlap this one, unpack into the ring part of the head;
     //   coarse level  MPI_Allgatherv (:4620-4621)               ->  all-gather (fixed count per rank, Qt_coarse
     //                 addresses the padded layout), then Qt_coarse and Pt into the tail (:4639-4644).
-    void tree_exchange(fdd::memory &Tu)
+    void tree_exchange(fdd::memory &Tu, fdd::memory &u)
     {
         void *stream = fdd::dev().stream;
         timer.start("subdomain.tree_exchange.subdomain");
-        if (num_send_points > 0) FDD_CALL(fdd_gather_indexed(send_all.as<double>(), work_dev[0].as<double>(), send_index.template as<int>(), nullptr, num_send_points, stream));
+        // level 0 of the tree is `u` itself, the restricted levels are in work_dev[0] at their tree offsets
+        if (num_send_points > 0) FDD_CALL(fdd_gather_indexed_split(send_all.as<double>(), u.as<double>(), work_dev[0].as<double>(), levels[0].num_points, send_index.template as<int>(), num_send_points, stream));
         if (not exchange_ops.empty()) fdd::comm().exchange(exchange_ops.data(), (int)exchange_ops.size());
-        Tu.copyFrom(work_dev[0], (size_t)own_points * sizeof(DType)); // the rank's own elements: the level-0 slice (:4630)
+        // the rank's own elements: the level-0 slice (:4630); nothing to do when the caller keeps its vector in place (tree_points())
+        if (Tu.ptr() != u.ptr()) Tu.copyFrom(u, (size_t)own_points * sizeof(DType));
         if (num_ring_points > 0) FDD_CALL(fdd_gather_indexed(Tu.as<double>() + own_points, recv_all.as<double>(), unpack_index.template as<int>(), nullptr, num_ring_points, stream));
         timer.stop("subdomain.tree_exchange.subdomain");
 
@@ -866,6 +870,9 @@ class Subdomain
         gmres_dofs_device(ua_out, fa, print_history, use_relative);
     }
     fdd::memory new_dof_vector() { return fdd::dev().malloc<DType>(std::max(dof_alloc_size(), 1)); }
+    // where the outer solve keeps its point-space residual: the own-points head of the tree vector, so that
+    // tree_operator finds level 0 in place
+    fdd::memory tree_points() { return f.slice(0, own_points); }
 
   private:
 
