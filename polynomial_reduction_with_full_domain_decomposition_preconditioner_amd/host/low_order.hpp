@@ -421,6 +421,36 @@ struct Level
     std::vector<double> D, coefs;
 };
 
+// entries below drop * (largest magnitude of the row) removed, the others scaled so that the row keeps its sum
+inline HostCSR filter_rows(const HostCSR &P, double drop)
+{
+    HostCSR F;
+    F.rows = P.rows;
+    F.cols = P.cols;
+    F.ptr.assign(P.rows + 1, 0);
+    for (int i = 0; i < P.rows; i++)
+    {
+        double big = 0.0, sum = 0.0, kept = 0.0;
+        for (int p = P.ptr[i]; p < P.ptr[i + 1]; p++)
+        {
+            big = std::max(big, std::abs(P.val[p]));
+            sum += P.val[p];
+        }
+        const size_t first = F.col.size();
+        for (int p = P.ptr[i]; p < P.ptr[i + 1]; p++)
+            if (std::abs(P.val[p]) >= drop * big)
+            {
+                F.col.push_back(P.col[p]);
+                F.val.push_back(P.val[p]);
+                kept += P.val[p];
+            }
+        if (kept != 0.0 and sum != 0.0)
+            for (size_t q = first; q < F.val.size(); q++) F.val[q] *= sum / kept;
+        F.ptr[i + 1] = (int)F.col.size();
+    }
+    return F;
+}
+
 // greedy aggregation on the strength graph: returns the aggregate of every row and the number of aggregates
 inline int aggregate(const HostCSR &A, double theta, std::vector<int> &agg)
 {
@@ -590,6 +620,11 @@ inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = fal
                             if (S.col[p] == i) S.val[p] += 1.0;
                         }
                     P = multiply(S, T);
+                    // development option: drop the small entries of the smoothed interpolator row by row and rescale the
+                    // rest to the row's sum (sparser Galerkin operators); 0 = keep everything
+                    static const double p_drop = getenv("FDD_TUNE_AMG_P_DROP") ? atof(getenv("FDD_TUNE_AMG_P_DROP")) : 0.0;
+                    static const int p_drop_from = getenv("FDD_TUNE_AMG_P_DROP_FROM") ? atoi(getenv("FDD_TUNE_AMG_P_DROP_FROM")) : 0;
+                    if (p_drop > 0.0 and l >= p_drop_from) P = filter_rows(P, p_drop);
                 }
                 else
                     P = T;
