@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Host-side cost of building the full-domain-decomposition composite on BASELINE config C4's topology
 (64^3 elements over a 2x2x2 rank grid), without a GPU: eight gloo ranks drive the product's host layer over
-the CPU stand-in of the kernel C-ABI (tests/cpu_shim, test infrastructure).  The degree is lowered (default
+the CPU stand-in of the kernel C-ABI (tests/cpu_shim, test infrastructure: it links the oracle,
+which is why this script lives under tests/).  The degree is lowered (default
 N = 3, levels 3/1) so that eight ranks fit this container's memory: the superdomain -- every element that is
 not in a rank's rings, at degree 1, graded by aggregation -- has exactly C4's size, and it is the part of
 the setup whose cost grows with the rank count.
 
-    python tools/c4_topology_setup_check.py [--E 64] [--N 3] [--reduction 2]
+    python tests/c4_topology_setup_check.py [--E 64] [--N 3] [--reduction 2]
 """
 import argparse
 import os
