@@ -165,3 +165,41 @@ def test_two_ranks_on_one_gpu_full_domain_decomposition_composite(gpu):
     import torch.multiprocessing as mp
 
     mp.spawn(_two_rank_worker, args=(2, _port(), (16, 4, 4), 3, 2, True), nprocs=2, join=True)
+
+
+def _full_size_worker(rank, world, port):
+    """Config C4's per-rank size (32^3 elements of degree 7 per rank) with two ranks sharing cuda:0: the composite with
+    the reference's default inner preconditioner (AMG V-cycle on the composite low-order operator).  No oracle run at
+    this size: the manufactured solution comes back, in a handful of outer iterations."""
+    import sys
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+
+    import support as S
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H.init(0, use_torch_stream=True)
+        H.set_print(False)
+        H.comm_torch_callbacks(on_gpu=True, staged=True)
+        p = H.Problem.box((64, 32, 32), (2, 1, 1), 7, 6, True)  # defaults: composite region, use_preconditioner = true
+        si = p.sub_info()
+        assert si["is_composite"] == 1 and si["num_peers"] == 1
+        assert si["num_elems"] == 32768 + 2 * 1024 and si["own_points"] == 32768 * 512  # own elements + a degree-7 and a degree-1 ring
+        assert si["interface_dofs"] == 31 * 31 and len(p.sub_composite_levels()) >= 3  # the far superdomain is graded
+        u_star, f = p.make_rhs_from(S.seeded_uniform(p.n, 1234 + rank))
+        x, its, hist = p.solve(f, "fcg")
+        assert 0 < its <= 6 and hist[-1] <= 1e-7 * hist[0] * 1.0001, (its, hist[-1] / hist[0])
+        assert np.abs(x - u_star).max() <= 1e-3 * np.abs(u_star).max()
+        p.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_full_size_composite_with_the_reference_default_preconditioner(gpu):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_full_size_worker, args=(2, _port()), nprocs=2, join=True)
