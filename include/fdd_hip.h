@@ -317,6 +317,10 @@ int fdd_gather_indexed(double *out, const double *in, const int *index, const do
  * same, unshifted index): out[i] = (index[i] < split ? lo : hi)[index[i]].  Packs the ring data of tree_operator's
  * pull (subdomain.tpp:4626) from the caller's level-0 vector and the restricted levels without copying the former. */
 int fdd_gather_indexed_split(double *out, const double *lo, const double *hi, int split, const int *index, int n, void *stream);
+/* y[index[i]] += t[i], distinct indices: the result of a transposed SpMV whose non-empty rows are few, added into the
+ * full vector (the hanging-point rows S^T of the composite region, subdomain.tpp:1522-1578 transposed). */
+int fdd_scatter_add_indexed(double *y, const int *index, const double *t, int n, void *stream);
+int fdd_scatter_add_indexed_f32(float *y, const int *index, const float *t, int n, void *stream);
 /* The same three operations on the row blocks of Qt's SpMV plan (unit-value plans only): entries are
  * staged through LDS so that no global access depends on a row length.  mode 0 = gather + scatter,
  * 1 = gather only (t out), 2 = scatter only (t in); nodes [row_lo, row_hi).  Same bits as above. */

@@ -159,6 +159,19 @@ __global__ __launch_bounds__(kBlock) void fill_indexed_kernel(double *__restrict
     const int stride = gridDim.x * kBlock;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[idx[i]] = value;
 }
+// y[index[i]] += t[i] (distinct indices): the transpose of a matrix with few non-empty rows applied through its
+// compressed rows (the hanging-point rows S^T of the composite: a few thousand of 11 million dofs)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scatter_add_indexed_kernel(T *__restrict__ y, const int *__restrict__ index, const T *__restrict__ t, int n)
+{
+    const int stride = gridDim.x * kBlock;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+    {
+        const int r = index[i];
+        y[r] = y[r] + t[i];
+    }
+}
+
 // out[i] = (index[i] < split ? lo : hi)[index[i]], 0 where index[i] < 0: a gather from a vector whose head [0, split)
 // lives in another buffer than its tail (the degree tree's level 0 is the caller's vector, the lower levels a
 // work buffer: Subdomain::tree_exchange packs the peers' ring data from both)
@@ -248,6 +261,26 @@ int fdd_gather_indexed_split(double *out, const double *lo, const double *hi, in
     if (n == 0) return 0;
     FDD_REQUIRE(out != nullptr && lo != nullptr && hi != nullptr && index != nullptr);
     hipLaunchKernelGGL(gather_indexed_split_kernel, dim3(fdd_stream_grid(n, kBlock)), dim3(kBlock), 0, fdd_stream(stream), out, lo, hi, split, index, n);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fdd_scatter_add_indexed(double *y, const int *index, const double *t, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(y != nullptr && index != nullptr && t != nullptr);
+    hipLaunchKernelGGL(scatter_add_indexed_kernel<double>, dim3(fdd_stream_grid(n, kBlock)), dim3(kBlock), 0, fdd_stream(stream), y, index, t, n);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fdd_scatter_add_indexed_f32(float *y, const int *index, const float *t, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(y != nullptr && index != nullptr && t != nullptr);
+    hipLaunchKernelGGL(scatter_add_indexed_kernel<float>, dim3(fdd_stream_grid(n, kBlock)), dim3(kBlock), 0, fdd_stream(stream), y, index, t, n);
     FDD_LAUNCH_CHECK();
     return 0;
 }

@@ -166,7 +166,8 @@ class Subdomain
     bool comp_dofs_ready = false;
     int n_sup_copies = 0, n_slaves = 0, slave_base = 0, W_len = 0;
     fdd::memory copy_src;                      // int[n_sup_copies]: the subdomain dof every superdomain-extended dof copies
-    CSR_Matrix<DType> S_slave, St_slave;       // hanging points: their J_cf rows over the subdomain dofs, and the transpose
+    CSR_Matrix<DType> S_slave, St_slave;       // hanging points: their J_cf rows over the subdomain dofs, and the transpose's NON-EMPTY rows
+    fdd::memory st_rows, st_tmp;               //   (a few thousand of millions of dofs): the dof of each such row, and its product
     CSR_Matrix<DType> G_unit;                  // boolean gather: rows = subdomain dofs then hanging points, columns = region points
     CSR_Matrix<DType> A_sup_reg;               // rows of the superdomain operator that belong to its regular dofs
     fdd::memory slave_vals;                    // gathered values of the hanging points
@@ -488,7 +489,32 @@ class Subdomain
             if (n_slaves > 0)
             {
                 S_slave.assemble_from_csr(n_slaves, nse, sp.data(), sc.data(), sv.data());
-                S_slave.transpose(St_slave);
+                // S^T by rows, entries in hanging-point order, empty rows left out
+                std::vector<int> count(nse, 0);
+                for (int c2 : sc) count[c2]++;
+                std::vector<int> rows_of, slot(nse, -1);
+                for (int d = 0; d < nse; d++)
+                    if (count[d] > 0)
+                    {
+                        slot[d] = (int)rows_of.size();
+                        rows_of.push_back(d);
+                    }
+                const int m = (int)rows_of.size();
+                std::vector<int> tp(m + 1, 0);
+                for (int r = 0; r < m; r++) tp[r + 1] = tp[r] + count[rows_of[r]];
+                std::vector<int> tc(sc.size()), fill(tp.begin(), tp.end() - 1);
+                std::vector<DType> tv(sc.size());
+                for (int h = 0; h < n_slaves; h++)
+                    for (int k = sp[h]; k < sp[h + 1]; k++)
+                    {
+                        const int at = fill[slot[sc[k]]]++;
+                        tc[at] = h;
+                        tv[at] = sv[k];
+                    }
+                St_slave.assemble_from_csr(m, n_slaves, tp.data(), tc.data(), tv.data());
+                st_rows = fdd::dev().malloc<int>(std::max(m, 1));
+                st_rows.copyFrom(rows_of.data(), (size_t)m * sizeof(int));
+                st_tmp = fdd::dev().malloc<DType>(std::max(m, 1));
             }
             slave_vals = fdd::dev().malloc<DType>(std::max(n_slaves, 1));
         }
@@ -552,7 +578,8 @@ class Subdomain
         if (n_slaves > 0)
         {
             G_unit.gather_scatter(nullptr, slave_vals.as<double>() - nse, q_k.as<double>(), nullptr, nullptr, nse, nse + n_slaves, 1);
-            St_slave.matvec(qa_out, slave_vals, 1.0, 1.0);
+            St_slave.multiply(st_tmp, slave_vals);
+            FDD_CALL(fdd_scatter_add_indexed(qa_out.as<double>(), st_rows.template as<int>(), st_tmp.as<double>(), St_slave.num_rows, stream));
         }
         if (n_reg > 0)
         {
@@ -570,7 +597,8 @@ class Subdomain
         if (n_slaves > 0)
         {
             G_unit.gather_scatter(nullptr, slave_vals.as<double>() - nse, Tr.as<double>(), nullptr, nullptr, nse, nse + n_slaves, 1);
-            St_slave.matvec(fa_out, slave_vals, 1.0, 1.0);
+            St_slave.multiply(st_tmp, slave_vals);
+            FDD_CALL(fdd_scatter_add_indexed(fa_out.as<double>(), st_rows.template as<int>(), st_tmp.as<double>(), St_slave.num_rows, fdd::dev().stream));
         }
         if (n_reg > 0)
         {
@@ -608,7 +636,7 @@ class Subdomain
         fdd::memory S_val, St_val, Asup_val;
         fdd_csr_plan *S_plan = nullptr, *St_plan = nullptr, *Asup_plan = nullptr;
         std::vector<fdd::memory> VA, ZA;
-        fdd::memory qa, ua, fa, q_pts, slaves;
+        fdd::memory qa, ua, fa, q_pts, slaves, st_tmp;
     } sp;
 
     static fdd::memory to_float(const std::vector<double> &v)
@@ -653,6 +681,7 @@ class Subdomain
         sp.fa = fdd::dev().malloc<float>(na);
         sp.q_pts = fdd::dev().malloc<float>(std::max(subdomain_operator.num_points, 1));
         sp.slaves = fdd::dev().malloc<float>(std::max(n_slaves, 1));
+        sp.st_tmp = fdd::dev().malloc<float>(std::max(St_slave.num_rows, 1));
         sp.ready = true;
     }
 
@@ -693,7 +722,8 @@ class Subdomain
         {
             float *sl = sp.slaves.template as<float>();
             FDD_CALL(fdd_gather_rows_f32(sl - nse, G_unit.ptr.template as<int>(), G_unit.col.template as<int>(), q, nse, nse + n_slaves, stream));
-            matvec32(sp.St_plan, St_slave, sp.St_val, y, y, sl, 1.0f, 1.0f);
+            matvec32(sp.St_plan, St_slave, sp.St_val, sp.st_tmp.template as<float>(), nullptr, sl, 1.0f, 0.0f);
+            FDD_CALL(fdd_scatter_add_indexed_f32(y, st_rows.template as<int>(), sp.st_tmp.template as<float>(), St_slave.num_rows, stream));
         }
         if (n_reg > 0)
         {

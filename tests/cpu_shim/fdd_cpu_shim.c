@@ -338,6 +338,8 @@ int fdd_dssum_fused(double *out, double *t, const int *p, const int *c, const do
 int fdd_dssum_gather(double *t, const int *p, const int *c, const double *u, const double *w, int n0, int n1, void *s) { (void)s; gather_range(t, p, c, u, w, n0, n1); return 0; }
 int fdd_dssum_scatter(double *out, const double *t, const int *p, const int *c, const double *m, int n0, int n1, void *s) { (void)s; scatter_range(out, t, p, c, m, n0, n1); return 0; }
 int fdd_fill_indexed(double *out, const int *idx, double v, int n, void *s) { (void)s; for (int i = 0; i < n; i++) out[idx[i]] = v; return 0; }
+int fdd_scatter_add_indexed(double *y, const int *index, const double *t, int n, void *s) { (void)s; for (int i = 0; i < n; i++) y[index[i]] = y[index[i]] + t[i]; return 0; }
+int fdd_scatter_add_indexed_f32(float *y, const int *index, const float *t, int n, void *s) { (void)s; for (int i = 0; i < n; i++) y[index[i]] = y[index[i]] + t[i]; return 0; }
 int fdd_gather_indexed_split(double *out, const double *lo, const double *hi, int split, const int *index, int n, void *s) { (void)s; for (int i = 0; i < n; i++) out[i] = index[i] < 0 ? 0.0 : (index[i] < split ? lo[index[i]] : hi[index[i]]); return 0; }
 int fdd_gather_indexed(double *out, const double *in, const int *index, const double *scale, int n, void *s) { (void)s; for (int i = 0; i < n; i++) { double v = index[i] >= 0 ? in[index[i]] : 0.0; if (scale) v *= scale[i]; out[i] = v; } return 0; }
 
