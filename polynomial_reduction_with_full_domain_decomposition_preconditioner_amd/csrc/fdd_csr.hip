@@ -623,10 +623,13 @@ __global__ __launch_bounds__(kBlock) void fold_partials_kernel(double *out, cons
 constexpr int kSellSlice = FDD_WAVE;
 
 template <typename T, typename Epi>
-__global__ __launch_bounds__(kBlock) void sell_kernel(T *__restrict__ y, const int *__restrict__ slice_off, const int *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x, Epi epi, int num_rows, int num_slices)
+__global__ __launch_bounds__(kBlock) void sell_kernel(T *__restrict__ y, const int *__restrict__ slice_off, const int *__restrict__ slice_order, const int *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x, Epi epi, int num_rows, int num_slices)
 {
-    const int slice = blockIdx.x * (kBlock / kSellSlice) + threadIdx.x / kSellSlice;
-    if (slice >= num_slices) return;
+    const int turn = blockIdx.x * (kBlock / kSellSlice) + threadIdx.x / kSellSlice;
+    if (turn >= num_slices) return;
+    // slices are visited widest first when their widths differ much (a few slices of long rows -- the interface and
+    // superdomain rows of a composite's low-order operator -- would otherwise finish long after everything else)
+    const int slice = slice_order ? slice_order[turn] : turn;
     const int lane = threadIdx.x & (kSellSlice - 1);
     const int row = slice * kSellSlice + lane;
     const int off = slice_off[slice];
@@ -697,6 +700,7 @@ struct fdd_csr_plan
     int *sell_off_dev = nullptr; // sell_slices + 1 entry offsets
     int *sell_col_dev = nullptr;
     void *sell_val_dev = nullptr;
+    int *sell_order_dev = nullptr; // slices by decreasing width (nullptr: widths are even, natural order)
     long long sell_entries = 0;
 };
 
@@ -705,7 +709,7 @@ static int sell_launch(const fdd_csr_plan *plan, T *y, const T *x, const Epi &ep
 {
     const int per_block = kBlock / kSellSlice;
     const dim3 grid((plan->sell_slices + per_block - 1) / per_block), block(kBlock);
-    hipLaunchKernelGGL((sell_kernel<T, Epi>), grid, block, 0, fdd_stream(stream), y, plan->sell_off_dev, plan->sell_col_dev, (const T *)plan->sell_val_dev, x, epi, plan->num_rows, plan->sell_slices);
+    hipLaunchKernelGGL((sell_kernel<T, Epi>), grid, block, 0, fdd_stream(stream), y, plan->sell_off_dev, plan->sell_order_dev, plan->sell_col_dev, (const T *)plan->sell_val_dev, x, epi, plan->num_rows, plan->sell_slices);
     FDD_LAUNCH_CHECK();
     return 0;
 }
@@ -888,6 +892,7 @@ int fdd_csr_plan_destroy(fdd_csr_plan *plan)
     if (plan->sell_off_dev) (void)hipFree(plan->sell_off_dev);
     if (plan->sell_col_dev) (void)hipFree(plan->sell_col_dev);
     if (plan->sell_val_dev) (void)hipFree(plan->sell_val_dev);
+    if (plan->sell_order_dev) (void)hipFree(plan->sell_order_dev);
     delete plan;
     return 0;
 }
@@ -904,26 +909,42 @@ int fdd_csr_plan_attach_sell(fdd_csr_plan *plan, const int *A_ptr_host, const in
     if (!fdd_env_int("FDD_TUNE_CSR_SELL", 1)) return 0;
     FDD_REQUIRE(A_ptr_host != nullptr && A_ptr != nullptr && A_col != nullptr && A_val != nullptr);
     const int n = plan->num_rows, slices = (n + kSellSlice - 1) / kSellSlice;
-    std::vector<int> off(slices + 1, 0);
+    std::vector<int> off(slices + 1, 0), width(slices, 0);
     long long total = 0;
+    int w_min = 1 << 30, w_max = 0;
     for (int s = 0; s < slices; s++)
     {
         int w = 0;
         for (int r = s * kSellSlice; r < n && r < (s + 1) * kSellSlice; r++) w = std::max(w, A_ptr_host[r + 1] - A_ptr_host[r]);
-        if (w > 64) return 0;
+        width[s] = w;
+        w_min = std::min(w_min, w);
+        w_max = std::max(w_max, w);
         total += (long long)w * kSellSlice;
         if (total > 2000000000LL) return 0;
         off[s + 1] = (int)total;
     }
     if ((double)total > max_padding * (double)plan->num_nnz) return 0;
+    // a few wide slices among narrow ones: visit the widest first (stable, so that equal widths keep their order and
+    // neighbouring waves stream neighbouring memory)
+    std::vector<int> order;
+    if (w_max > 64 || w_max > 4 * std::max(w_min, 1))
+    {
+        order.resize(slices);
+        for (int s = 0; s < slices; s++) order[s] = s;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return width[a] > width[b]; });
+    }
     const size_t vb = (size_t)plan->value_bytes;
     hipError_t err = hipMalloc((void **)&plan->sell_off_dev, off.size() * sizeof(int));
     if (err == hipSuccess) err = hipMalloc((void **)&plan->sell_col_dev, (size_t)total * sizeof(int));
     if (err == hipSuccess) err = hipMalloc(&plan->sell_val_dev, (size_t)total * vb);
     if (err == hipSuccess) err = hipMemcpy(plan->sell_off_dev, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (err == hipSuccess && !order.empty()) err = hipMalloc((void **)&plan->sell_order_dev, order.size() * sizeof(int));
+    if (err == hipSuccess && !order.empty()) err = hipMemcpy(plan->sell_order_dev, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice);
     if (err != hipSuccess)
     {
         fdd_set_error("fdd_csr_plan_attach_sell: %s", hipGetErrorString(err));
+        if (plan->sell_order_dev) (void)hipFree(plan->sell_order_dev);
+        plan->sell_order_dev = nullptr;
         if (plan->sell_off_dev) (void)hipFree(plan->sell_off_dev);
         if (plan->sell_col_dev) (void)hipFree(plan->sell_col_dev);
         if (plan->sell_val_dev) (void)hipFree(plan->sell_val_dev);
