@@ -317,6 +317,8 @@ def main():
         # the general CSR case, SURVEY 8(d)(ii): 27-point stencil on the C2 node grid (225^3 rows, 3.05e8 non-zeros);
         # every byte of the formula moves here (values, columns, row pointers, x, y)
         m = e * N + 1
+        if 27 * m**3 >= 2**31:  # int32 non-zero count (csr_matrix.tpp:132-134): larger node grids use SURVEY's 225^3
+            m = 225
         us, nbytes, nnz = H.spmv_stencil_time(m, 10)
         spmv["27-point stencil, %d^3 rows" % m] = {"frac_moved_of_hbm_peak": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "GBps_moved": nbytes / (us * 1e-6) / 1e9, "bytes_moved": nbytes, "avg_us": us, "nnz": nnz,
                                                   "kernel": "csr_block_kernel<EpiPlain>"}
