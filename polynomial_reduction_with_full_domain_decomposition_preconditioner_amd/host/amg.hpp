@@ -20,6 +20,7 @@
 #define FDD_AMG_HPP
 
 #include <utility>
+#include <chrono>
 #include <vector>
 
 #include "config.hpp"
@@ -264,6 +265,7 @@ class Hierarchy
     // CSR arrays on the host; P_* null on the coarsest level
     void add_level(int n, const int *A_ptr, const int *A_col, const double *A_val, const double *D_val, const double *coefs_, int n_coarse, const int *P_ptr, const int *P_col, const double *P_val)
     {
+        if (levels.capacity() < 32) levels.reserve(32); // a growing vector would copy every level built so far, host mirrors included
         levels.emplace_back();
         Level &L = levels.back();
         L.n = n;
