@@ -430,6 +430,8 @@ def test_single_precision_preconditioner(gpu):
     H.comm_single()
     for amg, (E, N, red) in ((0, ((4, 4, 4), 3, 2)), (1, ((4, 4, 4), 3, 2)), (1, ((6, 6, 6), 7, 6))):
         p = H.Problem.box(E, (1, 1, 1), N, red, True)
+        for lvl in range(p.info["num_levels"]):
+            p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])  # the oracle's tables, before anything is derived from them
         p.set_flag("sub_use_preconditioner", amg)
         if amg:
             p.amg_build(coarsest_size=40)
@@ -442,6 +444,13 @@ def test_single_precision_preconditioner(gpu):
         u32, its32, hist32 = p.solve(f, "fcg")
         assert np.abs(z32 - z64).max() <= 1e-5 * np.abs(z64).max()
         assert not np.array_equal(z32, z64)  # it really ran in float
+        if not amg:
+            # and directly against the CPU oracle's (double) inner solve: the float path is single-precision close to it
+            sd = S.OracleSubdomain(E, N, red)
+            z_or, _, _ = sd.solve(r, "gmres")
+            z32b, _ = p.precond_apply(r, "gmres")
+            assert np.abs(z32b - z_or).max() <= 1e-5 * np.abs(z_or).max()
+            sd.close()
         assert np.abs(h32 - h64).max() <= 1e-5 * h64[0]
         assert abs(its32 - its64) <= 1, (its32, its64)
         assert hist32[-1] <= 1e-7 * hist32[0] * 1.0001
