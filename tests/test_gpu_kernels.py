@@ -1065,6 +1065,31 @@ def test_gather_indexed(gpu):
     assert np.array_equal(host(out), base * sc)
 
 
+def test_gather_from_two_sources_and_scatter_add(gpu):
+    """The two small kernels of the composite's exchange and hanging-point stages: a gather whose source vector has its
+    head in one buffer and its tail in another (unshifted indices), and y[index[i]] += t[i] on distinct indices."""
+    n_lo, n_hi, n_out = 4000, 9000, 7001
+    lo, hi = rnd(n_lo, 170), rnd(n_hi, 171)  # hi is addressed by the same index as the whole vector: entries below n_lo unused
+    idx = np.random.default_rng(172).integers(-1, n_hi, n_out).astype(np.int32)
+    want = np.where(idx < 0, 0.0, np.where(idx < n_lo, lo[np.clip(idx, 0, n_lo - 1)], hi[np.maximum(idx, 0)]))
+    out = torch.full((n_out,), 9.0, dtype=torch.float64, device=gpu)
+    k("fdd_gather_indexed_split", out, dev(lo, gpu), dev(hi, gpu), n_lo, dev(idx, gpu), n_out)
+    assert np.array_equal(host(out), want)
+    y, t = rnd(n_hi, 173), rnd(3000, 174)
+    rows = np.random.default_rng(175).choice(n_hi, size=3000, replace=False).astype(np.int32)
+    ref = y.copy()
+    ref[rows] = ref[rows] + t
+    dy = dev(y, gpu)
+    k("fdd_scatter_add_indexed", dy, dev(rows, gpu), dev(t, gpu), 3000)
+    assert np.array_equal(host(dy), ref)
+    y32, t32 = y.astype(np.float32), t.astype(np.float32)
+    ref32 = y32.copy()
+    ref32[rows] = ref32[rows] + t32
+    dy32 = dev(y32, gpu)
+    k("fdd_scatter_add_indexed_f32", dy32, dev(rows, gpu), dev(t32, gpu), 3000)
+    assert np.array_equal(host(dy32), ref32)
+
+
 @pytest.mark.parametrize("shape", ["boolean", "stencil", "dense"])
 def test_csr_plan_matvec_axpby(gpu, shape):
     """y = alpha*A*x + beta*y on the plan (cusparseSpMV's role in the AMG V-cycle);
