@@ -356,7 +356,7 @@ def main():
     reference_default = None
     if not args.no_precond and not args.no_reference_default and not args.amg:
         reference_default = {"preconditioner": "fdd_gmres4 + low-order AMG V-cycle in every inner step (Subdomain::use_preconditioner = true, subdomain.hpp:231)"}
-        for precision in ((64, 32) if world == 1 else (64,)):
+        for precision in (64, 32):
             configure(True, precision)
             d, lr, _ = timed_steps(args.steps, min(args.warmup, 2), False)
             entry = {"ms_per_step": d / args.steps * 1e3, "value": nodes * args.steps / d, "last_residual_norm": lr}

@@ -194,6 +194,12 @@ def _full_size_worker(rank, world, port):
         x, its, hist = p.solve(f, "fcg")
         assert 0 < its <= 6 and hist[-1] <= 1e-7 * hist[0] * 1.0001, (its, hist[-1] / hist[0])
         assert np.abs(x - u_star).max() <= 1e-3 * np.abs(u_star).max()
+        # the same with the whole preconditioner in single precision (PTYPE = Float = float): float element kernels, hanging
+        # rows, superdomain rows and V-cycle
+        p.set_flag("preconditioner_precision", 32)
+        x32, its32, hist32 = p.solve(f, "fcg")
+        assert abs(its32 - its) <= 1 and hist32[-1] <= 1e-7 * hist32[0] * 1.0001, (its32, hist32[-1] / hist32[0])
+        assert np.abs(x32 - u_star).max() <= 1e-3 * np.abs(u_star).max()
         p.close()
     finally:
         dist.destroy_process_group()
