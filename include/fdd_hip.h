@@ -291,6 +291,8 @@ int fdd_vector_scaling_dev_f32(float *au, const double *scale_dev, const float *
 int fdd_vector_vector_addition_f32(float *uv, float alpha, const float *u, float beta, const float *v, int n, void *stream);
 int fdd_multi_lincomb_limited_dev_f32(float *q, int q_is_zero, const double *coeffs_dev, const float *const *v, const double *v_scale_dev, const double *last_dev, int m, int n, void *stream); /* q (+)= sum_{k <= *last} c_k (s_k v_k); last_dev NULL: all m */
 int fdd_gather_rows_f32(float *t, const int *ptr, const int *col, const float *u, int row_lo, int row_hi, void *stream); /* t[row] = sum of u over the row's entries (boolean gather) */
+/* fdd_gather_rows_f32 on the row blocks of a plan (LDS-staged, coalesced index stream): same sums in the same order */
+int fdd_csr_plan_gather_f32(const fdd_csr_plan *plan, float *t, const int *ptr, const int *col, const float *u, int row_lo, int row_hi, void *stream);
 int fdd_gather_indexed_f32(float *out, const float *in, const int *index, int n, void *stream);         /* out[i] = in[index[i]], 0 where index[i] < 0 */
 int fdd_gather_indexed_f32_f64(double *out, const float *in, const int *index, int n, void *stream);    /* the same, cast up (subdomain.okl:276-282 at the solve's exit) */
 int fdd_xmay_ratio_dev(double *out, const double *x, const double *num_dev, const double *den_dev, const double *y, int n, void *stream); /* out = x - (*num / *den) * y (domain.okl:191: r+ = r - alpha q with alpha on the device; out may be x) */

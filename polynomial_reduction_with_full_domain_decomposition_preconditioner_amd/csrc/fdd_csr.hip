@@ -350,6 +350,57 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(T *__restrict__ Au, c
     }
 }
 
+// The gather half (MODE 1, no weight) on float vectors: the single-precision preconditioner's Qt (subdomain.okl's kernels
+// instantiated with DType = float).  Same staging, the row sums in column order in IEEE single.
+template <int kBlockNnz>
+__global__ __launch_bounds__(kBlock) void gather_block_f32_kernel(float *__restrict__ t, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const float *__restrict__ u, const int *__restrict__ row_blocks, int block_first, int row_lo, int row_hi)
+{
+    __shared__ float x[kBlockNnz];
+    __shared__ int sp[kBlockNnz + 1];
+    constexpr int kIts = kBlockNnz / kBlock;
+    const int b = block_first + blockIdx.x;
+    const int r0 = row_blocks[b] > row_lo ? row_blocks[b] : row_lo;
+    const int r1 = row_blocks[b + 1] < row_hi ? row_blocks[b + 1] : row_hi;
+    if (r1 <= r0) return;
+    const int nrows = r1 - r0;
+    const int base = Qt_ptr[r0];
+    const int nnz = Qt_ptr[r1] - base;
+    int c[kIts], rp[kIts];
+#pragma unroll
+    for (int it = 0; it < kIts; it++)
+    {
+        const int k = threadIdx.x + it * kBlock;
+        c[it] = __builtin_nontemporal_load(Qt_col + ((k < nnz) ? base + k : ((nnz > 0) ? base : 0)));
+        rp[it] = Qt_ptr[r0 + ((k < nrows) ? k : 0) + 1];
+    }
+#pragma unroll
+    for (int it = 0; it < kIts; it++)
+    {
+        const int k = threadIdx.x + it * kBlock;
+        const float v = u[c[it]];
+        if (k < nnz) x[k] = v;
+    }
+    if (threadIdx.x == 0) sp[0] = 0;
+#pragma unroll
+    for (int it = 0; it < kIts; it++)
+    {
+        const int r = threadIdx.x + it * kBlock;
+        if (r < nrows) sp[r + 1] = rp[it] - base;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kIts; it++)
+    {
+        const int r = threadIdx.x + it * kBlock;
+        if (r < nrows)
+        {
+            float s = 0.0f;
+            for (int j = sp[r]; j < sp[r + 1]; j++) s += x[j];
+            t[r0 + r] = s;
+        }
+    }
+}
+
 template <typename Epi>
 int launch_rows(double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const Epi &epi, int row_start, int row_end, void *stream, bool unit_values = false)
 {
@@ -969,6 +1020,28 @@ int fdd_csr_plan_num_blocks(const fdd_csr_plan *plan, int *num_blocks)
 {
     FDD_REQUIRE(plan != nullptr && num_blocks != nullptr);
     *num_blocks = plan->num_blocks;
+    return 0;
+}
+
+// t[row] = sum of u over the row's entries, rows [row_lo, row_hi), float vectors, on the plan of a boolean gather matrix
+int fdd_csr_plan_gather_f32(const fdd_csr_plan *plan, float *t, const int *Qt_ptr, const int *Qt_col, const float *u, int row_lo, int row_hi, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr && row_lo >= 0 && row_hi >= row_lo && row_hi <= plan->num_rows);
+    if (row_hi == row_lo) return 0;
+    FDD_REQUIRE(t != nullptr && Qt_ptr != nullptr && Qt_col != nullptr && u != nullptr);
+    if (plan->kind == 0 || plan->has_long_rows) return fdd_gather_rows_f32(t, Qt_ptr, Qt_col, u, row_lo, row_hi, stream);
+    const std::vector<int> &rb = plan->row_blocks_host;
+    int first = (int)(std::upper_bound(rb.begin(), rb.end(), row_lo) - rb.begin()) - 1;
+    int last = (int)(std::lower_bound(rb.begin(), rb.end(), row_hi) - rb.begin()); // exclusive
+    if (first < 0) first = 0;
+    if (last > plan->num_blocks) last = plan->num_blocks;
+    if (last <= first) return 0;
+    const dim3 grid(last - first), block(kBlock);
+    if (plan->block_nnz == kBlockNnzSmall)
+        hipLaunchKernelGGL((gather_block_f32_kernel<kBlockNnzSmall>), grid, block, 0, fdd_stream(stream), t, Qt_ptr, Qt_col, u, plan->row_blocks_dev, first, row_lo, row_hi);
+    else
+        hipLaunchKernelGGL((gather_block_f32_kernel<kBlockNnzMax>), grid, block, 0, fdd_stream(stream), t, Qt_ptr, Qt_col, u, plan->row_blocks_dev, first, row_lo, row_hi);
+    FDD_LAUNCH_CHECK();
     return 0;
 }
 

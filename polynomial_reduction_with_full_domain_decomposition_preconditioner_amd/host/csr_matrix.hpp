@@ -300,6 +300,14 @@ class CSR_Matrix
         FDD_CALL(fdd_csr_plan_dssum(plan, out, t, ptr.as<int>(), col.as<int>(), u, node_weight, point_mask, row_lo, row_hi, mode, fdd::dev().stream));
     }
 
+    // t[row] = sum of u over the row's entries on float vectors (the gather of a boolean matrix in the single-precision preconditioner)
+    void gather_f32(float *t, const float *u, int row_lo, int row_hi)
+    {
+        if (row_hi <= row_lo or num_nnz == 0) return;
+        fdd::ProfileScope prof("gather_block_f32_kernel", 8.0 * (row_hi - row_lo) + 8.0 * num_nnz * ((double)(row_hi - row_lo) / std::max(num_rows, 1)));
+        FDD_CALL(fdd_csr_plan_gather_f32(plan, t, ptr.as<int>(), col.as<int>(), u, row_lo, row_hi, fdd::dev().stream));
+    }
+
     // out_dev[0] = sum_rows s*s*w with s = (this u)[row]*w[row]
     void gather_weighted_norm2(double *out_dev, double *ws, const double *u, const double *node_weight)
     {

@@ -713,15 +713,15 @@ class Subdomain
         if (not is_composite)
         {
             CSR_Matrix<DType> &Qt = subdomain_operator.Qt;
-            FDD_CALL(fdd_gather_rows_f32(y, Qt.ptr.template as<int>(), Qt.col.template as<int>(), q, 0, subdomain_operator.num_extended_dofs, stream));
+            Qt.gather_f32(y, q, 0, subdomain_operator.num_extended_dofs);
             return;
         }
         const int nse = subdomain_operator.num_extended_dofs, ns = subdomain_operator.num_dofs, nI = num_interface_dofs, n_reg = superdomain_operator.num_dofs - nI;
-        FDD_CALL(fdd_gather_rows_f32(y, G_unit.ptr.template as<int>(), G_unit.col.template as<int>(), q, 0, nse, stream));
+        G_unit.gather_f32(y, q, 0, nse);
         if (n_slaves > 0)
         {
             float *sl = sp.slaves.template as<float>();
-            FDD_CALL(fdd_gather_rows_f32(sl - nse, G_unit.ptr.template as<int>(), G_unit.col.template as<int>(), q, nse, nse + n_slaves, stream));
+            G_unit.gather_f32(sl - nse, q, nse, nse + n_slaves);
             matvec32(sp.St_plan, St_slave, sp.St_val, sp.st_tmp.template as<float>(), nullptr, sl, 1.0f, 0.0f);
             FDD_CALL(fdd_scatter_add_indexed_f32(y, st_rows.template as<int>(), sp.st_tmp.template as<float>(), St_slave.num_rows, stream));
         }

@@ -826,5 +826,7 @@ int fdd_gather_rows_f32(float *t, const int *ptr, const int *col, const float *u
     }
     return 0;
 }
+int fdd_gather_rows_f32(float *t, const int *ptr, const int *col, const float *u, int row_lo, int row_hi, void *s);
+int fdd_csr_plan_gather_f32(const fdd_csr_plan *plan, float *t, const int *ptr, const int *col, const float *u, int row_lo, int row_hi, void *s) { (void)plan; return fdd_gather_rows_f32(t, ptr, col, u, row_lo, row_hi, s); }
 int fdd_gather_indexed_f32(float *out, const float *in, const int *idx, int n, void *s) { (void)s; for (int i = 0; i < n; i++) out[i] = idx[i] < 0 ? 0.0f : in[idx[i]]; return 0; }
 int fdd_gather_indexed_f32_f64(double *out, const float *in, const int *idx, int n, void *s) { (void)s; for (int i = 0; i < n; i++) out[i] = idx[i] < 0 ? 0.0 : (double)in[idx[i]]; return 0; }
