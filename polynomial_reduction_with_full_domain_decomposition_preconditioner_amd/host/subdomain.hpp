@@ -154,7 +154,7 @@ class Subdomain
     bool is_composite = false;
     fdd::composite::Composite comp;            // host description; the big per-point arrays are released after the upload
     int own_points = 0;                        // points of the rank's own elements = head of every composite vector
-    fdd::memory ring_geom[NUM_GEOM_FACTS];     // geometric factors of the ring / extended elements (the own ones stay the Domain's)
+    fdd::memory ring_geom[NUM_GEOM_FACTS];     // geometric factors of the whole region when it has ring elements (own elements copied in: one list per degree)
     std::vector<DType> norm_weight_hst;
     // tree exchange (subdomain.tpp:4615-4644), all on device buffers
     fdd::memory send_index, send_all, recv_all, unpack_index; // pack: send_all[k] = tree[send_index[k]]; unpack: head ring part [i] = recv_all[unpack_index[i]]
@@ -1271,42 +1271,38 @@ class Subdomain
         rstdout("Composite region: %d own + %d ring + %d extended elements (%d points), %d + %d subdomain dofs, %d interface, superdomain %d of %d coarse dofs (+%d extended), %d unique dofs\n", levels[0].num_elements,
                 c.num_sub_elems - levels[0].num_elements, c.num_sub_ext_elems - c.num_sub_elems, NP, c.sub_num_dofs, nse - c.sub_num_dofs, c.num_interface_dofs, c.sup_num_dofs, c.num_coarse_dofs, nue - c.sup_num_dofs, c.num_dofs);
 
-        // geometry: own elements keep the Domain's arrays, the ring / extended elements get their own (subdomain.tpp:667-699)
+        // geometry (subdomain.tpp:667-699).  With ring elements the region gets its own factor arrays over ALL its
+        // points, own elements included (a copy of the Domain's: 48 B per own point), so that the degree-N ring is
+        // one element list with the own elements -- one launch per polynomial level; two lists would cost a second,
+        // latency-bound launch of ~1000 elements in every operator application.  Without rings (a one-rank composite)
+        // the Domain's arrays serve.
+        const bool own_copy = num_ring_points > 0;
         for (int g = 0; g < NUM_GEOM_FACTS; g++)
         {
-            subdomain_operator.geom_fact[g] = domain.geom_fact[g];
-            subdomain_operator.G_ptrs[g] = domain.geom_fact[g].template as<double>();
-            ring_geom[g] = fdd::dev().malloc<DType>(std::max(num_ring_points, 1));
-            if (num_ring_points > 0) ring_geom[g].copyFrom(c.G[g].data() + own_points, (size_t)num_ring_points * sizeof(DType));
+            if (own_copy)
+            {
+                ring_geom[g] = fdd::dev().malloc<DType>(std::max(NP, 1));
+                ring_geom[g].copyFrom(c.G[g].data(), (size_t)NP * sizeof(DType));
+                subdomain_operator.geom_fact[g] = ring_geom[g];
+            }
+            else
+                subdomain_operator.geom_fact[g] = domain.geom_fact[g];
+            subdomain_operator.G_ptrs[g] = subdomain_operator.geom_fact[g].template as<double>();
         }
 
         // level-sorted element lists (subdomain.tpp:1603-1630 sorted by level): the region is ordered by level, so
-        // every degree is one contiguous run; the level-0 run splits into the own elements and the degree-N ring
-        // because their geometric factors live in different arrays
+        // every degree is one contiguous run of elements
         subdomain_operator.level_lists.clear();
         for (int l = 0; l < num_levels; l++)
         {
-            int first = c.level_first_elem[l], count = c.level_num_elems[l];
+            const int first = c.level_first_elem[l], count = c.level_num_elems[l];
             if (count == 0) continue;
-            if (l == 0)
-            {
-                typename Stiffness_Operator<DType>::LevelList own;
-                own.level = 0;
-                own.poly_degree = poly_degree[0];
-                own.num_elements = levels[0].num_elements;
-                own.first_offset = 0;
-                for (int g = 0; g < NUM_GEOM_FACTS; g++) own.G[g] = subdomain_operator.G_ptrs[g];
-                if (own.num_elements > 0) subdomain_operator.level_lists.push_back(own);
-                first += own.num_elements;
-                count -= own.num_elements;
-                if (count == 0) continue;
-            }
             typename Stiffness_Operator<DType>::LevelList ll;
             ll.level = l;
             ll.poly_degree = poly_degree[l];
             ll.num_elements = count;
             ll.first_offset = c.sub[first].offset;
-            for (int g = 0; g < NUM_GEOM_FACTS; g++) ll.G[g] = ring_geom[g].template as<double>() + (ll.first_offset - own_points);
+            for (int g = 0; g < NUM_GEOM_FACTS; g++) ll.G[g] = subdomain_operator.G_ptrs[g] + ll.first_offset;
             subdomain_operator.level_lists.push_back(ll);
         }
 
