@@ -54,7 +54,7 @@ struct NoPreconditioner
     int own_dofs() const { return 0; }
     fdd::memory new_dof_vector() { return fdd::dev().malloc<double>(1); }
     fdd::memory tree_points() { return fdd::dev().malloc<double>(1); }
-    void gmres_composite_dofs(fdd::memory &, fdd::memory &, bool = true, bool = false) {}
+    void gmres_composite_dofs(fdd::memory &, fdd::memory &, bool = true, bool = false, const double * = nullptr) {}
 };
 
 template <typename DType>
@@ -120,6 +120,7 @@ class Domain
     int dof_shift = -1; // >= 0: subdomain dof d is node d + dof_shift (the numbering makes it so), no renumbering pass
     fdd::memory nu, nr, nr1, nq, nz, np, nt, sub_f, sub_u;
     fdd::memory fcg_u_pts;
+    bool composite_rhs_from_nodes = true; // composite preconditioner: own part of its right-hand side = the node residual (no second gather of the own points)
     fdd::memory rp;                 // composite preconditioner: the residual on the element-local points (the degree tree and the ring / superdomain exchange start from it)
     bool composite_precond = false; // the Subdomain is a full-domain-decomposition composite driven in dof space
 
@@ -841,7 +842,8 @@ class Domain
                 // full domain decomposition: the inner solve starts from the residual on the points (degree tree,
                 // ring pull, coarse all-gather: Subdomain::tree_operator) and returns the composite's dof vector,
                 // whose leading entries are this rank's nodes
-                subdomain.gmres_composite_dofs(sub_u, rp);
+                // (the own points' part of the right-hand side is the node residual itself when the dofs are a slice of the nodes)
+                subdomain.gmres_composite_dofs(sub_u, rp, true, false, (dof_shift >= 0 and composite_rhs_from_nodes) ? rn.as<double>() + dof_shift : nullptr);
             }
             else if (dof_shift >= 0)
             {

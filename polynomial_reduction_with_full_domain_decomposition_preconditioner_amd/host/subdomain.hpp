@@ -168,6 +168,8 @@ class Subdomain
     fdd::memory copy_src;                      // int[n_sup_copies]: the subdomain dof every superdomain-extended dof copies
     CSR_Matrix<DType> S_slave, St_slave;       // hanging points: their J_cf rows over the subdomain dofs, and the transpose's NON-EMPTY rows
     fdd::memory st_rows, st_tmp;               //   (a few thousand of millions of dofs): the dof of each such row, and its product
+    CSR_Matrix<DType> G_ring;                  // own dofs that ring points also feed: those points, by compressed rows (right-hand side from the node residual)
+    fdd::memory ring_rows, ring_tmp;
     CSR_Matrix<DType> G_unit;                  // boolean gather: rows = subdomain dofs then hanging points, columns = region points
     CSR_Matrix<DType> A_sup_reg;               // rows of the superdomain operator that belong to its regular dofs
     fdd::memory slave_vals;                    // gathered values of the hanging points
@@ -535,6 +537,29 @@ class Subdomain
             std::vector<DType> gv(gc.size(), 1.0);
             G_unit.assemble_from_csr(rows, NP, gp.data(), gc.data(), gv.data());
             G_unit.release_host();
+            // the rows of the rank's own dofs restricted to ring points, empty rows left out: with the own part of a
+            // right-hand side taken from the outer solve's assembled residual only these few sums are left to form
+            const int n_own = c.num_own_dofs;
+            std::vector<int> rows_of, rp2(1, 0), rc2;
+            for (int d = 0; d < n_own; d++)
+            {
+                const size_t before = rc2.size();
+                for (int k = gp[d]; k < gp[d + 1]; k++)
+                    if (gc[k] >= own_points) rc2.push_back(gc[k]);
+                if (rc2.size() > before)
+                {
+                    rows_of.push_back(d);
+                    rp2.push_back((int)rc2.size());
+                }
+            }
+            if (not rows_of.empty())
+            {
+                std::vector<DType> rv2(rc2.size(), 1.0);
+                G_ring.assemble_from_csr((int)rows_of.size(), NP, rp2.data(), rc2.data(), rv2.data());
+                ring_rows = fdd::dev().malloc<int>(rows_of.size());
+                ring_rows.copyFrom(rows_of.data(), rows_of.size() * sizeof(int));
+                ring_tmp = fdd::dev().malloc<DType>(rows_of.size());
+            }
         }
         {
             std::vector<int> src(std::max(n_sup_copies, 1), 0);
@@ -590,10 +615,24 @@ class Subdomain
     }
 
     // the right-hand side of the composite in dof space from the tree-exchanged composite vector T r (subdomain.tpp:4566-4646)
-    void composite_rhs_dofs(fdd::memory &fa_out, fdd::memory &Tr)
+    // own_assembled: the sums over the rank's OWN points of every own dof, already formed by the caller (the outer
+    // solve's node residual, which it keeps assembled): then only the ring points are gathered here
+    void composite_rhs_dofs(fdd::memory &fa_out, fdd::memory &Tr, const double *own_assembled = nullptr)
     {
         const int nse = subdomain_operator.num_extended_dofs, ns = subdomain_operator.num_dofs, nI = num_interface_dofs, n_reg = superdomain_operator.num_dofs - nI;
-        G_unit.gather_scatter(nullptr, fa_out.as<double>(), Tr.as<double>(), nullptr, nullptr, 0, nse, 1);
+        if (own_assembled)
+        {
+            const int n_own = comp.num_own_dofs;
+            FDD_CALL(fdd_memcpy_d2d(fa_out.ptr(), own_assembled, (size_t)n_own * sizeof(DType), fdd::dev().stream));
+            G_unit.gather_scatter(nullptr, fa_out.as<double>(), Tr.as<double>(), nullptr, nullptr, n_own, nse, 1);
+            if (G_ring.num_rows > 0)
+            {
+                G_ring.multiply(ring_tmp, Tr);
+                FDD_CALL(fdd_scatter_add_indexed(fa_out.as<double>(), ring_rows.template as<int>(), ring_tmp.as<double>(), G_ring.num_rows, fdd::dev().stream));
+            }
+        }
+        else
+            G_unit.gather_scatter(nullptr, fa_out.as<double>(), Tr.as<double>(), nullptr, nullptr, 0, nse, 1);
         if (n_slaves > 0)
         {
             G_unit.gather_scatter(nullptr, slave_vals.as<double>() - nse, Tr.as<double>(), nullptr, nullptr, nse, nse + n_slaves, 1);
@@ -892,11 +931,11 @@ class Subdomain
     // z~ = M^-1 r for the node-space outer solve: r is the outer residual on the rank's own points (the degree tree
     // and the ring / superdomain exchange start from it), the result the dof-space correction (its leading own_dofs()
     // entries follow the Domain's node order)
-    void gmres_composite_dofs(fdd::memory &ua_out, fdd::memory &r_pts, bool print_history = true, bool use_relative = false)
+    void gmres_composite_dofs(fdd::memory &ua_out, fdd::memory &r_pts, bool print_history = true, bool use_relative = false, const double *own_assembled = nullptr)
     {
         if (not fa.ptr()) fa = fdd::dev().malloc<DType>(std::max(dof_alloc_size(), 1));
         tree_operator(f, r_pts);
-        composite_rhs_dofs(fa, f);
+        composite_rhs_dofs(fa, f, own_assembled);
         gmres_dofs_device(ua_out, fa, print_history, use_relative);
     }
     fdd::memory new_dof_vector() { return fdd::dev().malloc<DType>(std::max(dof_alloc_size(), 1)); }
