@@ -902,6 +902,34 @@ class QuadMesh(BoxMesh):
         self.g = [np.ascontiguousarray((sc * M[..., a, b]).reshape(-1)) for a, b in ((0, 0), (1, 1), (0, 1))] + [zero, zero.copy(), zero.copy()]
 
 
+class QuadMeshRanks(QuadMesh):
+    """QuadMesh cut into P = (Px, Py) rank blocks (elements of a block x fastest), the 2-D counterpart of BoxMesh's
+    partition: global ids, multiplicities, mask and geometry are those of the global mesh."""
+
+    def __init__(self, E, N, P=(1, 1), rank=0, amplitude=0.0):
+        full = QuadMesh(E, N, amplitude)
+        Ex, Ey = E
+        Px, Py = P
+        assert Ex % Px == 0 and Ey % Py == 0
+        lx, ly = Ex // Px, Ey // Py
+        rx, ry = rank % Px, rank // Px
+        ex = rx * lx + np.arange(lx)
+        ey = ry * ly + np.arange(ly)
+        elems = (ey[:, None] * Ex + ex[None, :]).reshape(-1)
+        npts = full.num_elem_points
+        pts = (elems[:, None] * npts + np.arange(npts)[None, :]).reshape(-1)
+        self.E, self.N, self.P, self.rank = (Ex, Ey, 1), N, (Px, Py, 1), rank
+        self.local_E = (lx, ly, 1)
+        self.origin = (rx * lx, ry * ly, 0)
+        self.num_local_elements = lx * ly
+        self.num_elem_points = npts
+        self.num_local_points = lx * ly * npts
+        self.global_nodes = full.global_nodes
+        for name in ("glo_num", "node_degree", "p_mask", "x", "y", "z"):
+            setattr(self, name, np.ascontiguousarray(getattr(full, name)[pts]))
+        self.g = [np.ascontiguousarray(a[pts]) for a in full.g]
+
+
 def write_mesh_files(directory, mesh, proc_id=0):
     """The reference's per-rank input files (domain.tpp:45-224): lx1_<N+1>/{size,x,y,z,glo_num,node_degree,p_mask,g_1..g_6}_<rank>.<N>.dat"""
     N = mesh.N

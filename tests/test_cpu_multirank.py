@@ -53,6 +53,8 @@ def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None, composite=Fal
 
         def mesh_of(deg, r):
             # curved: an isoparametric deformation with all six geometric factors non-zero (sampled per degree, as a Nek5000 export is)
+            if curved == "quad":  # the reference's dim == 2 branches: a deformed quadrilateral mesh cut into rank strips
+                return S.QuadMeshRanks(E[:2], deg, Pg[:2], r, amplitude=0.04)
             return S.DeformedMesh(E, deg, 0.05, Pg, r) if curved else S.BoxMesh(E, deg, Pg, r)
 
         if mesh_dir:
@@ -201,6 +203,15 @@ def test_composite_on_a_curved_mesh_from_files(cpu_host_lib, tmp_path):
     import torch.multiprocessing as mp
 
     mp.spawn(_worker, args=(2, _free_port(), (8, 4, 4), 3, 2, True, str(tmp_path / "curved"), True, (1, 1), False, True), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("world,E", [(2, (16, 4, 1)), (4, (8, 8, 1))])
+def test_composite_in_two_dimensions_from_files(cpu_host_lib, tmp_path, world, E):
+    """The composite's `dim == 2` branches (quadrilaterals, hanging EDGES only, subdomain.tpp:1179-1585 with DIM 2):
+    rank strips / a 2x2 rank grid of a deformed quadrilateral mesh read from files, against the oracle."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker, args=(world, _free_port(), E, 3, 2, True, str(tmp_path / "quad"), True, (1, 1), False, "quad"), nprocs=world, join=True)
 
 
 def _amg_worker(rank, world, port, E, N, red):

@@ -209,3 +209,71 @@ def test_two_ranks_full_size_composite_with_the_reference_default_preconditioner
     import torch.multiprocessing as mp
 
     mp.spawn(_full_size_worker, args=(2, _port()), nprocs=2, join=True)
+
+
+def _two_rank_worker_2d(rank, world, port, mesh_dir):
+    """The composite's `dim == 2` branches on the HIP kernels: two rank strips of a deformed quadrilateral mesh read from
+    the reference's per-rank files (fused 2-D stiffness on mixed degrees, hanging edges, the exchange), against the oracle."""
+    import sys
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+
+    import support as S
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H.init(0, use_torch_stream=True)
+        H.set_print(False)
+        H.comm_torch_callbacks(on_gpu=True, staged=True)
+        E, N, red, Pg = (16, 4), 3, 2, (2, 1)
+        degs = S.level_degrees(N, red)
+        mesh_of = lambda deg, r: S.QuadMeshRanks(E, deg, Pg, r, amplitude=0.04)
+        for deg in degs:
+            S.write_mesh_files(mesh_dir, mesh_of(deg, rank), proc_id=rank)
+        dist.barrier()
+        p = H.Problem.from_directory(mesh_dir, N, red, 1, 1, with_subdomain=True)
+        p.set_flag("sub_use_preconditioner", 0)
+        for lvl in range(p.info["num_levels"]):
+            p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
+        meshes = [mesh_of(N, r) for r in range(world)]
+        W = S.OracleWorld(meshes, N)
+        F = S.OracleFdd(E + (1,), N, red, Pg + (1,), meshes=[[mesh_of(d, r) for d in degs] for r in range(world)])
+        si, oi = p.sub_info(), F.info[rank]
+        assert si["is_composite"] == 1 and si["num_values"] == oi["num_values"] and si["unique_dofs"] == oi["unique_dofs"]
+        ids, lv = p.sub_region()
+        assert np.array_equal(ids, F.region(rank)[0]) and len(set(lv.tolist())) > 1
+        us = [np.sin(3 * m.x + 1) * np.cos(2 * m.y) + m.y * m.x for m in meshes]
+        v = np.random.default_rng(5 + rank).standard_normal(si["num_values"])
+        for op in ("stiffness", "dssum"):
+            ref = getattr(F, op)(rank, v)
+            assert np.abs(p.sub_op(op, v) - ref).max() <= 1e-12 * np.abs(ref).max(), op
+        ref = F.tree(us)[rank]
+        assert np.abs(p.sub_op("tree", us[rank]) - ref).max() <= 1e-12 * np.abs(ref).max()
+        o_f = W.stiffness(W.dssum(us, True, True))
+        _, f = p.make_rhs_from(us[rank])
+        assert np.abs(f - o_f[rank]).max() <= 1e-13 * np.abs(o_f[rank]).max()
+
+        def pre(z, r):
+            out, _ = F.precondition(r, "gmres")
+            for k in range(world):
+                z[k][:] = out[k]
+
+        for method in ("fcg", "gmres"):
+            u, its, hist = p.solve(f, method)
+            ou, oits, ohist = W.solve(o_f, method, precond=pre)
+            assert its == oits, (method, its, oits)
+            assert np.abs(hist - ohist).max() <= 1e-8 * ohist[0]
+            assert np.abs(u - ou[rank]).max() <= 1e-8 * np.abs(ou[rank]).max()
+        p.close()
+        W.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_composite_in_two_dimensions(gpu, tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_two_rank_worker_2d, args=(2, _port(), str(tmp_path / "quad")), nprocs=2, join=True)
