@@ -414,6 +414,10 @@ def main():
         "reference_default": reference_default,
         "kernels": table,
     }
+    if world > 1:
+        # the solve path's collectives alone, with the solve's own sizes and buffers (max over ranks)
+        comm = prob.comm_time(20)
+        out["comm_us"] = {k: {"avg_us": max_over_ranks(v["avg_us"]), "bytes": v["bytes"]} for k, v in comm.items()}
     if composite_error:
         out["config"]["composite_unavailable"] = composite_error
     if composite:

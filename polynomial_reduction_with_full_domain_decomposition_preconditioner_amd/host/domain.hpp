@@ -54,6 +54,10 @@ struct NoPreconditioner
     int own_dofs() const { return 0; }
     fdd::memory new_dof_vector() { return fdd::dev().malloc<double>(1); }
     fdd::memory tree_points() { return fdd::dev().malloc<double>(1); }
+    void comm_probe_coarse() {}
+    void comm_probe_ring() {}
+    double comm_coarse_bytes() const { return 0.0; }
+    double comm_ring_bytes() const { return 0.0; }
     void gmres_composite_dofs(fdd::memory &, fdd::memory &, bool = true, bool = false, const double * = nullptr) {}
 };
 
@@ -294,6 +298,13 @@ class Domain
 
     int boundary_nodes_count() const { return num_bdary_nodes; }
     int interface_slots_count() const { return num_interface_slots; }
+    // one interface exchange of `vectors` (1 or 2) prefixes, as gs_add_boundary[_pair] issues it: the collective alone,
+    // on the exchange buffer's current contents (bench.py's communication timings)
+    void comm_probe_interface(int vectors)
+    {
+        if (fdd::comm().size == 1 or num_interface_slots == 0) return;
+        fdd::comm().allreduce_sum(interface_slots.as<double>(), (size_t)num_interface_slots * (vectors == 2 ? 2 : 1));
+    }
     CSR_Matrix<DType> &gather_matrix() { return Qt; }
     CSR_Matrix<DType> &scatter_matrix() { return Q; }
     fdd::memory &dirichlet_mask_memory() { return dirichlet_mask; }

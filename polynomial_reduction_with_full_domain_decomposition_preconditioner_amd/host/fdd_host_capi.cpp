@@ -14,6 +14,7 @@
 #include <string>
 #include <sys/stat.h>
 #include <unordered_map>
+#include <functional>
 #include <vector>
 
 #include "box_mesh.hpp"
@@ -1299,6 +1300,48 @@ int fddh_problem_spmv_time(fddh_problem *p, int which, int iterations, double *a
         y.free();
         *avg_us = 1.0e3 * ms / iterations;
         *algorithmic_bytes = A.algorithmic_bytes(false);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return fail("%s", e.what());
+    }
+}
+
+int fddh_problem_comm_time(fddh_problem *p, int iterations, double *avg_us, double *bytes)
+{
+    try
+    {
+        if (!p || !avg_us || !bytes || iterations < 1) return fail("bad argument");
+        for (int k = 0; k < 4; k++) avg_us[k] = bytes[k] = 0.0;
+        fdd::Comm &c = fdd::comm();
+        if (c.size == 1) return 0;
+        Domain<SType> &d = p->fine();
+        fdd::memory scal = fdd::dev().malloc<double>(4);
+        FDD_CALL(fdd_memset(scal.ptr(), 0, 4 * sizeof(double), fdd::dev().stream));
+        const auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        auto timed = [&](const std::function<void()> &op) {
+            op(); // warm-up (first use of a peer pair may set up a connection)
+            fdd::dev().finish();
+            c.barrier();
+            const double t0 = clock();
+            for (int i = 0; i < iterations; i++) op();
+            fdd::dev().finish();
+            return 1.0e6 * (clock() - t0) / iterations;
+        };
+        // every rank makes the same calls in the same order
+        avg_us[0] = timed([&] { c.allreduce_sum(scal.as<double>(), 3); });
+        bytes[0] = 3 * sizeof(double);
+        avg_us[1] = timed([&] { d.comm_probe_interface(2); });
+        bytes[1] = 2.0 * d.interface_slots_count() * sizeof(double);
+        if (p->subdomain)
+        {
+            avg_us[2] = timed([&] { p->subdomain->comm_probe_coarse(); });
+            bytes[2] = p->subdomain->comm_coarse_bytes();
+            avg_us[3] = timed([&] { p->subdomain->comm_probe_ring(); });
+            bytes[3] = p->subdomain->comm_ring_bytes();
+        }
+        scal.free();
         return 0;
     }
     catch (const std::exception &e)

@@ -939,6 +939,25 @@ class Subdomain
         gmres_dofs_device(ua_out, fa, print_history, use_relative);
     }
     fdd::memory new_dof_vector() { return fdd::dev().malloc<DType>(std::max(dof_alloc_size(), 1)); }
+    // the two exchanges of tree_operator alone, on their buffers' current contents (bench.py's communication timings)
+    void comm_probe_coarse()
+    {
+        if (not is_composite or superdomain_operator.num_extended_dofs == 0) return;
+        fdd::memory coarse = work_dev[0].slice(levels[num_levels - 1].offset, coarse_pad);
+        fdd::comm().allgather(coarse.ptr(), coarse_all.ptr(), (size_t)coarse_pad * sizeof(DType));
+    }
+    void comm_probe_ring()
+    {
+        if (not is_composite or exchange_ops.empty()) return;
+        fdd::comm().exchange(exchange_ops.data(), (int)exchange_ops.size());
+    }
+    double comm_coarse_bytes() const { return is_composite ? (double)coarse_pad * sizeof(DType) * fdd::comm().size : 0.0; }
+    double comm_ring_bytes() const
+    {
+        double b = 0.0;
+        for (const fdd::ExchangeOp &op : exchange_ops) b += (double)op.send_bytes;
+        return b;
+    }
     // where the outer solve keeps its point-space residual: the own-points head of the tree vector, so that
     // tree_operator finds level 0 in place
     fdd::memory tree_points() { return f.slice(0, own_points); }

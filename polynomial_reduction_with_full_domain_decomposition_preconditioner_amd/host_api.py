@@ -372,6 +372,14 @@ class Problem:
         _H().call("fddh_problem_precond_apply", self.h, 0 if method == "fcg" else 1, _dp(np.ascontiguousarray(r)), _dp(z), _dp(hist), 64, ctypes.byref(nh))
         return z, hist[: nh.value].copy()
 
+    def comm_time(self, iterations=20):
+        """the solve path's collectives alone (collective call): dict name -> (avg us, bytes)"""
+        us = (ctypes.c_double * 4)()
+        nbytes = (ctypes.c_double * 4)()
+        _H().call("fddh_problem_comm_time", self.h, int(iterations), us, nbytes)
+        names = ["allreduce_3_scalars", "interface_pair_allreduce", "coarse_allgather", "ring_exchange"]
+        return {n: {"avg_us": us[k], "bytes": nbytes[k]} for k, n in enumerate(names)}
+
     def sub_op(self, op, u):
         code = {"tree": 0, "stiffness": 1, "dssum": 2}[op]
         out = np.zeros(self.info["sub_num_values"])

@@ -135,6 +135,11 @@ def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None, composite=Fal
                 assert np.abs(z - oz[rank]).max() <= 1e-9 * np.abs(oz[rank]).max(), method
                 assert np.abs(hist - oh[rank]).max() <= 1e-9 * oh[rank][0], method
 
+            # the collectives of the solve path alone (what bench.py reports as comm_us): a collective call
+            ct = p.comm_time(2)
+            assert ct["ring_exchange"]["bytes"] > 0 and ct["coarse_allgather"]["bytes"] > 0 and ct["interface_pair_allreduce"]["bytes"] == 16 * p.info["num_interface_slots"]
+            assert all(v["avg_us"] > 0 for v in ct.values())
+
             def pre(z, r):
                 out, _ = F.precondition(r, "gmres")
                 for k in range(world):
