@@ -151,3 +151,30 @@ def test_c3_full_size_matrix_core_path(gpu):
         assert np.abs(x - u_star).max() <= 5e-3 * np.abs(u_star).max()
     finally:
         p.close()
+
+
+def test_fused_two_dimensional_stiffness_at_full_size(gpu):
+    """The fused 2-D kernel on 16.8 M points (262 144 quadrilaterals of degree 7, every workgroup walking four element
+    groups): constants are annihilated, the operator is linear and symmetric, element by element."""
+    import torch
+
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd.kernels import k
+
+    n, E = 8, 262144
+    P = E * n * n
+    gen = torch.Generator(device=gpu).manual_seed(7)
+    D = torch.tensor(np.ascontiguousarray(S.gll(7)[2]), dtype=torch.float64, device=gpu)
+    G = [torch.rand(P, dtype=torch.float64, device=gpu, generator=gen) + 0.5 for _ in range(2)] + [torch.rand(P, dtype=torch.float64, device=gpu, generator=gen) * 0.2 - 0.1]
+    G += [torch.zeros(1, dtype=torch.float64, device=gpu)] * 3  # not read in 2-D
+    u = torch.rand(P, dtype=torch.float64, device=gpu, generator=gen) - 0.5
+    v = torch.rand(P, dtype=torch.float64, device=gpu, generator=gen) - 0.5
+    Au, Av, Aw, Ac = (torch.empty(P, dtype=torch.float64, device=gpu) for _ in range(4))
+    k("fdd_stiffness_matrix_2d", Au, u, D, G, None, E, 7)
+    k("fdd_stiffness_matrix_2d", Av, v, D, G, None, E, 7)
+    k("fdd_stiffness_matrix_2d", Aw, u + 0.5 * v, D, G, None, E, 7)
+    k("fdd_stiffness_matrix_2d", Ac, torch.full((P,), 1.75, dtype=torch.float64, device=gpu), D, G, None, E, 7)
+    scale = float(Au.abs().max())
+    assert float(Ac.abs().max()) <= 1e-12 * scale
+    assert float((Aw - (Au + 0.5 * Av)).abs().max()) <= 1e-12 * scale
+    uAv, vAu = float(torch.dot(u, Av)), float(torch.dot(v, Au))
+    assert abs(uAv - vAu) <= 1e-11 * float(torch.dot(u, Au)) and float(torch.dot(u, Au)) > 0
