@@ -958,6 +958,9 @@ int fdd_csr_plan_attach_sell(fdd_csr_plan *plan, const int *A_ptr_host, const in
     *attached = 0;
     if (plan->num_rows == 0 || plan->num_nnz == 0 || plan->unit_values || plan->sell_slices > 0) return 0;
     if (!fdd_env_int("FDD_TUNE_CSR_SELL", 1)) return 0;
+    // one lane per row pays for short rows; wide-row matrices (the coarser Galerkin operators, 40-160 entries per row)
+    // stay on the row-block kernel (measured equal at 164 per row, far slower at 41 with rows sorted by length)
+    if ((long long)plan->num_nnz > 32LL * plan->num_rows) return 0;
     FDD_REQUIRE(A_ptr_host != nullptr && A_ptr != nullptr && A_col != nullptr && A_val != nullptr);
     const int n = plan->num_rows, slices = (n + kSellSlice - 1) / kSellSlice;
     std::vector<int> off(slices + 1, 0), width(slices, 0);
