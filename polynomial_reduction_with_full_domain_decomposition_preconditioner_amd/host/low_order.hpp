@@ -39,7 +39,13 @@ namespace low_order
 inline int host_threads()
 {
     if (const char *e = getenv("FDD_HOST_THREADS")) return std::max(1, atoi(e));
-    const unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = std::thread::hardware_concurrency();
+    // several ranks on the node (LOCAL_WORLD_SIZE from the launcher): each takes its share of the cores
+    if (const char *e = getenv("LOCAL_WORLD_SIZE"))
+    {
+        const int local = atoi(e);
+        if (local > 1) hw = std::max(1u, hw / (unsigned)local);
+    }
     return (int)std::min(16u, std::max(1u, hw));
 }
 
