@@ -288,7 +288,7 @@ def _amg_worker(rank, world, port, E, N, red):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,E,N,red", [(2, (16, 4, 4), 3, 2), (4, (8, 8, 4), 4, 2)])
+@pytest.mark.parametrize("world,E,N,red", [(2, (16, 4, 4), 3, 2), (4, (8, 8, 4), 4, 2), (8, (8, 8, 8), 3, 2)])
 def test_composite_with_low_order_preconditioner_gloo(cpu_host_lib, world, E, N, red):
     import torch.multiprocessing as mp
 
