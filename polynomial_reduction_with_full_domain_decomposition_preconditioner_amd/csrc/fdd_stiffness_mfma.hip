@@ -17,8 +17,8 @@
 //
 // One persistent 1024-lane workgroup per CU (16 wavefronts, wave w owns xy-slab
 // k = w and xz-slab j = w), four padded 16^3 arrays in LDS (136 KiB):
-//   P0  u(element)            -> sU                       (registers prefetched one element ahead)
-//   P1  Du_x, Du_y (slab k=w), Du_z (slab j=w) = D * views(sU)      -> sA1, sA2, sA3
+//   P0  u(element)            -> sU                       (registers prefetched one element ahead; wave w writes slab k=w)
+//   P1  Du_x, Du_y (slab k=w: the wave's own, no workgroup barrier), then Du_z (slab j=w) = D * views(sU) -> sA1, sA2, sA3
 //   P2  point-wise G mixing, in place on sA1..3            (G prefetched one element ahead)
 //   P3a Au_x + Au_y (slab k=w) = D^T * views(sA1, sA2)    -> sU
 //   P3b Au_z (slab j=w)       = D^T * view(sA3)           += sU
@@ -56,6 +56,14 @@ struct GPtrs
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Ordering of one wave's own LDS traffic (the LDS executes a wave's instructions in order; this keeps the compiler
+// from moving accesses across, and waits for the wave's outstanding LDS operations).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Y = Dm * X for the view X[row][col] = src[base + row*rs + col*cs];
@@ -120,15 +128,16 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
         }
     }
 
-    // padded point q = tid + 1024 m  <->  (i, j, k = k0 + 4m): i, j are the
-    // lane's own, so every index below is a lane constant plus m times a literal
-    const int pi = tid & 15, pj = (tid >> 4) & 15, k0 = tid >> 8;
-    const int l0 = pi + pj * LD + k0 * PL;
-    const int g0 = pi + pj * n + k0 * n2;
-    const bool vij = (pi < n) && (pj < n);
-#define lidx(m) (l0 + 4 * (m)*PL)
-#define goff(m) (g0 + 4 * (m)*n2)
-#define valid(m) (vij && (k0 + 4 * (m) < n))
+    // A wave owns the xy-slab k = wave: its lanes' points are (i = lane & 15, j = (lane >> 4) + 4m, k = wave), so
+    // that what the wave writes in P0 / P2 is what its own x and y products read -- those need no workgroup barrier,
+    // only the z products (which cross the slabs) do.  Every index is a lane constant plus m times a literal.
+    const int pi = lane & 15, pj0 = lane >> 4;
+    const int l0 = pi + pj0 * LD + wave * PL;
+    const int g0 = pi + pj0 * n + wave * n2;
+    const bool vik = (pi < n) && (wave < n);
+#define lidx(m) (l0 + 4 * (m)*LD)
+#define goff(m) (g0 + 4 * (m)*n)
+#define valid(m) (vik && (pj0 + 4 * (m) < n))
 
     auto elem_base = [&](int e) -> size_t { return elem_offset ? (size_t)elem_offset[e] : (size_t)e * n3; };
     const double uscale = (kGather && u_scale) ? *u_scale : 1.0;
@@ -176,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
         // P0: element -> LDS (each lane rewrites the slots it read in P4: no barrier needed before)
 #pragma unroll
         for (int m = 0; m < kPts; m++) sU[lidx(m)] = ru[m];
-        lds_barrier();
+        wave_lds_sync(); // the slab is this wave's own
         if (more)
         {
 #pragma unroll
@@ -189,12 +198,13 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
             }
         }
 
-        // P1: first derivatives
+        // P1: first derivatives; x and y on the wave's own slab, then (every slab written) z across the slabs
         {
             v4f64 y = tile_product(sU, wave * PL, 1, LD, a_D, lane); // x: rows i, cols j, slab k = wave
             tile_store(sA1, wave * PL, 1, LD, y, lane);
             y = tile_product(sU, wave * PL, LD, 1, a_D, lane);       // y: rows j, cols i, slab k = wave
             tile_store(sA2, wave * PL, LD, 1, y, lane);
+            lds_barrier();
             y = tile_product(sU, wave * LD, PL, 1, a_D, lane);       // z: rows k, cols i, slab j = wave
             tile_store(sA3, wave * LD, PL, 1, y, lane);
         }
@@ -216,16 +226,17 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
 #pragma unroll
                 for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? G.g[g][base_n + goff(m)] : 0.0;
         }
-        lds_barrier();
+        wave_lds_sync(); // P2 wrote this wave's slab of sA1 / sA2, which is all P3a reads
 
-        // P3a: Au_x then + Au_y on this wave's xy-slab
+        // P3a: Au_x then + Au_y on this wave's xy-slab (sU is free: the z products that read it are behind a barrier)
         {
             v4f64 y = tile_product(sA1, wave * PL, 1, LD, a_Dt, lane);
             tile_store(sU, wave * PL, 1, LD, y, lane);
+            wave_lds_sync();
             y = tile_product(sA2, wave * PL, LD, 1, a_Dt, lane);
             tile_add(sU, wave * PL, LD, 1, y, lane);
         }
-        lds_barrier();
+        lds_barrier(); // every slab of sA3 (P2) and of sU (P3a) complete
 
         // P3b: + Au_z on this wave's xz-slab
         {
