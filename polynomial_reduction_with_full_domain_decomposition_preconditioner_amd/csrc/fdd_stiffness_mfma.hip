@@ -36,6 +36,9 @@
 namespace
 {
 
+#ifndef FDD_MFMA_UNCOND_PREFETCH
+#define FDD_MFMA_UNCOND_PREFETCH 1 // 0: prefetch only when there is a next element (development A/B)
+#endif
 constexpr int kThreads = 1024;
 constexpr int LD = 17;        // padded row of 16
 constexpr int PL = 16 * LD;   // plane stride
@@ -80,6 +83,23 @@ __device__ __forceinline__ v4f64 tile_product(const double *src, int base, int r
     return acc;
 }
 
+// the same with the A-operand fragments read from LDS: sa[s*64 + lane]
+__device__ __forceinline__ v4f64 tile_product_lds(const double *src, int base, int rs, int cs, const double *sa, int lane)
+{
+    const int kk = lane >> 4, c = lane & 15;
+    double a[4], b[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+    {
+        a[s] = sa[s * 64 + lane];
+        b[s] = src[base + (4 * s + kk) * rs + c * cs];
+    }
+    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+    return acc;
+}
+
 // C/D layout of v_mfma_f64_16x16x4_f64: register r of lane l is Y[(l>>4) + 4r][l&15]
 __device__ __forceinline__ void tile_store(double *dst, int base, int rs, int cs, v4f64 y, int lane)
 {
@@ -108,14 +128,18 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
     double *sA1 = sU + ARR;
     double *sA2 = sA1 + ARR;
     double *sA3 = sA2 + ARR;
+    double *sDt = sA3 + ARR; // A-operand fragments of D^T, [4][64]: kept out of the register file (see below)
 
     constexpr int n2 = n * n, n3 = n2 * n;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    // A-operand fragments of D (pass 1) and D^T (pass 2), zero-padded to 16x16
-    double a_D[4], a_Dt[4];
+    // A-operand fragments of D (pass 1) and D^T (pass 2), zero-padded to 16x16.  Those of D stay in registers; those of
+    // D^T are read from LDS at each use: with both in registers (16 VGPRs) the allocation spilled, and every scratch
+    // reload waits on the in-order vector-memory counter, i.e. on the next element's prefetched loads and on the stores
+    // of the previous one.
+    double a_D[4];
     {
         const int row = lane & 15, kk = lane >> 4;
 #pragma unroll
@@ -123,10 +147,11 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
         {
             const int p = 4 * s + kk;
             const bool in = (row < n) && (p < n);
-            a_D[s] = in ? D_hat[p + row * n] : 0.0;   // D[row][p]   = D_hat[p + row*n_x] (domain.okl:42)
-            a_Dt[s] = in ? D_hat[row + p * n] : 0.0;  // D^T[row][p] = D_hat[row + p*n_x] (domain.okl:90)
+            a_D[s] = in ? D_hat[p + row * n] : 0.0;                              // D[row][p]   = D_hat[p + row*n_x] (domain.okl:42)
+            if (wave == 0) sDt[s * 64 + lane] = in ? D_hat[row + p * n] : 0.0;  // D^T[row][p] = D_hat[row + p*n_x] (domain.okl:90)
         }
     }
+    __syncthreads();
 
     // A wave owns the xy-slab k = wave: its lanes' points are (i = lane & 15, j = (lane >> 4) + 4m, k = wave), so
     // that what the wave writes in P0 / P2 is what its own x and y products read -- those need no workgroup barrier,
@@ -136,14 +161,14 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
     const int g0 = pi + pj0 * n + wave * n2;
     const bool vik = (pi < n) && (wave < n);
 #define lidx(m) (l0 + 4 * (m)*LD)
-#define goff(m) (g0 + 4 * (m)*n)
+#define goff(m) ((unsigned)(g0 + 4 * (m)*n)) // 32-bit lane offset behind a wave-uniform element base: SGPR base + VGPR offset loads
 #define valid(m) (vik && (pj0 + 4 * (m) < n))
 
     auto elem_base = [&](int e) -> size_t { return elem_offset ? (size_t)elem_offset[e] : (size_t)e * n3; };
     const double uscale = (kGather && u_scale) ? *u_scale : 1.0;
     // kGather: the dof indices run one element ahead of the values they address (rd), so that the value
     // loads of the prefetch never wait on an index load issued in the same phase
-    auto load_idx = [&](size_t p, bool ok) -> int { return ok ? __builtin_nontemporal_load(point_dof + p) : -1; }; // the index stream is read once
+    auto load_idx = [&](size_t eb, unsigned off, bool ok) -> int { return ok ? __builtin_nontemporal_load((point_dof + eb) + off) : -1; }; // the index stream is read once
     auto load_val = [&](int d) -> double { // unconditional load on a selected index, then the select
         const double v = u[d < 0 ? 0 : d];
         return (d < 0) ? 0.0 : (u_scale ? uscale * v : v);
@@ -158,21 +183,27 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
         if (kGather)
         {
 #pragma unroll
-            for (int m = 0; m < kPts; m++) rd[m] = load_idx(base + goff(m), valid(m));
+            for (int m = 0; m < kPts; m++) rd[m] = load_idx(base, goff(m), valid(m));
+        }
+        // u first, then the factors: the order the loop issues them in (u of the next element after P0, its factors in
+        // P2).  The compiler's wait before P0's LDS writes is the weaker of the two paths into the loop head: with the
+        // first element's loads interleaved it came out as vmcnt(0), i.e. every element waited for ALL outstanding
+        // vector memory -- the 24 prefetched factor loads and the stores of the element before.
+#pragma unroll
+        for (int m = 0; m < kPts; m++) ru[m] = kGather ? load_val(rd[kGather ? m : 0]) : (valid(m) ? (u + base)[goff(m)] : 0.0);
+        asm volatile("" ::: "memory"); // keep the order
+        if (kGather) // the next element's indices before the factors, as in the loop (they are needed right after P0)
+        {
+            const int en0 = e + (int)gridDim.x;
+            const size_t base_n = elem_base(en0 < num_elements ? en0 : e);
+#pragma unroll
+            for (int m = 0; m < kPts; m++) rd[m] = load_idx(base_n, goff(m), valid(m));
+            asm volatile("" ::: "memory");
         }
 #pragma unroll
         for (int m = 0; m < kPts; m++)
-        {
-            ru[m] = kGather ? load_val(rd[kGather ? m : 0]) : (valid(m) ? u[base + goff(m)] : 0.0);
 #pragma unroll
-            for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? G.g[g][base + goff(m)] : 0.0;
-        }
-        if (kGather && e + (int)gridDim.x < num_elements)
-        {
-            const size_t base_n = elem_base(e + gridDim.x);
-#pragma unroll
-            for (int m = 0; m < kPts; m++) rd[m] = load_idx(base_n + goff(m), valid(m));
-        }
+            for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? (G.g[g] + base)[goff(m)] : 0.0;
     }
 
     for (; e < num_elements; e += gridDim.x)
@@ -180,21 +211,25 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
         const size_t base = elem_base(e);
         const int en = e + gridDim.x;
         const bool more = en < num_elements;
-        const size_t base_n = more ? elem_base(en) : 0;
+        // The prefetches below are issued on EVERY iteration (the last one re-reads its own element): with them under
+        // `if (more)` the number of loads in flight at each wait differs between the paths, and the compiler has to wait
+        // for the weakest case -- vmcnt(0) in P2, which also drains the loads just issued for the next element.
+        const size_t base_n = elem_base(more ? en : e);
 
         // P0: element -> LDS (each lane rewrites the slots it read in P4: no barrier needed before)
 #pragma unroll
         for (int m = 0; m < kPts; m++) sU[lidx(m)] = ru[m];
         wave_lds_sync(); // the slab is this wave's own
-        if (more)
+        if (FDD_MFMA_UNCOND_PREFETCH || more)
         {
 #pragma unroll
-            for (int m = 0; m < kPts; m++) ru[m] = kGather ? load_val(rd[kGather ? m : 0]) : (valid(m) ? u[base_n + goff(m)] : 0.0);
-            if (kGather && en + (int)gridDim.x < num_elements)
+            for (int m = 0; m < kPts; m++) ru[m] = kGather ? load_val(rd[kGather ? m : 0]) : (valid(m) ? (u + base_n)[goff(m)] : 0.0);
+            if (kGather)
             {
-                const size_t base_nn = elem_base(en + gridDim.x);
+                const int enn = en + (int)gridDim.x;
+                const size_t base_nn = elem_base(enn < num_elements ? enn : (more ? en : e));
 #pragma unroll
-                for (int m = 0; m < kPts; m++) rd[m] = load_idx(base_nn + goff(m), valid(m));
+                for (int m = 0; m < kPts; m++) rd[m] = load_idx(base_nn, goff(m), valid(m));
             }
         }
 
@@ -219,28 +254,28 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
             sA2[lidx(m)] = rg[3][m] * Du_1 + rg[1][m] * Du_2 + rg[5][m] * Du_3;
             sA3[lidx(m)] = rg[4][m] * Du_1 + rg[5][m] * Du_2 + rg[2][m] * Du_3;
         }
-        if (more)
+        if (FDD_MFMA_UNCOND_PREFETCH || more)
         {
 #pragma unroll
             for (int m = 0; m < kPts; m++)
 #pragma unroll
-                for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? G.g[g][base_n + goff(m)] : 0.0;
+                for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? (G.g[g] + base_n)[goff(m)] : 0.0;
         }
         wave_lds_sync(); // P2 wrote this wave's slab of sA1 / sA2, which is all P3a reads
 
         // P3a: Au_x then + Au_y on this wave's xy-slab (sU is free: the z products that read it are behind a barrier)
         {
-            v4f64 y = tile_product(sA1, wave * PL, 1, LD, a_Dt, lane);
+            v4f64 y = tile_product_lds(sA1, wave * PL, 1, LD, sDt, lane);
             tile_store(sU, wave * PL, 1, LD, y, lane);
             wave_lds_sync();
-            y = tile_product(sA2, wave * PL, LD, 1, a_Dt, lane);
+            y = tile_product_lds(sA2, wave * PL, LD, 1, sDt, lane);
             tile_add(sU, wave * PL, LD, 1, y, lane);
         }
         lds_barrier(); // every slab of sA3 (P2) and of sU (P3a) complete
 
         // P3b: + Au_z on this wave's xz-slab
         {
-            v4f64 y = tile_product(sA3, wave * LD, PL, 1, a_Dt, lane);
+            v4f64 y = tile_product_lds(sA3, wave * LD, PL, 1, sDt, lane);
             tile_add(sU, wave * LD, PL, 1, y, lane);
         }
         lds_barrier();
@@ -248,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
         // P4: LDS -> global
 #pragma unroll
         for (int m = 0; m < kPts; m++)
-            if (valid(m)) Au[base + goff(m)] = sU[lidx(m)]; // default cache policy: non-temporal accesses measured 4 % slower here
+            if (valid(m)) (Au + base)[goff(m)] = sU[lidx(m)]; // default cache policy: non-temporal accesses measured 4 % slower here
     }
 #undef lidx
 #undef goff
@@ -258,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
 template <int n>
 int launch_mfma(double *Au, const double *u, const int *point_dof, const double *u_scale, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
 {
-    const size_t lds = 4 * (size_t)ARR * sizeof(double);
+    const size_t lds = (4 * (size_t)ARR + 4 * 64) * sizeof(double);
     // once per kernel instance, whichever host thread gets here first
     static std::once_flag configured;
     hipError_t attr_a = hipSuccess, attr_b = hipSuccess;
