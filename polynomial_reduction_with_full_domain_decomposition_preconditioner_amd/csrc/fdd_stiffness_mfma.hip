@@ -39,6 +39,20 @@ namespace
 #ifndef FDD_MFMA_UNCOND_PREFETCH
 #define FDD_MFMA_UNCOND_PREFETCH 1 // 0: prefetch only when there is a next element (development A/B)
 #endif
+#ifndef FDD_MFMA_TRACE
+#define FDD_MFMA_TRACE 0 // 1: wave 0 of workgroup 0 accumulates the cycles spent in each phase and prints them (development)
+#endif
+#if FDD_MFMA_TRACE
+#define FDD_TR(k)                                   \
+    do                                              \
+    {                                               \
+        const unsigned long long c1_ = clock64();   \
+        tr_[k] += c1_ - c0_;                        \
+        c0_ = c1_;                                  \
+    } while (0)
+#else
+#define FDD_TR(k)
+#endif
 constexpr int kThreads = 1024;
 constexpr int LD = 17;        // padded row of 16
 constexpr int PL = 16 * LD;   // plane stride
@@ -206,8 +220,16 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
             for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? (G.g[g] + base)[goff(m)] : 0.0;
     }
 
+#if FDD_MFMA_TRACE
+    unsigned long long tr_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, c0_ = clock64();
+    int tr_elems = 0;
+#endif
     for (; e < num_elements; e += gridDim.x)
     {
+#if FDD_MFMA_TRACE
+        tr_elems++;
+        c0_ = clock64();
+#endif
         const size_t base = elem_base(e);
         const int en = e + gridDim.x;
         const bool more = en < num_elements;
@@ -232,6 +254,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
                 for (int m = 0; m < kPts; m++) rd[m] = load_idx(base_nn, goff(m), valid(m));
             }
         }
+        FDD_TR(0);
 
         // P1: first derivatives; x and y on the wave's own slab, then (every slab written) z across the slabs
         {
@@ -239,11 +262,15 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
             tile_store(sA1, wave * PL, 1, LD, y, lane);
             y = tile_product(sU, wave * PL, LD, 1, a_D, lane);       // y: rows j, cols i, slab k = wave
             tile_store(sA2, wave * PL, LD, 1, y, lane);
+            FDD_TR(1);
             lds_barrier();
+            FDD_TR(2);
             y = tile_product(sU, wave * LD, PL, 1, a_D, lane);       // z: rows k, cols i, slab j = wave
             tile_store(sA3, wave * LD, PL, 1, y, lane);
+            FDD_TR(3);
         }
         lds_barrier();
+        FDD_TR(4);
 
         // P2: geometric factors, point-wise, in place (domain.okl:47-49)
 #pragma unroll
@@ -262,6 +289,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
                 for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? (G.g[g] + base_n)[goff(m)] : 0.0;
         }
         wave_lds_sync(); // P2 wrote this wave's slab of sA1 / sA2, which is all P3a reads
+        FDD_TR(5);
 
         // P3a: Au_x then + Au_y on this wave's xy-slab (sU is free: the z products that read it are behind a barrier)
         {
@@ -271,20 +299,30 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
             y = tile_product_lds(sA2, wave * PL, LD, 1, sDt, lane);
             tile_add(sU, wave * PL, LD, 1, y, lane);
         }
+        FDD_TR(6);
         lds_barrier(); // every slab of sA3 (P2) and of sU (P3a) complete
+        FDD_TR(7);
 
         // P3b: + Au_z on this wave's xz-slab
         {
             v4f64 y = tile_product_lds(sA3, wave * LD, PL, 1, sDt, lane);
             tile_add(sU, wave * LD, PL, 1, y, lane);
         }
+        FDD_TR(8);
         lds_barrier();
+        FDD_TR(9);
 
         // P4: LDS -> global
 #pragma unroll
         for (int m = 0; m < kPts; m++)
             if (valid(m)) (Au + base)[goff(m)] = sU[lidx(m)]; // default cache policy: non-temporal accesses measured 4 % slower here
+        FDD_TR(10);
     }
+#if FDD_MFMA_TRACE
+    if (blockIdx.x == 0 && tid == 0)
+        printf("mfma trace (cycles per element, wave 0 of workgroup 0, %d elements): P0+issue %llu | xy %llu | wait %llu | z %llu | wait %llu | P2+issue %llu | P3a %llu | wait %llu | P3b %llu | wait %llu | P4 %llu\n", tr_elems,
+               tr_[0] / tr_elems, tr_[1] / tr_elems, tr_[2] / tr_elems, tr_[3] / tr_elems, tr_[4] / tr_elems, tr_[5] / tr_elems, tr_[6] / tr_elems, tr_[7] / tr_elems, tr_[8] / tr_elems, tr_[9] / tr_elems, tr_[10] / tr_elems);
+#endif
 #undef lidx
 #undef goff
 #undef valid
