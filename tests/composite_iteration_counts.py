@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Outer PCG iterations to 1e-7 for block-local vs composite preconditioning, with and without the V-cycle inside
+(test infrastructure: gloo ranks on the CPU stand-in of the kernel C-ABI).  python tests/composite_iteration_counts.py [ranks] [E per rank] [N]"""
+import json, os, socket, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def worker(rank, world, port, e, N, red):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import support as S
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H, lib
+    lib._host = lib._Lib(os.path.join(ROOT, "tests/cpu_shim/_build/libfdd_host_cpu.so"), os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H.init(0, use_torch_stream=False); H.set_print(False)
+    if world > 1: H.comm_torch_callbacks(on_gpu=False)
+    else: H.comm_single()
+    Pg = S.rank_grid(world); E = tuple(e * p for p in Pg)
+    res = {}
+    for name, bl in (("block_local", True), ("composite", False)):
+        p = H.Problem.box(E, Pg, N, red, True, block_local=bl)
+        p.set_options(max_iterations=400)
+        _, f = p.make_rhs(function_id=4, seed=1234 + rank)
+        for amg in (0, 1):
+            p.set_flag("sub_use_preconditioner", amg)
+            _, its, hist = p.solve(f, "fcg")
+            res["%s, V-cycle %s" % (name, "on" if amg else "off")] = (its, float(hist[-1] / hist[0]))
+        p.close()
+    if rank == 0: print(json.dumps({"ranks": world, "elements": E, "N": N, "iterations": res}))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    import torch.multiprocessing as mp
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    e = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    N = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(worker, args=(world, port, e, N, 6 if N == 7 else 2), nprocs=world, join=True)
