@@ -31,7 +31,15 @@ roofline: the device kernel family with the largest total time in the timed
           bytes per BASELINE.md section 4.
 cpu_baseline: the CPU oracle (serial restatement of the reference's
           OCCA-Serial path) timed on this box's host cores on a bounded sample
-          (rank 0, N=1 only).  A reported baseline, not a target.
+          by rank 0, at every N: the oracle's N-rank world (all ranks'
+          composites simulated in one process, one core) on a smaller cube
+          with the same rank grid.  A reported baseline, not a target.
+legs    : every time-to-tolerance object carries `converged` (the reference's
+          500-iteration cap can be hit first).  At N > 1 the line also carries
+          the block-local comparison point (`block_local`) next to the
+          composite, and at every N the headline configuration with
+          point-Jacobi in the inner solver's preconditioner slot
+          (`point_jacobi`, a labelled option of this build).
 """
 import argparse
 import ctypes
@@ -74,41 +82,64 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """Oracle timed on host cores: same solver structure on a smaller cube."""
+def cpu_baseline(args, world, P):
+    """Oracle timed on host cores: same solver structure, same rank grid, on a smaller cube.  One rank: the
+    single-subdomain preconditioner; N ranks: the oracle's N-rank world -- every rank's full-domain-decomposition
+    composite (or its own elements only with --block-local), ring pull and coarse all-gather included -- simulated in
+    this one process on one core (SURVEY 8(d) asks for one core per subdomain; the oracle is a serial program, so the
+    count that was really used is what `cores` states)."""
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import support as S
 
-    e, N, red = args.cpu_sample_elements, args.degree, args.reduction
+    N, red = args.degree, args.reduction
+    e = args.cpu_sample_elements if world == 1 else max(4, int(round(0.6 * args.cpu_sample_elements / world ** (1.0 / 3.0))))
+    E = tuple(e * p for p in P)
     deg = S.level_degrees(N, red)
-    meshes = [S.BoxMesh((e, e, e), d) for d in deg]
-    W = S.OracleWorld([meshes[0]], N)
-    sd = None if args.no_precond else S.OracleSubdomain(None, N, red, meshes=meshes)
-    us = W.dssum([S.seeded_uniform(meshes[0].num_local_points, 1234)], True, True)
+    t_setup = time.perf_counter()
+    meshes = [[S.BoxMesh(E, d, P, r) for d in deg] for r in range(world)]
+    W = S.OracleWorld([m[0] for m in meshes], N)
+    F = sds = None
+    if not args.no_precond:
+        if world > 1 and not args.block_local:
+            F = S.OracleFdd(E, N, red, P, meshes=meshes)
+        else:
+            sds = [S.OracleSubdomain(None, N, red, meshes=meshes[r]) for r in range(world)]
+    us = W.dssum([S.seeded_uniform(meshes[r][0].num_local_points, 1234 + r) for r in range(world)], True, True)
     f = W.stiffness(us)
+    t_setup = time.perf_counter() - t_setup
 
     def pre(z, r):
-        out, _, _ = sd.solve(r[0], "gmres")
-        z[0][:] = out
+        if F is not None:
+            out, _ = F.precondition(r, "gmres")
+            for k in range(world):
+                z[k][:] = out[k]
+        else:
+            for k in range(world):
+                out, _, _ = sds[k].solve(r[k], "gmres")
+                z[k][:] = out
 
     steps = args.cpu_sample_steps
     t0 = time.perf_counter()
-    _, its, _ = W.solve(f, "fcg", max_iterations=steps, tolerance=0.0, precond=None if sd is None else pre)
+    _, its, _ = W.solve(f, "fcg", max_iterations=steps, tolerance=0.0, precond=None if args.no_precond else pre)
     dt = time.perf_counter() - t0
-    nodes = meshes[0].global_nodes
+    nodes = meshes[0][0].global_nodes
     W.close()
-    if sd is not None:
+    if F is not None:
+        F.close()
+    for sd in sds or []:
         sd.close()
     # orc_world_fcg runs `steps` full iterations plus the start-up residual norm
     # and first preconditioner application, all inside dt (slightly pessimistic)
+    kind = "no preconditioner" if args.no_precond else ("full-domain-decomposition composite of every rank" if F is not None else "FDD preconditioner on every rank's own elements")
     return {
         "value": nodes * steps / dt,
         "unit": "DOF-updates/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{e}^3 elements, N={N}, {steps} outer PCG iterations with the same FDD preconditioner (inner GMRES(4)), serial C oracle, {dt:.1f} s",
+        "sample": f"{E[0]}x{E[1]}x{E[2]} elements ({e}^3 per rank, {world} rank{'s' if world > 1 else ''} simulated serially in one process), N={N}, {steps} outer PCG iterations, "
+                  f"{kind} (inner GMRES(4)), serial C oracle, {dt:.1f} s (+ {t_setup:.1f} s of oracle setup outside the clock)",
     }
 
 
@@ -200,26 +231,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    t_setup = time.perf_counter()
-    block_local, composite_error = args.block_local, None
-    if world > 1 and not args.no_precond and not block_local:
-        # The composite needs the point-to-point exchange (grouped send / receive) at setup and in every preconditioner
-        # application.  If that fails on this system the ranks agree on it and the run continues block-local, labelled.
-        prob = None
+    def create(block_local):
+        """A failure on one rank leaves the others inside the composite's setup collectives: report it and leave with a
+        failure code so that the launcher tears the job down, instead of moving on to a mismatched collective."""
         try:
-            prob = H.Problem.box(E, P, N, args.reduction, with_subdomain=True)
-            prob.sub_op("tree", np.zeros(prob.n))  # the solve-time ring pull and coarse all-gather, once
-        except Exception as exc:  # a failure all ranks see (an unsupported collective); a one-sided one cannot be caught here
-            composite_error = str(exc)
-        if max_over_ranks(1.0 if composite_error else 0.0) > 0:
-            composite_error = composite_error or "the composite failed on another rank"
-            if prob is not None:
-                prob.close()
-            block_local = True
-            if rank == 0:
-                print("bench.py: full-domain-decomposition composite unavailable (%s); continuing block-local" % composite_error, file=sys.stderr, flush=True)
-    if world == 1 or args.no_precond or block_local:
-        prob = H.Problem.box(E, P, N, args.reduction, with_subdomain=not args.no_precond, block_local=block_local, force_composite=args.force_composite and world == 1)
+            return H.Problem.box(E, P, N, args.reduction, with_subdomain=not args.no_precond, block_local=block_local, force_composite=args.force_composite and world == 1)
+        except Exception as exc:
+            print("bench.py rank %d: problem setup failed: %s" % (rank, exc), file=sys.stderr, flush=True)
+            os._exit(1)
+
+    t_setup = time.perf_counter()
+    block_local = args.block_local
+    prob = create(block_local)
     _, f = prob.make_rhs(function_id=4, seed=1234 + rank)  # rand()/RAND_MAX u*, poisson.cpp:211
     t_setup = time.perf_counter() - t_setup
     sub = prob.sub_info() if not args.no_precond else None
@@ -227,8 +250,9 @@ def main():
 
     amg_state = {"levels": 0, "setup_s": 0.0}
 
-    def configure(amg, precision=64):
-        """headline: inner GMRES(4) alone; reference default: the low-order V-cycle inside every inner step"""
+    def configure(amg, precision=64, jacobi=False):
+        """headline: inner GMRES(4) alone; reference default: the low-order V-cycle inside every inner step;
+        jacobi: point-Jacobi in that slot (labelled option of this build)"""
         if args.no_precond:
             return
         if amg and amg_state["levels"] == 0:
@@ -239,7 +263,7 @@ def main():
                 prob.set_flag("amg_graph", 0)
             if args.no_amg_fusion:
                 prob.set_flag("amg_fused_smoother", 0)
-        prob.set_flag("sub_use_preconditioner", 1 if amg else 0)
+        prob.set_flag("sub_use_preconditioner", 1 if amg else (2 if jacobi else 0))
         # the reference's PTYPE = Float (config.hpp:19-20): the WHOLE inner solve (element stiffness, gather, Krylov vectors,
         # V-cycle) in double or in float
         prob.set_flag("preconditioner_precision", precision)
@@ -247,29 +271,30 @@ def main():
     info0 = prob.refresh()
     nodes = info0["num_total_nodes"]
 
-    def timed_steps(steps, warmup, kernel_timing):
+    def timed_steps(steps, warmup, kernel_timing, problem=None, rhs=None):
         """`warmup` untimed + exactly `steps` timed outer PCG iterations bracketed by barrier + synchronise"""
-        prob.pcg_begin(f)
+        problem = problem or prob
+        problem.pcg_begin(f if rhs is None else rhs)
         dominant = None
         if warmup > 0 and kernel_timing:
             # which kernel family dominates is MEASURED during the warm-up (every family timed); the timed region then
             # records HIP events around that family only (two records per launch cost a few microseconds)
             lib.host().call("fddh_profile_enable", 1)
-            prob.pcg_steps(warmup)
+            problem.pcg_steps(warmup)
             wbuf = ctypes.create_string_buffer(1 << 16)
             lib.host().call("fddh_profile_collect", wbuf, len(wbuf))
             wk = json.loads(wbuf.value.decode())
             if wk:
                 dominant = max(wk, key=lambda k: wk[k]["ms"])
         else:
-            prob.pcg_steps(warmup)
+            problem.pcg_steps(warmup)
         lib.host().call("fddh_profile_enable", 1 if kernel_timing else 0)
         if dominant and not args.kernel_table:
             lib.host().call("fddh_profile_only", dominant.encode())
         H.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        last = prob.pcg_steps(steps)
+        last = problem.pcg_steps(steps)
         torch.cuda.synchronize()
         H.barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
@@ -278,11 +303,13 @@ def main():
         lib.host().call("fddh_profile_enable", 0)
         return dt, last, json.loads(buf.value.decode())
 
-    def to_tolerance():
-        """the reference's own stopping rule: relative residual 1e-7 (domain.hpp:118), clock around the device work"""
-        its, hist, sec = prob.solve_timed(f, "fcg")
+    def to_tolerance(problem=None, rhs=None):
+        """the reference's own stopping rule: relative residual 1e-7 within 500 iterations (domain.hpp:116-118), clock
+        around the device work; `converged` says which of the two ended the solve"""
+        its, hist, sec = (problem or prob).solve_timed(f if rhs is None else rhs, "fcg")
         sec = max_over_ranks(sec)
-        return {"iterations": its, "time_ms": sec * 1e3, "relative_residual": float(hist[-1] / hist[0]) if len(hist) else None, "DOF_updates_per_s": nodes * its / sec if sec > 0 else None}
+        rel = float(hist[-1] / hist[0]) if len(hist) else None
+        return {"iterations": its, "converged": bool(rel is not None and rel <= 1e-7), "time_ms": sec * 1e3, "relative_residual": rel, "DOF_updates_per_s": nodes * its / sec if sec > 0 else None}
 
     # ---------------- headline configuration ----------------
     configure(args.amg, args.amg_precision)
@@ -304,6 +331,33 @@ def main():
         if not args.no_time_to_tolerance:
             headline_f32["to_1e-7"] = to_tolerance()
         configure(args.amg, args.amg_precision)
+
+    # the headline configuration with point-Jacobi in the inner solver's preconditioner slot (labelled option of this
+    # build; DESIGN 5: what four unpreconditioned Krylov steps lack is row scaling, most of all on the composite)
+    point_jacobi = None
+    if not args.no_precond and not args.no_reference_default and not args.amg:
+        configure(False, args.amg_precision, jacobi=True)
+        dj, lrj, _ = timed_steps(args.steps, min(args.warmup, 2), False)
+        point_jacobi = {"preconditioner": "fdd_gmres4 + point-Jacobi in the inner preconditioner slot (option of this build, not in the reference)",
+                        "ms_per_step": dj / args.steps * 1e3, "value": nodes * args.steps / dj, "last_residual_norm": lrj}
+        if not args.no_time_to_tolerance:
+            point_jacobi["to_1e-7"] = to_tolerance()
+        configure(args.amg, args.amg_precision)
+
+    # N > 1: the block-local comparison point (every rank's own elements only: block-Jacobi) next to the composite, so
+    # that an iteration count of the composite is never read without it
+    block_local_leg = None
+    if world > 1 and composite and not args.no_reference_default:
+        other = create(True)
+        other.set_flag("sub_use_preconditioner", 0)
+        _, f_bl = other.make_rhs(function_id=4, seed=1234 + rank)
+        db, lrb, _ = timed_steps(args.steps, min(args.warmup, 2), False, problem=other, rhs=f_bl)
+        block_local_leg = {"preconditioner": "BLOCK-LOCAL fdd_gmres4 (own elements only: no neighbour rings / superdomain)", "ms_per_step": db / args.steps * 1e3, "value": nodes * args.steps / db, "last_residual_norm": lrb}
+        if not args.no_time_to_tolerance:
+            block_local_leg["to_1e-7"] = to_tolerance(other, f_bl)
+            other.set_flag("sub_use_preconditioner", 2)
+            block_local_leg["point_jacobi_to_1e-7"] = to_tolerance(other, f_bl)
+        other.close()
 
     table = {}
     for name, st in kernels.items():
@@ -408,6 +462,8 @@ def main():
         "ms_per_step_with_stopping_tests": dt_tests / args.steps * 1e3,
         "to_1e-7": headline_tol,
         "preconditioner_in_f32": headline_f32,
+        "point_jacobi": point_jacobi,
+        "block_local": block_local_leg,
         "setup_s": t_setup,
         "roofline": roofline,
         "spmv": spmv,
@@ -418,16 +474,14 @@ def main():
         # the solve path's collectives alone, with the solve's own sizes and buffers (max over ranks)
         comm = prob.comm_time(20)
         out["comm_us"] = {k: {"avg_us": max_over_ranks(v["avg_us"]), "bytes": v["bytes"]} for k, v in comm.items()}
-    if composite_error:
-        out["config"]["composite_unavailable"] = composite_error
     if composite:
         out["config"]["composite"] = {k: sub[k] for k in ("num_elems", "num_ext_elems", "num_points", "sub_dofs", "sub_ext_dofs", "interface_dofs", "sup_dofs", "sup_ext_dofs", "unique_dofs", "coarse_dofs", "num_peers")}
         out["config"]["composite"]["superdomain_levels"] = prob.sub_composite_levels()
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args)
-    else:
-        out["cpu_baseline"] = None
+    # rank 0 times the oracle on its host cores while the other ranks wait at the barrier below
+    out["cpu_baseline"] = cpu_baseline(args, world, P) if (rank == 0 and not args.no_cpu_baseline) else None
+    if world > 1:
+        H.barrier()
 
     if rank == 0:
         print(json.dumps(out))

@@ -288,6 +288,11 @@ int fdd_sub_stiffness_matrix_gather_scaled_f32(float *Au, const float *v, const 
 int fdd_multi_inner_product_scaled_f32(double *out, double *ws, const float *a, const float *const *b, const double *b_scale_dev, int m, int n, void *stream); /* out[k] = sum a * (s_k b_k), k < m <= 8 */
 int fdd_multi_axpy_norm2_scaled_dev_f32(double *out, double *ws, float *dst, const float *y, const double *coeffs_dev, double sign, const float *const *x, const double *x_scale_dev, int m, int n, void *stream); /* dst = y + sign sum c_k (s_k x_k); out = |dst|^2 */
 int fdd_vector_scaling_dev_f32(float *au, const double *scale_dev, const float *u, int n, void *stream);
+/* z = d .* ((*scale_dev) * u), scale_dev NULL: z = d .* u.  The point-Jacobi preconditioner of the inner solve (a labelled
+ * option of this build, host/subdomain.hpp) on a Krylov vector kept unnormalised: math.okl:29-35, then
+ * AMG/kernels.cu:64-73 (vector_multiplication), in that order */
+int fdd_vector_diagonal_scaling_dev(double *z, const double *d, const double *scale_dev, const double *u, int n, void *stream);
+int fdd_vector_diagonal_scaling_dev_f32(float *z, const float *d, const double *scale_dev, const float *u, int n, void *stream);
 int fdd_vector_vector_addition_f32(float *uv, float alpha, const float *u, float beta, const float *v, int n, void *stream);
 int fdd_multi_lincomb_limited_dev_f32(float *q, int q_is_zero, const double *coeffs_dev, const float *const *v, const double *v_scale_dev, const double *last_dev, int m, int n, void *stream); /* q (+)= sum_{k <= *last} c_k (s_k v_k); last_dev NULL: all m */
 int fdd_gather_rows_f32(float *t, const int *ptr, const int *col, const float *u, int row_lo, int row_hi, void *stream); /* t[row] = sum of u over the row's entries (boolean gather) */

@@ -154,7 +154,10 @@ int fddh_problem_set_options(fddh_problem *p, int max_iterations, double toleran
  *   "mfma_stiffness"           1: degrees 11..15 apply the stiffness on the fp64 matrix cores (default;
  *                              agrees with the bit-exact kernel to ~1e-15, not bit for bit), 0: scalar fused kernel
  *   "sub_use_preconditioner"   1: the inner solver preconditions with the low-order AMG V-cycle
- *                              (Subdomain::use_preconditioner, subdomain.hpp:231; needs fddh_problem_amg_*), 0: dssum (default)
+ *                              (Subdomain::use_preconditioner, subdomain.hpp:231; the reference's and this build's default),
+ *                              0: the identity on assembled data (dssum, subdomain.tpp:4379-4382),
+ *                              2: point-Jacobi, the exact diagonal of the inner iteration's operator -- a labelled option of
+ *                              this build, not in the reference (host/subdomain.hpp)
  *   "amg_graph"                1: the V-cycle is replayed as one hipGraph when the stream allows capture (default)
  *   "amg_fused_smoother"       1: the smoother's element-wise kernels run as SpMV epilogues, bit-identical (default); 0: the reference's launch sequence 
  *   "amg_precision"            64 (default) or 32: the reference's `Float` (AMG/config.hpp:4): the V-cycle in double or in float */
@@ -202,6 +205,13 @@ int fddh_problem_precond_apply(fddh_problem *p, int type, const double *r, doubl
  * 1 = stiffness_matrix, 2 = direct_stiffness_summation; in/out of sub_num_values = [region points | superdomain dofs] */
 int fddh_problem_sub_op(fddh_problem *p, int op, const double *in, double *out);
 int fddh_problem_sub_residual_norm(fddh_problem *p, const double *r, double *norm);
+/* The inner iteration in its dof-space form (host/subdomain.hpp: GMRES on Qt A_L Q over the unique dofs
+ * [subdomain regular | interface | superdomain regular], n = FDDH_SUB_NUM_UNIQUE_DOFS):
+ * op 0: out = operator(in), both n dofs; op 1: out (n dofs) = the right-hand side the inner solve sees for the outer
+ * vector `in` (num_local_points; runs tree_operator: collective on a composite region).  Analysis and tests. */
+int fddh_problem_sub_dof_op(fddh_problem *p, int op, const double *in, double *out, int n);
+/* the diagonal of that operator over the n unique dofs, as the point-Jacobi option ("sub_use_preconditioner" = 2) uses it */
+int fddh_problem_sub_jacobi_diagonal(fddh_problem *p, double *out, int n);
 
 /* Average launch time (HIP events on the stream) and algorithmic bytes (12 B per non-zero,
  * 12 B per row, 8 B per column) of the assembly SpMVs of csr_matrix.okl on the problem's matrices:

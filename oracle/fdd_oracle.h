@@ -192,7 +192,7 @@ typedef struct orc_subdomain_opts
     int num_vectors;        /* subdomain.hpp:229 (4) */
     int max_iterations;     /* subdomain.hpp:230 (4) */
     double tolerance;       /* subdomain.hpp:232 (1e-12) */
-    int use_preconditioner; /* 0: direct_stiffness_summation identity path */
+    int use_preconditioner; /* 0: direct_stiffness_summation identity path, 1: low-order AMG V-cycle, 2: point-Jacobi (labelled option of the build, not in the reference) */
 } orc_subdomain_opts;
 
 /* levels: poly degrees N, N-r, ..., 1 (subdomain.tpp:98-110); D_hat[l] and
@@ -256,6 +256,9 @@ int orc_amg_level_size(const orc_amg *a, int l);
 void orc_amg_vcycle(orc_amg *a, double *u0, const double *f0);
 void orc_subdomain_attach_amg(orc_subdomain *s, orc_amg *amg);
 void orc_subdomain_point_dofs(const orc_subdomain *s, int *dof);
+/* point-Jacobi option: diagonal of Qt_int Qt' A Q' Q_int over the unique dofs; and the closed-form element diagonal against the kernels (max relative error) */
+void orc_subdomain_jacobi_diagonal(const orc_subdomain *s, double *diag);
+double orc_subdomain_element_diagonal_check(const orc_subdomain *s);
 void orc_subdomain_low_order_preconditioner(orc_subdomain *s, double *z, const double *r);
 
 /* the same V-cycle with Float = float (AMG/config.hpp:4; fdd_oracle_amg_f32.c): arrays given in double are rounded */
@@ -264,6 +267,18 @@ orc_amg32 *orc_amg32_create(int num_levels, int cheby_order, int num_vcycles);
 void orc_amg32_set_level(orc_amg32 *a, int l, int n, const int *A_ptr, const int *A_col, const double *A_val, const double *D_val, const double *coefs, int n_coarse, const int *P_ptr, const int *P_col, const double *P_val);
 void orc_amg32_destroy(orc_amg32 *a);
 void orc_amg32_vcycle(orc_amg32 *a, double *u0, const double *f0);
+
+/* the inner solve's kernels with PTYPE = Float = float (config.hpp:19-20; fdd_oracle_f32.c): IEEE single throughout,
+ * except the reductions, which restate this build's double accumulators over float data */
+void orc_f32_sub_stiffness(float *Au, const float *v, const int *index, const float *scale, const float *D_hat, const float *const G[6], int num_elements, int poly_degree);
+void orc_f32_vector_vector_addition(float *uv, float alpha, const float *u, float beta, const float *v, int n);
+void orc_f32_vector_scaling(float *au, double alpha, const float *u, int n);
+void orc_f32_csr_gather(float *t, const int *ptr, const int *col, const float *u, int row_lo, int row_hi);
+void orc_f32_gather_indexed(float *out, const float *in, const int *index, int n);
+void orc_f32_gather_indexed_f64(double *out, const float *in, const int *index, int n);
+void orc_f32_multi_inner_product_scaled(double *out, const float *a, const float *const *b, const double *b_scale, int m, int n);
+double orc_f32_multi_axpy_norm2_scaled(float *dst, const float *y, const double *c, double sign, const float *const *x, const double *x_scale, int m, int n);
+void orc_f32_multi_lincomb(float *q, int q_is_zero, const double *c, const float *const *v, const double *v_scale, int last, int m, int n);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,7 @@ struct orc_subdomain
     int cap_vectors;
 
     orc_amg *amg; /* low-order preconditioner hierarchy (not owned) */
+    double *jacobi_dinv; /* 1 / diagonal over the unique dofs, built on first use (point-Jacobi option) */
 };
 
 void *orc_xcalloc(size_t n, size_t sz);

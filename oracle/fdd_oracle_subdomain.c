@@ -325,6 +325,7 @@ void orc_subdomain_destroy(orc_subdomain *s)
     free(s->level);
     free(s->norm_weight);
     free(s->inner_weight);
+    free(s->jacobi_dinv);
     for (int w = 0; w < 3; w++) free(s->work[w]);
     free(s->f);
     free(s->u_k);
@@ -483,9 +484,206 @@ void orc_subdomain_low_order_preconditioner(orc_subdomain *s, double *z, const d
     memcpy(z + s->num_points, s->work[0] + s->num_extended_dofs, (size_t)s->sup_num_extended_dofs * sizeof(double)); /* :4157 */
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Point-Jacobi in the preconditioner slot (a labelled option of the build under test, not in the reference):
+ * z = Q Q_int D^-1 (Qt_int Qt r), D = diag(Qt_int Qt' A Q' Q_int) over the unique dofs, with Q' = [Q 0; 0 I] and
+ * A = [A_L 0; 0 A_sup] the reference's operators on composite vectors (subdomain.tpp:3942-3985).  The diagonal is
+ * formed from those operators as they stand: entry u = (row of the dof's representative, Qt_int) . (column of the
+ * dof's copies, Q_int); the element part element by element with the restated kernels of subdomain.okl:4-101.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Au = A_e u on the np points of one element starting at point `first` (element-local vectors) */
+static void element_apply(const orc_subdomain *s, int first, int np, double *Au, const double *u, double *const GDu[3], const int *zero_offset)
+{
+    const double *G[6];
+    for (int g = 0; g < 6; g++) G[g] = s->geom_fact[g] + first;
+    orc_sub_stiffness_matrix_1(GDu, u, (const double *const *)s->D_hat, zero_offset, s->vertex + first, s->level + first, s->poly_degree, G, np, s->dim);
+    orc_sub_stiffness_matrix_2(Au, (const double *const *)GDu, (const double *const *)s->D_hat, zero_offset, s->vertex + first, s->level + first, s->poly_degree, np, s->dim);
+}
+
+/* coefficient of u(v) in (A_e u)(v), read off subdomain.okl:4-101 */
+static double element_diagonal_entry(const orc_subdomain *s, int first, int v, int n)
+{
+    const double *D = s->D_hat[s->level[first]];
+    const double *const *G = (const double *const *)s->geom_fact;
+    if (s->dim == 2)
+    {
+        const int i = v % n, j = v / n;
+        double a = 0.0;
+        for (int p = 0; p < n; p++) a += D[i + p * n] * D[i + p * n] * G[0][first + p + j * n] + D[j + p * n] * D[j + p * n] * G[1][first + i + p * n];
+        return a + 2.0 * D[i + i * n] * D[j + j * n] * G[2][first + v];
+    }
+    const int nn = n * n, i = v % n, j = (v / n) % n, k = v / nn;
+    double a = 0.0;
+    for (int p = 0; p < n; p++)
+        a += D[i + p * n] * D[i + p * n] * G[0][first + p + j * n + k * nn] + D[j + p * n] * D[j + p * n] * G[1][first + i + p * n + k * nn] + D[k + p * n] * D[k + p * n] * G[2][first + i + j * n + p * nn];
+    const double di = D[i + i * n], dj = D[j + j * n], dk = D[k + k * n];
+    return a + 2.0 * (di * dj * G[3][first + v] + di * dk * G[4][first + v] + dj * dk * G[5][first + v]);
+}
+
+/* test hook: the closed form above against the kernels applied to a unit vector */
+double orc_subdomain_element_diagonal_check(const orc_subdomain *s)
+{
+    double worst = 0.0;
+    int first = 0;
+    while (first < s->num_points)
+    {
+        const int n = s->poly_degree[s->level[first]] + 1;
+        int np = 1;
+        for (int d = 0; d < s->dim; d++) np *= n;
+        double *u = (double *)xcalloc((size_t)np, sizeof(double)), *Au = (double *)xcalloc((size_t)np, sizeof(double));
+        double *GDu[3] = {(double *)xcalloc((size_t)np, sizeof(double)), (double *)xcalloc((size_t)np, sizeof(double)), (double *)xcalloc((size_t)np, sizeof(double))};
+        int *zero = (int *)xcalloc((size_t)np, sizeof(int));
+        for (int v = 0; v < np; v += (np > 64 ? 7 : 1))
+        {
+            u[v] = 1.0;
+            element_apply(s, first, np, Au, u, GDu, zero);
+            u[v] = 0.0;
+            const double a = element_diagonal_entry(s, first, v, n);
+            const double err = fabs(a - Au[v]) / fabs(Au[v]);
+            if (err > worst) worst = err;
+        }
+        free(u);
+        free(Au);
+        for (int g = 0; g < 3; g++) free(GDu[g]);
+        free(zero);
+        first += np;
+    }
+    return worst;
+}
+
+typedef struct
+{
+    int dof, point;
+    double weight;
+} jac_entry;
+
+static int jac_cmp(const void *a_, const void *b_)
+{
+    const jac_entry *a = (const jac_entry *)a_, *b = (const jac_entry *)b_;
+    if (a->dof != b->dof) return a->dof < b->dof ? -1 : 1;
+    return a->point - b->point;
+}
+
+/* diag[u], u < num_unique_dofs */
+void orc_subdomain_jacobi_diagonal(const orc_subdomain *s, double *diag)
+{
+    const int nse = s->num_extended_dofs, nu = s->num_unique_dofs;
+    /* representative (row of Qt_int) of every unique dof, and the unique dof every extended index is a copy of (Q_int) */
+    int *rep = (int *)xcalloc((size_t)nu, sizeof(int));
+    int *uniq_of = (int *)xcalloc((size_t)(nse + s->sup_num_extended_dofs) + 1, sizeof(int));
+    for (int u = 0; u < nu; u++) rep[u] = s->Qt_int.col[s->Qt_int.ptr[u]];
+    for (int i = 0; i < s->Q_int.num_rows; i++) uniq_of[i] = (s->Q_int.ptr[i + 1] > s->Q_int.ptr[i]) ? s->Q_int.col[s->Q_int.ptr[i]] : -1;
+    for (int u = 0; u < nu; u++) diag[u] = 0.0;
+
+    /* element part: rows of representatives below nse.  left[e] = Q e_rep, right[e] = Q (copies of the same unique dof) */
+    int first = 0;
+    while (first < s->num_points)
+    {
+        const int n = s->poly_degree[s->level[first]] + 1;
+        int np = 1;
+        for (int d = 0; d < s->dim; d++) np *= n;
+        int cap = 0;
+        for (int v = 0; v < np; v++) cap += s->Q.ptr[first + v + 1] - s->Q.ptr[first + v];
+        jac_entry *ent = (jac_entry *)xcalloc((size_t)cap + 1, sizeof(jac_entry));
+        int ne = 0, simple = 1;
+        for (int v = 0; v < np; v++)
+            for (int t = s->Q.ptr[first + v]; t < s->Q.ptr[first + v + 1]; t++)
+            {
+                const int u = uniq_of[s->Q.col[t]];
+                if (u < 0) continue;
+                ent[ne].dof = u;
+                ent[ne].point = v;
+                ent[ne].weight = s->Q.val[t];
+                if (s->Q.col[t] != rep[u] || s->Q.val[t] != 1.0) simple = 0;
+                ne++;
+            }
+        qsort(ent, (size_t)ne, sizeof(jac_entry), jac_cmp);
+        for (int b = 1; b < ne && simple; b++)
+            if (ent[b].dof == ent[b - 1].dof) simple = 0;
+        if (simple)
+        {
+            for (int b = 0; b < ne; b++) diag[ent[b].dof] += element_diagonal_entry(s, first, ent[b].point, n);
+        }
+        else
+        {
+            double *wl = (double *)xcalloc((size_t)np, sizeof(double)), *wr = (double *)xcalloc((size_t)np, sizeof(double)), *Aw = (double *)xcalloc((size_t)np, sizeof(double));
+            double *GDu[3] = {(double *)xcalloc((size_t)np, sizeof(double)), (double *)xcalloc((size_t)np, sizeof(double)), (double *)xcalloc((size_t)np, sizeof(double))};
+            int *zero = (int *)xcalloc((size_t)np, sizeof(int));
+            for (int b = 0; b < ne;)
+            {
+                int e2 = b + 1;
+                while (e2 < ne && ent[e2].dof == ent[b].dof) e2++;
+                const int u = ent[b].dof;
+                if (rep[u] < nse)
+                {
+                    /* right: all copies; left: the representative's entries only -- recover them from Q */
+                    for (int v = 0; v < np; v++) wl[v] = wr[v] = 0.0;
+                    for (int t = b; t < e2; t++) wr[ent[t].point] += ent[t].weight;
+                    int any_left = 0;
+                    for (int v = 0; v < np; v++)
+                        for (int t = s->Q.ptr[first + v]; t < s->Q.ptr[first + v + 1]; t++)
+                            if (s->Q.col[t] == rep[u])
+                            {
+                                wl[v] += s->Q.val[t];
+                                any_left = 1;
+                            }
+                    if (any_left)
+                    {
+                        element_apply(s, first, np, Aw, wr, GDu, zero);
+                        double acc = 0.0;
+                        for (int v = 0; v < np; v++) acc += wl[v] * Aw[v];
+                        diag[u] += acc;
+                    }
+                }
+                b = e2;
+            }
+            free(wl);
+            free(wr);
+            free(Aw);
+            for (int g = 0; g < 3; g++) free(GDu[g]);
+            free(zero);
+        }
+        free(ent);
+        first += np;
+    }
+
+    /* superdomain part: the dofs whose representative is a superdomain entry take that row of A against their copies there */
+    for (int u = 0; u < nu; u++)
+    {
+        if (rep[u] < nse) continue;
+        const int row = rep[u] - nse;
+        double acc = 0.0;
+        for (int t = s->sup_A.ptr[row]; t < s->sup_A.ptr[row + 1]; t++)
+            if (uniq_of[nse + s->sup_A.col[t]] == u) acc += s->sup_A.val[t];
+        diag[u] = acc; /* the row of the representative alone (Qt_int picks one row); element sums of its subdomain copies are not its row */
+    }
+    free(rep);
+    free(uniq_of);
+}
+
+static void jacobi_preconditioner(orc_subdomain *s, double *z, const double *r)
+{
+    if (!s->jacobi_dinv)
+    {
+        s->jacobi_dinv = (double *)xcalloc((size_t)s->num_unique_dofs + 1, sizeof(double));
+        orc_subdomain_jacobi_diagonal(s, s->jacobi_dinv);
+        for (int u = 0; u < s->num_unique_dofs; u++) s->jacobi_dinv[u] = 1.0 / s->jacobi_dinv[u];
+    }
+    orc_csr_multiply(s->work[0], s->Qt.ptr, s->Qt.col, s->Qt.val, r, s->Qt.num_rows);
+    memcpy(s->work[0] + s->num_extended_dofs, r + s->num_points, (size_t)s->sup_num_extended_dofs * sizeof(double));
+    orc_csr_multiply(s->work[1], s->Qt_int.ptr, s->Qt_int.col, s->Qt_int.val, s->work[0], s->Qt_int.num_rows);
+    orc_amg_vector_multiplication(s->work[2], s->jacobi_dinv, s->work[1], s->num_unique_dofs);
+    orc_csr_multiply(s->work[0], s->Q_int.ptr, s->Q_int.col, s->Q_int.val, s->work[2], s->Q_int.num_rows);
+    orc_csr_multiply(z, s->Q.ptr, s->Q.col, s->Q.val, s->work[0], s->Q.num_rows);
+    memcpy(z + s->num_points, s->work[0] + s->num_extended_dofs, (size_t)s->sup_num_extended_dofs * sizeof(double));
+}
+
 static void apply_inner_preconditioner(orc_subdomain *s, const orc_subdomain_opts *opts, double *z, const double *r)
 {
-    if (opts->use_preconditioner)
+    if (opts->use_preconditioner == 2)
+        jacobi_preconditioner(s, z, r);
+    else if (opts->use_preconditioner)
         orc_subdomain_low_order_preconditioner(s, z, r);
     else
         orc_subdomain_dssum(s, z, r);

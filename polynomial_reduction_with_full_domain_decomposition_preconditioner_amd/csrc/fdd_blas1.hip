@@ -126,6 +126,23 @@ struct ScaleDevOp
     __device__ void one(long long i) const { au[i] = (*scale) * u[i]; }
 };
 
+// z = d .* ((*scale) * u): the point-Jacobi preconditioner of the inner solve applied to a Krylov vector kept
+// unnormalised (vector_scaling, math.okl:29-35, then AMG/kernels.cu:64-73 vector_multiplication, in that order)
+struct DiagScaleDevOp
+{
+    double *z;
+    const double *d;
+    const double *u;
+    const double *scale; // may be null: z = d .* u
+    __device__ void vec2(long long i) const
+    {
+        const double alpha = scale ? *scale : 1.0;
+        const double2 a = ld2(u, i), dd = ld2(d, i);
+        st2(z, i, scale ? make_double2(dd.x * (alpha * a.x), dd.y * (alpha * a.y)) : make_double2(dd.x * a.x, dd.y * a.y));
+    }
+    __device__ void one(long long i) const { z[i] = scale ? d[i] * ((*scale) * u[i]) : d[i] * u[i]; }
+};
+
 // out = x + (*num / *den) * y: the p = z + beta*p half of residual_and_search_update (domain.okl:218-233)
 // when r = r+ is a buffer swap instead of a copy
 struct XpbyRatioDevOp
@@ -619,6 +636,14 @@ int fdd_vector_scaling_dev(double *au, const double *scale_dev, const double *u,
     if (n == 0) return 0;
     FDD_REQUIRE(au != nullptr && u != nullptr && scale_dev != nullptr);
     return launch_ew(ScaleDevOp{au, u, scale_dev}, n, fdd_aligned16(au) && fdd_aligned16(u), stream);
+}
+
+int fdd_vector_diagonal_scaling_dev(double *z, const double *d, const double *scale_dev, const double *u, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(z != nullptr && u != nullptr && d != nullptr);
+    return launch_ew(DiagScaleDevOp{z, d, u, scale_dev}, n, fdd_aligned16(z) && fdd_aligned16(u) && fdd_aligned16(d), stream);
 }
 
 int fdd_vector_scaling_rsqrt_dev(double *au, const double *norm2_dev, const double *u, int n, void *stream)

@@ -26,6 +26,13 @@ __global__ __launch_bounds__(kBlock) void scale_dev_f32_kernel(float *__restrict
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) au[i] = s * u[i];
 }
 
+// z = d .* ((*scale) * u), scale optional
+__global__ __launch_bounds__(kBlock) void diag_scale_dev_f32_kernel(float *__restrict__ z, const float *__restrict__ d, const double *__restrict__ scale, const float *__restrict__ u, long long n)
+{
+    const float s = scale ? (float)(*scale) : 1.0f;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) z[i] = scale ? d[i] * (s * u[i]) : d[i] * u[i];
+}
+
 // uv = alpha * u + beta * v
 __global__ __launch_bounds__(kBlock) void axpby_f32_kernel(float *uv, float alpha, const float *u, float beta, const float *v, long long n)
 {
@@ -97,6 +104,16 @@ int fdd_vector_scaling_dev_f32(float *au, const double *scale_dev, const float *
     if (n == 0) return 0;
     FDD_REQUIRE(au != nullptr && u != nullptr && scale_dev != nullptr);
     hipLaunchKernelGGL(scale_dev_f32_kernel, dim3(grid_for(n)), dim3(kBlock), 0, fdd_stream(stream), au, scale_dev, u, (long long)n);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fdd_vector_diagonal_scaling_dev_f32(float *z, const float *d, const double *scale_dev, const float *u, int n, void *stream)
+{
+    FDD_REQUIRE(n >= 0);
+    if (n == 0) return 0;
+    FDD_REQUIRE(z != nullptr && u != nullptr && d != nullptr);
+    hipLaunchKernelGGL(diag_scale_dev_f32_kernel, dim3(grid_for(n)), dim3(kBlock), 0, fdd_stream(stream), z, d, scale_dev, u, (long long)n);
     FDD_LAUNCH_CHECK();
     return 0;
 }

@@ -364,12 +364,26 @@ class RcclComm : public Comm
     {
         if (n <= 0) return;
         ok(group_start_(), "ncclGroupStart");
-        for (int i = 0; i < n; i++)
+        // a failing call must not leave the communicator in group mode: remember the first error, always close the
+        // group, throw afterwards
+        int first_rc = 0;
+        const char *first_what = nullptr;
+        for (int i = 0; i < n and first_rc == 0; i++)
         {
-            if (ops[i].send_bytes) ok(send_(const_cast<void *>(ops[i].send), ops[i].send_bytes, kInt8, ops[i].peer, comm_, dev().stream), "ncclSend");
-            if (ops[i].recv_bytes) ok(recv_(ops[i].recv, ops[i].recv_bytes, kInt8, ops[i].peer, comm_, dev().stream), "ncclRecv");
+            if (ops[i].send_bytes)
+            {
+                const int rc = send_(const_cast<void *>(ops[i].send), ops[i].send_bytes, kInt8, ops[i].peer, comm_, dev().stream);
+                if (rc != 0 and first_rc == 0) first_rc = rc, first_what = "ncclSend";
+            }
+            if (ops[i].recv_bytes and first_rc == 0)
+            {
+                const int rc = recv_(ops[i].recv, ops[i].recv_bytes, kInt8, ops[i].peer, comm_, dev().stream);
+                if (rc != 0 and first_rc == 0) first_rc = rc, first_what = "ncclRecv";
+            }
         }
-        ok(group_end_(), "ncclGroupEnd");
+        const int end_rc = group_end_();
+        if (first_rc != 0) ok(first_rc, first_what);
+        ok(end_rc, "ncclGroupEnd");
     }
     void barrier() override
     {

@@ -233,6 +233,18 @@ class CSR_Matrix
         std::vector<DType>().swap(val_hst);
     }
 
+    // ... and fetch them back from the device copies when a later setup step wants to walk the matrix again
+    void download_host()
+    {
+        if (num_nnz == 0 or not ptr.ptr()) return;
+        ptr_hst.resize(num_rows + 1);
+        col_hst.resize(num_nnz);
+        val_hst.resize(num_nnz);
+        ptr.copyTo(ptr_hst.data(), (size_t)(num_rows + 1) * sizeof(int));
+        col.copyTo(col_hst.data(), (size_t)num_nnz * sizeof(int));
+        val.copyTo(val_hst.data(), (size_t)num_nnz * sizeof(DType));
+    }
+
     void print(FILE *file_ptr = NULL, int offset = 0)
     {
         FILE *out = file_ptr ? file_ptr : fdd::globals().pstdout_file;
@@ -324,7 +336,7 @@ class CSR_Matrix
             FDD_CALL(fdd_set_to_value(Au.as<double>(), 0.0, num_rows, 0, fdd::dev().stream));
             return;
         }
-        fdd::ProfileScope prof(sell ? "sell_kernel<EpiPlain>" : plan_kind == 0 ? "csr_row_kernel<EpiPlain>" : "csr_block_kernel<EpiPlain>", algorithmic_bytes(false));
+        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiPlain>" : "csr_block_kernel<EpiPlain>", algorithmic_bytes(false));
         FDD_CALL(fdd_csr_plan_multiply(plan, Au.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), u.as<double>(), nullptr, fdd::dev().stream));
     }
 
@@ -350,7 +362,7 @@ class CSR_Matrix
             FDD_CALL(fdd_set_to_value(Au.as<double>(), 0.0, num_rows, 0, fdd::dev().stream));
             return;
         }
-        fdd::ProfileScope prof(sell ? "sell_kernel<EpiWeight>" : plan_kind == 0 ? "csr_row_kernel<EpiWeight>" : "csr_block_kernel<EpiWeight>", algorithmic_bytes(true));
+        fdd::ProfileScope prof(plan_kind == 0 ? "csr_row_kernel<EpiWeight>" : "csr_block_kernel<EpiWeight>", algorithmic_bytes(true));
         FDD_CALL(fdd_csr_plan_multiply(plan, Au.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), u.as<double>(), weight.as<double>(), fdd::dev().stream));
     }
 };

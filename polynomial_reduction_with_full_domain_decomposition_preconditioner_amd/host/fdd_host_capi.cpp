@@ -784,7 +784,8 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
         else if (s == "sub_use_preconditioner")
         {
             if (!p->subdomain) return fail("problem was created without a Subdomain");
-            p->subdomain->use_preconditioner = value != 0;
+            p->subdomain->use_preconditioner = value == 1;
+            p->subdomain->use_jacobi = value == 2;
         }
         else if (s == "amg_graph")
         {
@@ -1194,6 +1195,49 @@ int fddh_problem_sub_op(fddh_problem *p, int op, const double *in, double *out)
                 return fail("unknown subdomain op %d", op);
         }
         p->sb.copyTo(out, bytes);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return fail("%s", e.what());
+    }
+}
+
+int fddh_problem_sub_dof_op(fddh_problem *p, int op, const double *in, double *out, int n)
+{
+    try
+    {
+        if (!p || !in || !out) return fail("null argument");
+        if (!p->subdomain) return fail("problem was created without a Subdomain");
+        Subdomain<PType> &s = *p->subdomain;
+        if (not s.dof_space_available()) return fail("the inner iteration of this problem does not run in dof space");
+        if (n != s.dof_count()) return fail("dof vectors have %d entries, got %d", s.dof_count(), n);
+        if (op == 0)
+            s.host_operator_dofs(out, in);
+        else if (op == 1)
+        {
+            p->a.copyFrom(in, (size_t)p->fine().num_local_points * sizeof(double));
+            s.host_rhs_dofs(out, p->a);
+        }
+        else
+            return fail("unknown dof-space op %d", op);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return fail("%s", e.what());
+    }
+}
+
+int fddh_problem_sub_jacobi_diagonal(fddh_problem *p, double *out, int n)
+{
+    try
+    {
+        if (!p || !out) return fail("null argument");
+        if (!p->subdomain) return fail("problem was created without a Subdomain");
+        const std::vector<double> &d = p->subdomain->jacobi_diagonal();
+        if (n != p->subdomain->dofs()) return fail("the diagonal has %d entries, got %d", p->subdomain->dofs(), n);
+        for (int i = 0; i < n; i++) out[i] = d[i];
         return 0;
     }
     catch (const std::exception &e)

@@ -291,11 +291,15 @@ class Subdomain
         if (num_ring_points > 0) FDD_CALL(fdd_gather_indexed(Tu.as<double>() + own_points, recv_all.as<double>(), unpack_index.template as<int>(), nullptr, num_ring_points, stream));
         timer.stop("subdomain.tree_exchange.subdomain");
 
-        if (superdomain_operator.num_extended_dofs == 0) return;
+        // The all-gather is issued by EVERY rank, as the reference's MPI_Allgatherv is (subdomain.tpp:4620): whether a
+        // rank has a superdomain of its own is a per-rank fact (a rank whose rings already cover the whole domain has
+        // none while its peers do), and a collective gated on it would leave the peers waiting.  Only the local
+        // products below are skipped by such a rank.
         timer.start("subdomain.tree_exchange.superdomain");
         fdd::memory coarse = work_dev[0].slice(levels[num_levels - 1].offset, coarse_pad);
-        fdd::comm().allgather(coarse.ptr(), coarse_all.ptr(), (size_t)coarse_pad * sizeof(DType));
+        if (fdd::comm().size > 1 or superdomain_operator.num_extended_dofs > 0) fdd::comm().allgather(coarse.ptr(), coarse_all.ptr(), (size_t)coarse_pad * sizeof(DType));
         timer.stop("subdomain.tree_exchange.superdomain");
+        if (superdomain_operator.num_extended_dofs == 0) return;
 
         timer.start("subdomain.tree_construction.assemble_coarse");
         Qt_coarse.multiply(work_dev[1], coarse_all); // :4639
@@ -429,6 +433,222 @@ class Subdomain
         }
     }
 
+
+    // ------------------------------------------------------------------
+    // POINT-JACOBI in the inner solver's preconditioner slot -- a LABELLED OPTION of this build, not in the reference,
+    // whose slot holds the AMG V-cycle (use_preconditioner = true, subdomain.tpp:4373-4378) or the identity (dssum,
+    // :4379-4382).  z = Q Q_int D^-1 (Qt_int Qt r) with D = diag of the operator of the inner iteration over the
+    // unique dofs, (Qt A_L Q | A_sup).  Why: with the V-cycle off, four Krylov steps act on an operator whose rows
+    // are scaled very differently -- GLL clustering inside an element (diagonal 0.02 ... 0.8 at N = 7), and in the
+    // composite the coarse dofs that reduced-degree ring elements hang on (diagonal up to 6x the largest own row);
+    // unscaled, GMRES(4) spends its four steps on those few rows (tools/composite_operator_analysis.py).
+    // The diagonal is exact: sum of the element diagonals over a dof's points, and w^T A_e w for a dof that several
+    // points of one element interpolate from (hanging faces / edges, the J_cf rows of Q).
+    // ------------------------------------------------------------------
+    fdd::memory jacobi_dinv, jacobi_dinv_f32;
+    std::vector<double> jacobi_diag_hst; // the diagonal itself over the unique dofs (test hook)
+
+    // diagonal of the element operator D^T G D (domain.okl:5-98 / subdomain.okl:4-101): the coefficient of u(i,j,k) in Au(i,j,k)
+    static void element_diagonal(double *a, const std::vector<DType> &D, const double *const G[NUM_GEOM_FACTS], int n, int dim)
+    {
+        if (dim == 2)
+        {
+            for (int j = 0; j < n; j++)
+                for (int i = 0; i < n; i++)
+                {
+                    double v = 0.0;
+                    for (int p = 0; p < n; p++) v += D[i + p * n] * D[i + p * n] * G[0][p + j * n] + D[j + p * n] * D[j + p * n] * G[1][i + p * n];
+                    v += 2.0 * D[i + i * n] * D[j + j * n] * G[2][i + j * n];
+                    a[i + j * n] = v;
+                }
+            return;
+        }
+        const int nn = n * n;
+        for (int k = 0; k < n; k++)
+            for (int j = 0; j < n; j++)
+                for (int i = 0; i < n; i++)
+                {
+                    const int v0 = i + j * n + k * nn;
+                    double v = 0.0;
+                    for (int p = 0; p < n; p++)
+                        v += D[i + p * n] * D[i + p * n] * G[0][p + j * n + k * nn] + D[j + p * n] * D[j + p * n] * G[1][i + p * n + k * nn] + D[k + p * n] * D[k + p * n] * G[2][i + j * n + p * nn];
+                    const double di = D[i + i * n], dj = D[j + j * n], dk = D[k + k * n];
+                    v += 2.0 * (di * dj * G[3][v0] + di * dk * G[4][v0] + dj * dk * G[5][v0]);
+                    a[v0] = v;
+                }
+    }
+
+    // Au = D^T G D u on one element, host (setup only: the hanging dofs of the exact diagonal)
+    static void element_apply(double *Au, const double *u, const std::vector<DType> &D, const double *const G[NUM_GEOM_FACTS], int n, int dim)
+    {
+        const int nn = n * n, np = dim == 3 ? nn * n : nn;
+        std::vector<double> g1(np), g2(np), g3(np);
+        const int nk = dim == 3 ? n : 1;
+        for (int k = 0; k < nk; k++)
+            for (int j = 0; j < n; j++)
+                for (int i = 0; i < n; i++)
+                {
+                    const int v = i + j * n + k * nn;
+                    double d1 = 0.0, d2 = 0.0, d3 = 0.0;
+                    for (int p = 0; p < n; p++)
+                    {
+                        d1 += D[p + i * n] * u[p + j * n + k * nn];
+                        d2 += D[p + j * n] * u[i + p * n + k * nn];
+                        if (dim == 3) d3 += D[p + k * n] * u[i + j * n + p * nn];
+                    }
+                    if (dim == 3)
+                    {
+                        g1[v] = G[0][v] * d1 + G[3][v] * d2 + G[4][v] * d3;
+                        g2[v] = G[3][v] * d1 + G[1][v] * d2 + G[5][v] * d3;
+                        g3[v] = G[4][v] * d1 + G[5][v] * d2 + G[2][v] * d3;
+                    }
+                    else
+                    {
+                        g1[v] = G[0][v] * d1 + G[2][v] * d2;
+                        g2[v] = G[2][v] * d1 + G[1][v] * d2;
+                    }
+                }
+        for (int k = 0; k < nk; k++)
+            for (int j = 0; j < n; j++)
+                for (int i = 0; i < n; i++)
+                {
+                    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                    for (int p = 0; p < n; p++)
+                    {
+                        a1 += D[i + p * n] * g1[p + j * n + k * nn];
+                        a2 += D[j + p * n] * g2[i + p * n + k * nn];
+                        if (dim == 3) a3 += D[k + p * n] * g3[i + j * n + p * nn];
+                    }
+                    Au[i + j * n + k * nn] = a1 + a2 + a3;
+                }
+    }
+
+    void ensure_jacobi()
+    {
+        if (jacobi_dinv.ptr()) return;
+        CSR_Matrix<DType> &Q = subdomain_operator.Q;
+        const bool had_host = not Q.ptr_hst.empty();
+        if (not had_host) Q.download_host();
+        const int nse = subdomain_operator.num_extended_dofs, ns = subdomain_operator.num_dofs, nI = num_interface_dofs;
+        std::vector<double> diag_ext(std::max(nse, 1), 0.0);
+        std::vector<double> a, w, Aw, Gh[NUM_GEOM_FACTS];
+        struct Entry
+        {
+            int dof, point;
+            double weight;
+        };
+        std::vector<Entry> ent;
+        for (auto &ll : subdomain_operator.level_lists)
+        {
+            const int n = ll.poly_degree + 1, np = (int)std::lround(std::pow(n, dim));
+            const size_t total = (size_t)ll.num_elements * np;
+            for (int g = 0; g < NUM_GEOM_FACTS; g++)
+            {
+                Gh[g].resize(total);
+                if (total) FDD_CALL(fdd_memcpy_d2h(Gh[g].data(), ll.G[g], total * sizeof(double), fdd::dev().stream));
+            }
+            const std::vector<DType> &D = D_hat[ll.level].first;
+            a.resize(np);
+            w.resize(np);
+            Aw.resize(np);
+            for (int e = 0; e < ll.num_elements; e++)
+            {
+                const double *Ge[NUM_GEOM_FACTS];
+                for (int g = 0; g < NUM_GEOM_FACTS; g++) Ge[g] = Gh[g].data() + (size_t)e * np;
+                element_diagonal(a.data(), D, Ge, n, dim);
+                const int base = ll.first_offset + e * np;
+                bool plain = true; // every point of the element has at most one entry, of weight one: distinct dofs, no interpolation
+                for (int p = 0; p < np and plain; p++)
+                {
+                    const int t0 = Q.ptr_hst[base + p], t1 = Q.ptr_hst[base + p + 1];
+                    plain = t1 - t0 == 0 or (t1 - t0 == 1 and Q.val_hst[t0] == (DType)1.0);
+                }
+                if (plain)
+                {
+                    for (int p = 0; p < np; p++)
+                        for (int t = Q.ptr_hst[base + p]; t < Q.ptr_hst[base + p + 1]; t++) diag_ext[Q.col_hst[t]] += Q.val_hst[t] * Q.val_hst[t] * a[p];
+                    continue;
+                }
+                ent.clear();
+                for (int p = 0; p < np; p++)
+                    for (int t = Q.ptr_hst[base + p]; t < Q.ptr_hst[base + p + 1]; t++) ent.push_back(Entry{Q.col_hst[t], p, (double)Q.val_hst[t]});
+                std::sort(ent.begin(), ent.end(), [](const Entry &x, const Entry &y) { return x.dof != y.dof ? x.dof < y.dof : x.point < y.point; });
+                for (size_t b = 0; b < ent.size();)
+                {
+                    size_t e2 = b + 1;
+                    while (e2 < ent.size() and ent[e2].dof == ent[b].dof) e2++;
+                    if (e2 == b + 1)
+                        diag_ext[ent[b].dof] += ent[b].weight * ent[b].weight * a[ent[b].point];
+                    else
+                    {
+                        std::fill(w.begin(), w.end(), 0.0);
+                        for (size_t t = b; t < e2; t++) w[ent[t].point] += ent[t].weight;
+                        element_apply(Aw.data(), w.data(), D, Ge, n, dim);
+                        double v = 0.0;
+                        for (size_t t = b; t < e2; t++) v += ent[t].weight * Aw[ent[t].point];
+                        diag_ext[ent[b].dof] += v;
+                    }
+                    b = e2;
+                }
+            }
+        }
+        if (not had_host) Q.release_host();
+        // the unique dofs: [subdomain regular | interface] take the element sums; the superdomain's regular dofs (the
+        // subdomain's extended dofs among them) take their rows of A (operator_dofs / subdomain.tpp:3951)
+        jacobi_diag_hst.assign(std::max(num_dofs, 1), 1.0);
+        for (int d = 0; d < std::min(ns, num_dofs); d++) jacobi_diag_hst[d] = diag_ext[d];
+        if (superdomain_operator.num_extended_dofs > 0)
+        {
+            const CSR_Matrix<DType> &A = superdomain_operator.A;
+            for (int d = ns; d < num_dofs; d++)
+            {
+                const int row = nI + (d - ns);
+                double v = 0.0;
+                for (int t = A.ptr_hst[row]; t < A.ptr_hst[row + 1]; t++)
+                    if (A.col_hst[t] == row) v = A.val_hst[t];
+                jacobi_diag_hst[d] = v;
+            }
+        }
+        std::vector<double> inv(jacobi_diag_hst.size());
+        for (size_t d = 0; d < inv.size(); d++)
+        {
+            if (not(jacobi_diag_hst[d] > 0.0))
+            {
+                fprintf(stderr, "ERROR: Subdomain point-Jacobi: dof %zu has diagonal %g\n", d, jacobi_diag_hst[d]);
+                exit(EXIT_FAILURE);
+            }
+            inv[d] = 1.0 / jacobi_diag_hst[d];
+        }
+        jacobi_dinv = fdd::dev().malloc<DType>(inv.size());
+        jacobi_dinv.copyFrom(inv.data(), inv.size() * sizeof(DType));
+        jacobi_dinv_f32 = to_float(inv);
+    }
+
+    // the preconditioner slot of the reference-shaped loops with point-Jacobi in it: low_order_preconditioner
+    // (subdomain.tpp:3987-4159) with the V-cycle replaced by a division by the diagonal
+    void jacobi_preconditioner(fdd::memory &z, fdd::memory &r)
+    {
+        ensure_jacobi();
+        fdd::memory r_sub_l = r.slice(0, subdomain_operator.num_points);
+        fdd::memory z_sub_l = z.slice(0, subdomain_operator.num_points);
+        subdomain_operator.Qt.multiply(work_dev[0], r_sub_l);
+        copy_tail(work_dev[0], r);
+        fdd::memory *t = &work_dev[0];
+        if (not Qt_int.is_identity)
+        {
+            Qt_int.multiply(work_dev[1], work_dev[0]);
+            t = &work_dev[1];
+        }
+        FDD_CALL(fdd_vector_diagonal_scaling_dev(work_dev[2].as<double>(), jacobi_dinv.as<double>(), nullptr, t->template as<double>(), num_dofs, fdd::dev().stream));
+        if (Q_int.is_identity)
+            subdomain_operator.Q.multiply(z_sub_l, work_dev[2]);
+        else
+        {
+            Q_int.multiply(work_dev[0], work_dev[2]);
+            subdomain_operator.Q.multiply(z_sub_l, work_dev[0]);
+            copy_tail_back(z, work_dev[0]);
+        }
+    }
 
     // ------------------------------------------------------------------
     // The composite in DOF SPACE: what gmres_dofs works on when the region is a composite.
@@ -785,7 +1005,10 @@ class Subdomain
             sp.VA.resize(m + 1);
             for (auto &v : sp.VA) v = fdd::dev().malloc<float>(na);
         }
-        if (use_preconditioner and (int)sp.ZA.size() != m)
+        const bool jacobi = use_jacobi and not use_preconditioner;
+        const bool pre = use_preconditioner or jacobi;
+        if (jacobi) ensure_jacobi();
+        if (pre and (int)sp.ZA.size() != m)
         {
             for (auto &v : sp.ZA) v.free();
             sp.ZA.resize(m);
@@ -853,6 +1076,11 @@ class Subdomain
                     sp.ZA[j].copyFrom(amg_hierarchy.solution32(), (size_t)nd * sizeof(float));
                     operator_dofs_f32(sp.qa, sp.ZA[j]);
                 }
+                else if (jacobi)
+                {
+                    FDD_CALL(fdd_vector_diagonal_scaling_dev_f32(sp.ZA[j].template as<float>(), jacobi_dinv_f32.template as<float>(), inv_dev + j, W[j], nd, stream));
+                    operator_dofs_f32(sp.qa, sp.ZA[j]);
+                }
                 else
                     operator_dofs_f32(sp.qa, *Wm[j], inv_dev + j);
 
@@ -868,8 +1096,8 @@ class Subdomain
             }
             FDD_CALL(fdd_gmres_finish_dev(st, m, stream));
 
-            for (int i = 0; i < m; i++) ptrs[i] = use_preconditioner ? sp.ZA[i].template as<float>() : W[i];
-            const double *scales = use_preconditioner ? nullptr : inv_dev;
+            for (int i = 0; i < m; i++) ptrs[i] = pre ? sp.ZA[i].template as<float>() : W[i];
+            const double *scales = pre ? nullptr : inv_dev;
             if (lazy)
             {
                 const double *last_dev = nullptr;
@@ -942,7 +1170,7 @@ class Subdomain
     // the two exchanges of tree_operator alone, on their buffers' current contents (bench.py's communication timings)
     void comm_probe_coarse()
     {
-        if (not is_composite or superdomain_operator.num_extended_dofs == 0) return;
+        if (not is_composite or (fdd::comm().size == 1 and superdomain_operator.num_extended_dofs == 0)) return; // rank-uniform, like tree_exchange
         fdd::memory coarse = work_dev[0].slice(levels[num_levels - 1].offset, coarse_pad);
         fdd::comm().allgather(coarse.ptr(), coarse_all.ptr(), (size_t)coarse_pad * sizeof(DType));
     }
@@ -972,6 +1200,12 @@ class Subdomain
     int num_vectors = 4;
     int max_iterations = 4;
     bool use_preconditioner = true; // subdomain.hpp:231; the hierarchy is handed in (amg_add_level) or built on first use (amg_build)
+    bool use_jacobi = false;        // with use_preconditioner == false: point-Jacobi in the preconditioner slot instead of the identity (labelled option of this build)
+    const std::vector<double> &jacobi_diagonal()
+    {
+        ensure_jacobi();
+        return jacobi_diag_hst;
+    }
     DType tolerance = 1.0e-12;
     DType epsilon = 1.0e-12;
 
@@ -1607,6 +1841,8 @@ class Subdomain
         timer.start("subdomain.preconditioner");
         if (use_preconditioner)
             low_order_preconditioner(z_k, r_k);
+        else if (use_jacobi)
+            jacobi_preconditioner(z_k, r_k);
         else
             direct_stiffness_summation(z_k, r_k);
         timer.stop("subdomain.preconditioner");
@@ -1655,6 +1891,8 @@ class Subdomain
             timer.start("subdomain.preconditioner");
             if (use_preconditioner)
                 low_order_preconditioner(z_k, r_kp1);
+            else if (use_jacobi)
+                jacobi_preconditioner(z_k, r_kp1);
             else
                 direct_stiffness_summation(z_k, r_kp1);
             timer.stop("subdomain.preconditioner");
@@ -1690,7 +1928,7 @@ class Subdomain
     // 4 node passes per step instead of 3 + 2(j+1) + 1 SpMVs.
     bool can_restructure() const
     {
-        return not is_composite and subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0 and not use_preconditioner and num_vectors + 1 <= FDD_MULTI_MAX;
+        return not is_composite and subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0 and not use_preconditioner and not use_jacobi and num_vectors + 1 <= FDD_MULTI_MAX;
     }
 
     void gather_weighted(fdd::memory &t, fdd::memory &v)
@@ -1957,7 +2195,10 @@ class Subdomain
             qa.free();
             qa = fdd::dev().malloc<DType>(na);
         }
-        if (use_preconditioner and (int)ZA.size() != m)
+        const bool jacobi = use_jacobi and not use_preconditioner;
+        const bool pre = use_preconditioner or jacobi; // the preconditioned basis Z is kept
+        if (jacobi) ensure_jacobi();
+        if (pre and (int)ZA.size() != m)
         {
             for (auto &v : ZA) v.free();
             ZA.resize(m);
@@ -2022,6 +2263,12 @@ class Subdomain
                     ZA[j].copyFrom(fine.u, (size_t)nd * sizeof(DType));
                     operator_dofs(qa, ZA[j]);
                 }
+                else if (jacobi)
+                {
+                    // z~_j = D^-1 (inv_j W_j)
+                    FDD_CALL(fdd_vector_diagonal_scaling_dev(ZA[j].template as<double>(), jacobi_dinv.as<double>(), inv_dev + j, W[j], nd, stream));
+                    operator_dofs(qa, ZA[j]);
+                }
                 else
                     operator_dofs(qa, *Wm[j], inv_dev + j);
 
@@ -2044,7 +2291,7 @@ class Subdomain
                 const double *last_dev = nullptr;
                 FDD_CALL(fdd_gmres_last_column(st, &last_dev));
                 fdd::ProfileScope prof("ew_vec2_kernel<MultiAxpy>", 8.0 * nd * (m + 2));
-                if (use_preconditioner)
+                if (pre)
                 {
                     for (int i = 0; i < m; i++) ptrs[i] = ZA[i].template as<double>();
                     FDD_CALL(fdd_multi_lincomb_limited_dev(ua.as<double>(), 1, y_dev, ptrs.data(), nullptr, last_dev, m, nd, stream));
@@ -2074,7 +2321,7 @@ class Subdomain
             if (j_last >= 0)
             {
                 fdd::ProfileScope prof("ew_vec2_kernel<MultiAxpy>", 8.0 * nd * (j_last + (first_cycle ? 2 : 3)));
-                if (use_preconditioner)
+                if (pre)
                 {
                     for (int i = 0; i < j_last + 1; i++) ptrs[i] = ZA[i].template as<double>();
                     FDD_CALL(fdd_multi_lincomb_scaled_dev(ua.as<double>(), first_cycle ? 1 : 0, y_dev, ptrs.data(), nullptr, j_last + 1, nd, stream));
@@ -2109,7 +2356,10 @@ class Subdomain
             qa.free();
             qa = fdd::dev().malloc<DType>(std::max(nd, 1));
         }
-        if (use_preconditioner and (int)ZA.size() != m)
+        const bool jacobi = use_jacobi and not use_preconditioner;
+        const bool pre = use_preconditioner or jacobi;
+        if (jacobi) ensure_jacobi();
+        if (pre and (int)ZA.size() != m)
         {
             for (auto &v : ZA) v.free();
             ZA.resize(m);
@@ -2182,6 +2432,11 @@ class Subdomain
                     ZA[j].copyFrom(fine.u, (size_t)nd * sizeof(DType));
                     za = &ZA[j];
                 }
+                else if (jacobi)
+                {
+                    FDD_CALL(fdd_vector_diagonal_scaling_dev(ZA[j].template as<double>(), jacobi_dinv.as<double>(), nullptr, VA[j].template as<double>(), nd, stream));
+                    za = &ZA[j];
+                }
 
                 stiffness_from_dofs(q_k, *za);
                 gather_weighted(qa, q_k);
@@ -2250,7 +2505,7 @@ class Subdomain
             for (int i = 0; i < j + 1; i++)
             {
                 coeffs[i] = c_gmres[i];
-                ptrs[i] = use_preconditioner ? ZA[i].template as<double>() : VA[i].template as<double>();
+                ptrs[i] = pre ? ZA[i].template as<double>() : VA[i].template as<double>();
             }
             {
                 fdd::ProfileScope prof("ew_vec2_kernel<MultiAxpy>", 8.0 * nd * (j + 3));
@@ -2335,6 +2590,10 @@ class Subdomain
                 if (use_preconditioner)
                 {
                     low_order_preconditioner(Z[j], V[j]);
+                }
+                else if (use_jacobi)
+                {
+                    jacobi_preconditioner(Z[j], V[j]);
                 }
                 else
                 {
@@ -2443,6 +2702,34 @@ class Subdomain
         timer.stop("subdomain.vector_operations");
 
         num_iterations += iter;
+    }
+
+    // test / analysis hooks on the dof-space form of the inner iteration: y = (Qt A_L Q | A_sup) x on host vectors of
+    // dof_count() values, and the dof-space right-hand side of an outer point vector
+    int dof_count() const { return dof_space_size(); }
+    bool dof_space_available() const { return (assembled_inner and can_assemble()) or composite_dof_space(); }
+    void host_operator_dofs(double *y, const double *x)
+    {
+        const int nd = dof_space_size(), na = std::max(dof_alloc_size(), 1);
+        fdd::memory xa = fdd::dev().malloc<DType>(na), ya = fdd::dev().malloc<DType>(na);
+        FDD_CALL(fdd_set_to_value(xa.as<double>(), 0.0, na, 0, fdd::dev().stream));
+        xa.copyFrom(x, (size_t)nd * sizeof(DType));
+        operator_dofs(ya, xa);
+        ya.copyTo(y, (size_t)nd * sizeof(DType));
+        xa.free();
+        ya.free();
+    }
+    void host_rhs_dofs(double *y, fdd::memory &r_pts)
+    {
+        const int nd = dof_space_size(), na = std::max(dof_alloc_size(), 1);
+        fdd::memory ya = fdd::dev().malloc<DType>(na);
+        tree_operator(f, r_pts);
+        if (is_composite)
+            composite_rhs_dofs(ya, f);
+        else
+            gather_weighted(ya, f);
+        ya.copyTo(y, (size_t)nd * sizeof(DType));
+        ya.free();
     }
 
     // test hook: tree_operator is private in the reference too

@@ -386,6 +386,26 @@ class Problem:
         _H().call("fddh_problem_sub_op", self.h, code, _dp(np.ascontiguousarray(u)), _dp(out))
         return out
 
+    def sub_dof_operator(self, x):
+        """y = (Qt A_L Q | A_sup) x on the unique dofs of the inner iteration"""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros(len(x))
+        _H().call("fddh_problem_sub_dof_op", self.h, 0, _dp(x), _dp(y), len(x))
+        return y
+
+    def sub_jacobi_diagonal(self):
+        n = self.sub_info()["unique_dofs"]
+        d = np.zeros(n)
+        _H().call("fddh_problem_sub_jacobi_diagonal", self.h, _dp(d), n)
+        return d
+
+    def sub_dof_rhs(self, r):
+        """the dof-space right-hand side of the inner solve for the outer point vector r (collective on a composite)"""
+        n = self.sub_info()["unique_dofs"]
+        y = np.zeros(n)
+        _H().call("fddh_problem_sub_dof_op", self.h, 1, _dp(np.ascontiguousarray(r, dtype=np.float64)), _dp(y), n)
+        return y
+
     # --- low-order AMG preconditioner of the inner solve (hierarchy handed in) ---
     def sub_point_dofs(self):
         n = self.sub_info()["num_points"]

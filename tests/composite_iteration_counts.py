@@ -20,12 +20,15 @@ def worker(rank, world, port, e, N, red):
     res = {}
     for name, bl in (("block_local", True), ("composite", False)):
         p = H.Problem.box(E, Pg, N, red, True, block_local=bl)
-        p.set_options(max_iterations=400)
+        inner = int(os.environ.get("FDD_COUNTS_INNER", "4"))  # inner Krylov steps per application (subdomain.hpp:229-230: 4)
+        p.set_options(max_iterations=400, sub_num_vectors=inner, sub_max_iterations=inner)
         _, f = p.make_rhs(function_id=4, seed=1234 + rank)
-        for amg in (0, 1):
-            p.set_flag("sub_use_preconditioner", amg)
+        for mode, label in ((0, "inner GMRES(4) only"), (2, "inner GMRES(4) + point-Jacobi"), (1, "inner GMRES(4) + V-cycle")):
+            if mode == 1 and os.environ.get("FDD_COUNTS_NO_AMG"):
+                continue
+            p.set_flag("sub_use_preconditioner", mode)
             _, its, hist = p.solve(f, "fcg")
-            res["%s, V-cycle %s" % (name, "on" if amg else "off")] = (its, float(hist[-1] / hist[0]))
+            res["%s, %s" % (name, label)] = (its, float(hist[-1] / hist[0]))
         p.close()
     if rank == 0: print(json.dumps({"ranks": world, "elements": E, "N": N, "iterations": res}))
     dist.destroy_process_group()

@@ -800,6 +800,8 @@ int fdd_multi_axpy_norm2_scaled_dev_f32(double *out, double *ws, float *dst, con
     out[0] = acc;
     return 0;
 }
+int fdd_vector_diagonal_scaling_dev(double *z, const double *d, const double *sc, const double *u, int n, void *s) { (void)s; for (int i = 0; i < n; i++) z[i] = sc ? d[i] * ((*sc) * u[i]) : d[i] * u[i]; return 0; }
+int fdd_vector_diagonal_scaling_dev_f32(float *z, const float *d, const double *sc, const float *u, int n, void *s) { (void)s; const float f = sc ? (float)*sc : 1.0f; for (int i = 0; i < n; i++) z[i] = sc ? d[i] * (f * u[i]) : d[i] * u[i]; return 0; }
 int fdd_vector_scaling_dev_f32(float *au, const double *sc, const float *u, int n, void *s) { (void)s; const float f = (float)*sc; for (int i = 0; i < n; i++) au[i] = f * u[i]; return 0; }
 int fdd_vector_vector_addition_f32(float *uv, float a, const float *u, float b, const float *v, int n, void *s) { (void)s; for (int i = 0; i < n; i++) uv[i] = a * u[i] + b * v[i]; return 0; }
 int fdd_multi_lincomb_limited_dev_f32(float *q, int q_is_zero, const double *c, const float *const *v, const double *vs, const double *last, int m, int n, void *s)

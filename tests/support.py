@@ -115,6 +115,7 @@ def oracle():
         L.orc_subdomain_create.restype = vp
         L.orc_subdomain_residual_norm.restype = ctypes.c_double
         L.orc_amg_create.restype = vp
+        L.orc_f32_multi_axpy_norm2_scaled.restype = ctypes.c_double
         L.orc_fdd_create.restype = vp
         L.orc_fdd_subdomain.restype = vp
         L.orc_fdd_composite_levels.restype = ctypes.POINTER(ctypes.c_int)
@@ -450,6 +451,16 @@ class OracleSubdomain:
             self.L.orc_amg_set_level(self.amg, l, A.shape[0], arrs[0].ctypes.data_as(ip), arrs[1].ctypes.data_as(ip), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), *pargs)
         self.L.orc_subdomain_attach_amg(self.s, self.amg)
 
+    def jacobi_diagonal(self):
+        """point-Jacobi option: the diagonal of the inner iteration's operator over the unique dofs (oracle numbering)"""
+        d = np.zeros(self.num_dofs())
+        self.L.orc_subdomain_jacobi_diagonal(self.s, _p(d))
+        return d
+
+    def element_diagonal_check(self):
+        self.L.orc_subdomain_element_diagonal_check.restype = ctypes.c_double
+        return self.L.orc_subdomain_element_diagonal_check(self.s)
+
     def low_order_preconditioner(self, r):
         z = np.zeros(self.num_values)
         self.L.orc_subdomain_low_order_preconditioner(self.s, _p(z), _p(np.ascontiguousarray(r)))
@@ -608,6 +619,15 @@ class OracleFdd:
 
     def residual_norm(self, r, v):
         return self.L.orc_subdomain_residual_norm(self.sub(r), _p(np.ascontiguousarray(v)))
+
+    def jacobi_diagonal(self, r):
+        d = np.zeros(self.info[r]["unique_dofs"])
+        self.L.orc_subdomain_jacobi_diagonal(self.sub(r), _p(d))
+        return d
+
+    def element_diagonal_check(self, r):
+        self.L.orc_subdomain_element_diagonal_check.restype = ctypes.c_double
+        return self.L.orc_subdomain_element_diagonal_check(self.sub(r))
 
     def precondition(self, r, method="gmres", num_vectors=4, max_iterations=4, tolerance=1e-12, use_preconditioner=False):
         """r: one outer (own points) vector per rank; returns z per rank and the inner histories."""

@@ -99,8 +99,8 @@ def test_product_never_touches_the_oracle():
 
 def test_bench_uses_oracle_only_in_cpu_baseline():
     src = open(os.path.join(S.ROOT, "bench.py")).read()
-    head, _, tail = src.partition("def cpu_baseline(args):")
-    body, _, rest = tail.partition("\ndef main():")
-    assert "support" not in head and "oracle" not in head.replace("CPU oracle", "")
+    head, _, tail = src.partition("def cpu_baseline(args, world, P):")
+    body, _, rest = tail.partition("\nPMC_FILES")
+    assert "support" not in head and "oracle" not in head.replace("CPU oracle", "").replace("the oracle's N-rank world", "")
     assert "import support" in body
     assert "import support" not in rest

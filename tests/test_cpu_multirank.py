@@ -135,6 +135,30 @@ def _worker(rank, world, port, E, N, red, with_sub, mesh_dir=None, composite=Fal
                 assert np.abs(z - oz[rank]).max() <= 1e-9 * np.abs(oz[rank]).max(), method
                 assert np.abs(hist - oh[rank]).max() <= 1e-9 * oh[rank][0], method
 
+            # the point-Jacobi option (labelled: not in the reference): the exact diagonal of the inner iteration's
+            # operator against the oracle's (formed from Qt_int, Qt, A, Q, Q_int as they stand) and, for a sample of
+            # dofs, against the operator itself applied to unit vectors; then the preconditioner application with it
+            if not reference_shaped:
+                to_oracle = S.composite_dof_permutation(p.sub_point_dofs(), F.point_dofs(rank), si["sub_dofs"], si["unique_dofs"])
+                dj, od = p.sub_jacobi_diagonal(), F.jacobi_diagonal(rank)
+                assert F.element_diagonal_check(rank) <= 1e-12
+                assert np.abs(dj - od[to_oracle]).max() <= 1e-12 * np.abs(od).max()
+                n_u = si["unique_dofs"]
+                x = np.zeros(n_u)
+                for d in [] if curved == "quad" else np.unique(  # 2-D regions run the reference-shaped point-space loops: no dof-space operator to probe
+np.concatenate([np.arange(n_u - min(n_u, 40), n_u), np.random.default_rng(3).integers(0, n_u, 60), np.argsort(dj)[-20:]])
+                ):
+                    x[d] = 1.0
+                    assert abs(p.sub_dof_operator(x)[d] - dj[d]) <= 1e-12 * np.abs(dj).max(), d
+                    x[d] = 0.0
+            p.set_flag("sub_use_preconditioner", 2)
+            for method in ("gmres", "fcg"):
+                z, hist = p.precond_apply(us[rank], method)
+                oz, oh = F.precondition(us, method, use_preconditioner=2)
+                assert np.abs(z - oz[rank]).max() <= 1e-9 * np.abs(oz[rank]).max(), ("jacobi", method)
+                assert np.abs(hist - oh[rank]).max() <= 1e-9 * oh[rank][0], ("jacobi", method)
+            p.set_flag("sub_use_preconditioner", 0)
+
             # the collectives of the solve path alone (what bench.py reports as comm_us): a collective call
             ct = p.comm_time(2)
             assert ct["ring_exchange"]["bytes"] > 0 and ct["coarse_allgather"]["bytes"] > 0 and ct["interface_pair_allreduce"]["bytes"] == 16 * p.info["num_interface_slots"]
@@ -190,6 +214,7 @@ def test_host_layer_multirank_gloo(cpu_host_lib, world, with_sub):
     (2, (16, 4, 4), 3, 2, (2, 1)),   # two rings per polynomial level
     (2, (16, 4, 4), 3, 2, (2, 2)),   # both overlaps 2
     (3, (12, 4, 4), 3, 2, (1, 1)),   # a rank count that is not a power of two: the middle rank has two neighbours
+    (3, (6, 2, 2), 3, 2, (1, 1)),    # the middle rank's rings cover the whole domain: it has NO superdomain while its peers do (the coarse all-gather must still be issued by all three)
 ])
 def test_full_domain_decomposition_composite_gloo(cpu_host_lib, world, E, N, red, overlaps):
     """The composite of SURVEY 8(f) next-1 from the host layer under a gloo group -- neighbour rings at reduced

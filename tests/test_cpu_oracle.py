@@ -371,3 +371,73 @@ def test_uncoarsened_degree_one_composite_is_the_global_operator():
     finally:
         W.close()
         F.close()
+
+
+# ------------------------------------------------------------------ the float twins (oracle/fdd_oracle_f32.c)
+@pytest.mark.parametrize("N", [1, 3, 7, 15])
+def test_float_oracle_twins_against_the_double_oracle(N):
+    """The IEEE-single restatement of the inner solve's kernels (PTYPE = Float = float) is the double restatement
+    rounded: element stiffness with the scatter and the scale fused into the load within single precision of the double
+    kernels on the same values, and bit-identical to numpy's float32 arithmetic where that is one rounded operation."""
+    L = S.oracle()
+    vp = ctypes.c_void_p
+    f32 = np.float32
+    n3 = (N + 1) ** 3
+    E = 5
+    rng = np.random.default_rng(40 + N)
+    G = [rng.uniform(0.5, 1.5, E * n3) if g < 3 else rng.uniform(-0.2, 0.2, E * n3) for g in range(6)]
+    D = np.ascontiguousarray(S.gll(N)[2])
+    ndof = E * n3 // 2
+    pd = rng.integers(-1, ndof, E * n3).astype(np.int32)
+    v = rng.uniform(-1, 1, ndof)
+    scale = 0.61
+    u = np.where(pd >= 0, scale * v[np.maximum(pd, 0)], 0.0)
+    GDu = [np.zeros(E * n3) for _ in range(3)]
+    Au = np.zeros(E * n3)
+    gd = (vp * 3)(*[a.ctypes.data for a in GDu])
+    gg = (vp * 6)(*[a.ctypes.data for a in G])
+    L.orc_dom_stiffness_matrix_1(gd, S._p(u), S._p(D), gg, E * n3, N, 3)
+    L.orc_dom_stiffness_matrix_2(S._p(Au), gd, S._p(D), E * n3, N, 3)
+    G32 = [g.astype(f32) for g in G]
+    D32, v32, sc32 = D.astype(f32), v.astype(f32), np.array([scale]).astype(f32)
+    Au32 = np.zeros(E * n3, f32)
+    gg32 = (vp * 6)(*[a.ctypes.data for a in G32])
+    L.orc_f32_sub_stiffness(vp(Au32.ctypes.data), vp(v32.ctypes.data), vp(pd.ctypes.data), vp(sc32.ctypes.data), vp(D32.ctypes.data), gg32, E, N)
+    assert np.abs(Au32 - Au).max() <= 2e-5 * np.abs(Au).max()
+    assert not np.array_equal(Au32.astype(np.float64), Au)
+
+    n = 10007
+    a, b = rng.uniform(-1, 1, n).astype(f32), rng.uniform(-1, 1, n).astype(f32)
+    out = np.zeros(n, f32)
+    L.orc_f32_vector_vector_addition(vp(out.ctypes.data), ctypes.c_float(1.25), vp(a.ctypes.data), ctypes.c_float(-0.7), vp(b.ctypes.data), n)
+    assert np.array_equal(out, (f32(1.25) * a).astype(f32) + (f32(-0.7) * b).astype(f32))
+    L.orc_f32_vector_scaling(vp(out.ctypes.data), ctypes.c_double(1 / 3), vp(a.ctypes.data), n)
+    assert np.array_equal(out, f32(1 / 3) * a)
+    bs = [b, a]
+    pp = (vp * 2)(*[x.ctypes.data for x in bs])
+    sc = np.array([0.5, 2.0])
+    dots = np.zeros(2)
+    L.orc_f32_multi_inner_product_scaled(S._p(dots), vp(a.ctypes.data), pp, S._p(sc), 2, n)
+    for k in range(2):
+        ref = math.fsum(a.astype(np.float64) * (sc[k] * bs[k].astype(np.float64)))
+        assert abs(dots[k] - ref) <= 1e-13 * np.sum(np.abs(a.astype(np.float64) * bs[k].astype(np.float64))) * sc[k]
+    dst = np.zeros(n, f32)
+    c = np.array([0.3, -0.8])
+    nrm = L.orc_f32_multi_axpy_norm2_scaled(vp(dst.ctypes.data), vp(a.ctypes.data), S._p(c), ctypes.c_double(-1.0), pp, S._p(sc), 2, n)
+    full = a.astype(np.float64) - (c[0] * sc[0]) * b.astype(np.float64) - (c[1] * sc[1]) * a.astype(np.float64)
+    assert np.abs(dst - full).max() <= 6e-8 * np.abs(full).max()  # one rounding to float
+    assert abs(nrm - np.sum(dst.astype(np.float64) ** 2)) <= 1e-12 * nrm
+
+
+def test_element_diagonal_closed_form_against_the_kernels():
+    """The point-Jacobi option's element diagonal (closed form read off subdomain.okl:4-101) equals the restated
+    kernels applied to unit vectors: deformed 3-D elements (all six factors non-zero) and a deformed 2-D mesh."""
+    cases = (
+        (4, lambda d: S.DeformedMesh((2, 2, 2), d, 0.05)),
+        (3, lambda d: S.QuadMeshRanks((3, 2), d, (1, 1), 0, amplitude=0.04)),
+    )
+    for deg, make in cases:
+        sd = S.OracleSubdomain(None, deg, 2, meshes=[make(d) for d in S.level_degrees(deg, 2)])
+        assert sd.element_diagonal_check() <= 1e-12
+        assert np.all(sd.jacobi_diagonal() > 0)
+        sd.close()

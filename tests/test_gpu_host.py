@@ -463,3 +463,73 @@ def test_single_precision_preconditioner(gpu):
         z64b, _ = p.precond_apply(r, "gmres")
         assert np.array_equal(z64b, z64)
         p.close()
+
+
+@pytest.mark.parametrize("E,N,red", [((4, 4, 4), 3, 2), ((3, 3, 3), 7, 6)])
+def test_point_jacobi_option(setup, E, N, red):
+    """Point-Jacobi in the inner solver's preconditioner slot ("sub_use_preconditioner" = 2; a labelled option of
+    this build, not in the reference): the exact diagonal of the inner iteration's operator against the oracle's and
+    against the operator applied to unit vectors, the preconditioner application (GMRES and flexible CG, every launch
+    sequence) and the outer solve against the oracle with the same option, the float path against the double one."""
+    p = make_problem(E, N, red, True)
+    m = S.ArrayMesh.from_problem(p)
+    W = S.OracleWorld([m], N)
+    sd = oracle_subdomain(p, N, red)
+    try:
+        assert sd.element_diagonal_check() <= 1e-12
+        n_u = p.sub_info()["unique_dofs"]
+        dj, od = p.sub_jacobi_diagonal(), sd.jacobi_diagonal()
+        pd, opd = p.sub_point_dofs(), sd.point_dofs()
+        has = pd >= 0
+        assert np.array_equal(has, opd >= 0)
+        assert np.abs(dj[pd[has]] - od[opd[has]]).max() <= 1e-12 * od.max()  # numberings differ: compare through the points
+        x = np.zeros(n_u)
+        for d in np.random.default_rng(1).integers(0, n_u, 40):
+            x[d] = 1.0
+            assert abs(p.sub_dof_operator(x)[d] - dj[d]) <= 1e-12 * dj.max()
+            x[d] = 0.0
+
+        p.set_flag("sub_use_preconditioner", 2)
+        r = S.seeded_uniform(p.n, 5) - 0.5
+        for method in ("gmres", "fcg"):
+            oz, _, ohist = sd.solve(r, method, use_preconditioner=2)
+            z, hist = p.precond_apply(r, method)
+            assert np.abs(hist - ohist).max() <= 1e-10 * ohist[0], method
+            assert np.abs(z - oz).max() <= 1e-10 * np.abs(oz).max(), method
+        # the reference-shaped launch sequence (point-space vectors, SpMV chain, host scalars) runs the same option
+        for flag in ("assembled_inner_solve", "restructured_inner_solve", "fused_dssum", "device_bookkeeping"):
+            p.set_flag(flag, 0)
+        z2, hist2 = p.precond_apply(r, "gmres")
+        oz, _, ohist = sd.solve(r, "gmres", use_preconditioner=2)
+        assert np.abs(hist2 - ohist).max() <= 1e-10 * ohist[0]
+        assert np.abs(z2 - oz).max() <= 1e-10 * np.abs(oz).max()
+        for flag in ("assembled_inner_solve", "restructured_inner_solve", "fused_dssum", "device_bookkeeping"):
+            p.set_flag(flag, 1)
+
+        _, f = p.make_rhs_from(S.seeded_uniform(p.n, 1234))
+        u, its, hist = p.solve(f, "fcg")
+
+        def pre(zz, rr):
+            out, _, _ = sd.solve(rr[0], "gmres", use_preconditioner=2)
+            zz[0][:] = out
+
+        ou, oits, ohist = W.solve([f], "fcg", precond=pre)
+        assert its == oits
+        assert np.abs(hist - ohist).max() <= 1e-8 * ohist[0]
+        assert np.abs(u - ou[0]).max() <= 1e-9 * np.abs(ou[0]).max()
+        p.set_flag("sub_use_preconditioner", 0)
+        _, its_plain, _ = p.solve(f, "fcg")
+        assert its <= its_plain  # what the option is for
+        p.set_flag("sub_use_preconditioner", 2)
+
+        z64, h64 = p.precond_apply(r, "gmres")
+        p.set_flag("preconditioner_precision", 32)
+        z32, h32 = p.precond_apply(r, "gmres")
+        u32, its32, hist32 = p.solve(f, "fcg")
+        assert np.abs(z32 - z64).max() <= 1e-5 * np.abs(z64).max() and not np.array_equal(z32, z64)
+        assert abs(its32 - its) <= 1 and hist32[-1] <= 1e-7 * hist32[0] * 1.0001
+        p.set_flag("preconditioner_precision", 64)
+    finally:
+        sd.close()
+        W.close()
+        p.close()
