@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--amg-precision", type=int, choices=[64, 32], default=64, help="the reference's `Float` (config.hpp:19-20, AMG/config.hpp:4): the preconditioner (inner Krylov solve and V-cycle) in double (default) or float")
     ap.add_argument("--no-amg-graph", action="store_true", help="with --amg: launch the V-cycle kernel by kernel (so that --kernel-table shows them) instead of replaying its hipGraph")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N>1 ranks all on cuda:0 with a gloo group staging device buffers over the host: exercises the multi-rank code path on a one-GPU box (not a measurement)")
+    ap.add_argument("--rehearse-ranks", type=int, default=0, help="run N ranks as N host threads of THIS process on cuda:0 (no launcher; collectives are device-to-device copies between the ranks' buffers): exercises the N-rank code path, up to 2x2x2 = 8 ranks, on a one-GPU box (not a measurement)")
     ap.add_argument("--kernel-table", action="store_true", help="time every instrumented kernel family in the timed region (fills `kernels`; costs ~8 %% of a step)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events around the kernels of the timed region (no roofline object): how much the instrumentation costs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -180,10 +181,40 @@ def pmc_traffic(kernel_key, elements, degree):
     return (None, None) if best is None else (best["hbm_bytes_per_launch"], source)
 
 
+class _ThreadRanks:
+    """max over the ranks of an in-process rehearsal (ranks are threads of this process)"""
+
+    def __init__(self, n):
+        import threading
+
+        self.n, self.vals, self.barrier = n, [0.0] * n, threading.Barrier(n)
+
+    def max(self, rank, x):
+        self.vals[rank] = x
+        self.barrier.wait()
+        m = max(self.vals)
+        self.barrier.wait()
+        return m
+
+
 def main():
     args = parse()
-    import numpy as np
     import torch
+
+    if args.rehearse_ranks > 1:
+        # N ranks as N host threads of THIS process, all on cuda:0, each with its own stream; collectives are
+        # device-to-device copies between the ranks' buffers (host/comm.hpp LocalComm).  The multi-rank code path of a
+        # rank -- composite, ring pull, coarse all-gather, interface exchange -- is the one RCCL serves on a node; the
+        # timings are NOT a scaling measurement (the ranks share one GPU).  More than 6 ranks cannot be rehearsed as
+        # processes on the pool's boxes (process guard), hence threads.
+        from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
+
+        torch.cuda.set_device(0)
+        R = args.rehearse_ranks
+        args.gpus = R
+        group = _ThreadRanks(R)
+        H.run_local_ranks(R, lambda r, w: run(args, r, w, lambda x, r=r: group.max(r, x), "in-process rehearsal: %d ranks as threads sharing cuda:0 (LocalComm, device-to-device copies)" % w))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,7 +237,6 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
-    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
 
     H.init(local_rank, use_torch_stream=True)
     H.set_print(False)
@@ -219,17 +249,30 @@ def main():
     else:
         H.comm_torch_callbacks(on_gpu=True)
 
-    P = H.rank_grid(world)
-    e = args.elements
-    E = tuple(e * p for p in P)
-    N = args.degree
-
     def max_over_ranks(x):
         if world == 1:
             return x
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    run(args, rank, world, max_over_ranks, "single" if world == 1 else ("gloo-staged rehearsal on one GPU" if args.rehearse_on_one_gpu else args.comm))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run(args, rank, world, max_over_ranks, comm_label):
+    """one rank's bench: the communicator of the calling thread is set up"""
+    import numpy as np
+    import torch
+
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
+    from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
+
+    P = H.rank_grid(world)
+    e = args.elements
+    E = tuple(e * p for p in P)
+    N = args.degree
 
     def create(block_local):
         """A failure on one rank leaves the others inside the composite's setup collectives: report it and leave with a
@@ -455,7 +498,7 @@ def main():
             "points_per_gpu": info["num_local_points"],
             "unique_nodes": nodes,
             "preconditioner": pre_name,
-            "comm": "single" if world == 1 else ("gloo-staged rehearsal on one GPU" if args.rehearse_on_one_gpu else args.comm),
+            "comm": comm_label,
         },
         "points_updates_per_s": info["num_local_points"] * world * args.steps / dt,
         "last_residual_norm": last_res,
@@ -486,8 +529,6 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     prob.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -45,6 +45,14 @@ int fddh_comm_callbacks(int rank, int size, void *ctx, fddh_allreduce_fn allredu
  * recv_bytes[i] from peers[i] arrive in recv[i] (device buffers of this rank; either side may be 0). */
 typedef int (*fddh_exchange_fn)(void *ctx, int n, const int *peers, const void *const *send, const long long *send_bytes, void *const *recv, const long long *recv_bytes);
 int fddh_comm_callbacks_ex(int rank, int size, void *ctx, fddh_allreduce_fn allreduce_sum_f64, fddh_allreduce_fn allreduce_max_f64, fddh_allgather_fn allgather_bytes, fddh_barrier_fn barrier, fddh_exchange_fn exchange_bytes);
+/* Several ranks inside ONE process, each on its own host thread (every fddh_* entry acts on the calling thread's rank:
+ * device stream, communicator, timer and print switches are per thread), sharing one GPU: collectives are device-to-device
+ * copies and rank-ordered sums between the ranks' buffers.  For rehearsing the N-rank path where RCCL cannot be used (it
+ * admits one rank per device): create the world once, then every rank thread calls fddh_init (own stream) and
+ * fddh_comm_local with its rank. */
+int fddh_local_world_create(void **world, int size);
+int fddh_local_world_destroy(void *world);
+int fddh_comm_local(void *world, int rank);
 int fddh_comm_info(int *rank, int *size, char *name, size_t name_len);
 /* run every collective of the active communicator once on n doubles and verify the results */
 int fddh_comm_selftest(int n);

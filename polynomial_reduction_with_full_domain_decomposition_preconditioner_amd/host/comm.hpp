@@ -12,7 +12,11 @@
  *                 kernel library carries no link-time dependency on it);
  *   - CallbackComm: the collectives are supplied by the embedding process
  *                 through C function pointers (torch.distributed: "nccl" on
- *                 GPUs, "gloo" in the CPU tests).
+ *                 GPUs, "gloo" in the CPU tests);
+ *   - LocalComm:  several ranks inside ONE process, one host thread and one
+ *                 stream each, sharing one GPU: collectives are device-to-device
+ *                 copies and sums between the ranks' buffers (rehearsal of the
+ *                 N-rank path on a one-GPU box; RCCL admits one rank per device).
  * gs_add becomes: scatter the prefix into a dense interface-slot vector,
  * all-reduce it, gather back (slots = sorted unique global ids that appear in
  * any rank's prefix).
@@ -29,7 +33,11 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -115,7 +123,7 @@ class Comm
             }
             ops.push_back(op);
         }
-        if (not ops.empty()) exchange(ops.data(), (int)ops.size());
+        exchange(ops.data(), (int)ops.size()); // also with no peers: every rank of the world takes part in the call
         for (const ExchangeOp &op : ops)
         {
             if (op.recv_bytes)
@@ -393,9 +401,174 @@ class RcclComm : public Comm
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Several ranks in one process.  The per-rank state of the host layer (device stream, communicator, globals, timer,
+// profiler) is thread_local: a rank is a host thread, as in the reference (one MPI rank = one host thread), and
+// nothing stops several of them from living in one process and sharing a GPU.  RCCL cannot connect them (one rank per
+// device and communicator), so this back-end moves the data itself: every collective is
+//   finish my stream | publish my pointers | meet | copy / sum from the peers' DEVICE buffers on my stream | finish | meet
+// Sums run in rank order on every rank: all ranks get bit-identical results, like a ring all-reduce's.
+// Used by the 4- and 8-rank tests and the bench rehearsal on the one-GPU box; not a performance path.
+// ---------------------------------------------------------------------------------------------------------------
+struct LocalWorld
+{
+    const int size;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    long generation = 0;
+    bool failed = false;
+    std::vector<void *> buf;                     // all-reduce operands
+    std::vector<const void *> send;              // all-gather operands
+    std::vector<std::vector<ExchangeOp>> ops;    // exchange operands
+    int timeout_seconds = 300;
+
+    explicit LocalWorld(int n) : size(n), buf(n, nullptr), send(n, nullptr), ops(n) {}
+
+    void fail()
+    {
+        std::lock_guard<std::mutex> lock(m);
+        failed = true;
+        cv.notify_all();
+    }
+
+    // every rank arrives; a rank that never does (it failed elsewhere) turns into an error after the timeout, not a hang
+    void meet()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        if (failed) throw CommError("local world: a peer rank failed");
+        const long gen = generation;
+        if (++arrived == size)
+        {
+            arrived = 0;
+            generation++;
+            cv.notify_all();
+            return;
+        }
+        const bool ok = cv.wait_for(lock, std::chrono::seconds(timeout_seconds), [&] { return generation != gen or failed; });
+        if (not ok or failed)
+        {
+            failed = true;
+            cv.notify_all();
+            throw CommError(ok ? "local world: a peer rank failed" : "local world: timed out waiting for a peer rank (collective mismatch?)");
+        }
+    }
+};
+
+class LocalComm : public Comm
+{
+    std::shared_ptr<LocalWorld> w_;
+    memory tmp_;
+    size_t tmp_n_ = 0;
+
+    double *scratch(size_t n)
+    {
+        if (n > tmp_n_)
+        {
+            tmp_.free();
+            tmp_ = dev().malloc<double>(n);
+            tmp_n_ = n;
+        }
+        return tmp_.as<double>();
+    }
+
+    void reduce(double *buf, size_t n, bool max)
+    {
+        if (n == 0) return;
+        void *stream = dev().stream;
+        dev().finish();
+        w_->buf[rank] = buf;
+        w_->meet();
+        double *t = scratch(n);
+        try
+        {
+            if (max)
+            {
+                // small vectors only (timers, setup flags): through the host
+                std::vector<double> acc(n), one(n);
+                for (int r = 0; r < size; r++)
+                {
+                    FDD_CALL(fdd_memcpy_d2h(one.data(), w_->buf[r], n * sizeof(double), stream));
+                    for (size_t i = 0; i < n; i++) acc[i] = (r == 0) ? one[i] : std::max(acc[i], one[i]);
+                }
+                FDD_CALL(fdd_memcpy_h2d(t, acc.data(), n * sizeof(double), stream));
+            }
+            else
+            {
+                FDD_CALL(fdd_memcpy_d2d(t, w_->buf[0], n * sizeof(double), stream));
+                for (int r = 1; r < size; r++) FDD_CALL(fdd_vector_vector_addition(t, 1.0, t, 1.0, (const double *)w_->buf[r], (int)n, stream));
+            }
+            dev().finish();
+        }
+        catch (...)
+        {
+            w_->fail();
+            throw;
+        }
+        w_->meet(); // every rank has read every operand
+        FDD_CALL(fdd_memcpy_d2d(buf, t, n * sizeof(double), stream));
+    }
+
+  public:
+    LocalComm(std::shared_ptr<LocalWorld> world, int rank_) : w_(std::move(world))
+    {
+        rank = rank_;
+        size = w_->size;
+    }
+    const char *name() const override { return "local"; }
+    void allreduce_sum(double *buf, size_t n) override { reduce(buf, n, false); }
+    void allreduce_max(double *buf, size_t n) override { reduce(buf, n, true); }
+    void allgather(const void *send_dev, void *recv_dev, size_t bytes) override
+    {
+        void *stream = dev().stream;
+        dev().finish();
+        w_->send[rank] = send_dev;
+        w_->meet();
+        for (int r = 0; r < size; r++)
+            if (bytes) FDD_CALL(fdd_memcpy_d2d((char *)recv_dev + (size_t)r * bytes, w_->send[r], bytes, stream));
+        dev().finish();
+        w_->meet();
+    }
+    void exchange(const ExchangeOp *ops, int n) override
+    {
+        // like the other back-ends this is collective among the ranks that exchange; here every rank of the world
+        // must call it (a rank without peers passes n = 0), because the meeting point is world-wide
+        void *stream = dev().stream;
+        dev().finish();
+        w_->ops[rank].assign(ops, ops + std::max(n, 0));
+        w_->meet();
+        std::string error;
+        for (int i = 0; i < n and error.empty(); i++)
+        {
+            if (ops[i].recv_bytes == 0) continue;
+            const ExchangeOp *theirs = nullptr;
+            for (const ExchangeOp &o : w_->ops[ops[i].peer])
+                if (o.peer == rank) theirs = &o;
+            if (theirs == nullptr or theirs->send_bytes != ops[i].recv_bytes)
+                error = "local world: rank " + std::to_string(rank) + " expects " + std::to_string(ops[i].recv_bytes) + " bytes from rank " + std::to_string(ops[i].peer) + ", which sends " + std::to_string(theirs ? theirs->send_bytes : 0);
+            else
+                FDD_CALL(fdd_memcpy_d2d(ops[i].recv, theirs->send, ops[i].recv_bytes, stream));
+        }
+        if (not error.empty())
+        {
+            w_->fail();
+            throw CommError(error);
+        }
+        dev().finish();
+        w_->meet();
+    }
+    void barrier() override
+    {
+        dev().finish();
+        w_->meet();
+    }
+};
+
+// the communicator of the calling rank (= host thread)
 inline Comm *&comm_ptr()
 {
-    static Comm *c = new SingleComm();
+    static thread_local Comm *c = new SingleComm();
     return c;
 }
 

@@ -1,5 +1,5 @@
 /*
- * config.hpp -- process-wide state shared by the host classes, the role of the
+ * config.hpp -- per-rank (= per host thread) state shared by the host classes, the role of the
  * reference's config.hpp (globals dim / proc_id / num_procs / device, the
  * rstdout / pstdout macros and quit()).  The device and communicator objects
  * live in fdd_device.hpp / comm.hpp.
@@ -35,7 +35,7 @@ struct globals_t
 
 inline globals_t &globals()
 {
-    static globals_t g;
+    static thread_local globals_t g; // per rank = per host thread
     return g;
 }
 

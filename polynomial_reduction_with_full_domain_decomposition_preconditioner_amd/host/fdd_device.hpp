@@ -44,9 +44,11 @@ struct device_t
     void finish() { FDD_CALL(fdd_stream_sync(stream)); }
 };
 
+// the device handle of the calling rank: one rank = one host thread (the reference's model), so the state is
+// thread_local and several ranks may live in one process (LocalComm, comm.hpp)
 inline device_t &dev()
 {
-    static device_t d;
+    static thread_local device_t d;
     return d;
 }
 
@@ -208,7 +210,7 @@ class KernelProfiler
 
 inline KernelProfiler &profiler()
 {
-    static KernelProfiler p;
+    static thread_local KernelProfiler p;
     return p;
 }
 

@@ -168,6 +168,44 @@ int fddh_comm_single(void)
     }
 }
 
+int fddh_local_world_create(void **world, int size)
+{
+    try
+    {
+        if (!world || size < 1) return fail("bad argument");
+        *world = new std::shared_ptr<fdd::LocalWorld>(new fdd::LocalWorld(size));
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return fail("%s", e.what());
+    }
+}
+
+int fddh_local_world_destroy(void *world)
+{
+    delete static_cast<std::shared_ptr<fdd::LocalWorld> *>(world);
+    return 0;
+}
+
+int fddh_comm_local(void *world, int rank)
+{
+    try
+    {
+        if (!world) return fail("null argument");
+        std::shared_ptr<fdd::LocalWorld> w = *static_cast<std::shared_ptr<fdd::LocalWorld> *>(world);
+        if (rank < 0 || rank >= w->size) return fail("bad rank");
+        fdd::set_comm(new fdd::LocalComm(w, rank));
+        fdd::globals().proc_id = rank;
+        fdd::globals().num_procs = w->size;
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return fail("%s", e.what());
+    }
+}
+
 int fddh_comm_rccl_unique_id(char *out128)
 {
     try

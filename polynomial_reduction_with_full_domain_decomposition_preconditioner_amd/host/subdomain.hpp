@@ -285,7 +285,7 @@ class Subdomain
         timer.start("subdomain.tree_exchange.subdomain");
         // level 0 of the tree is `u` itself, the restricted levels are in work_dev[0] at their tree offsets
         if (num_send_points > 0) FDD_CALL(fdd_gather_indexed_split(send_all.as<double>(), u.as<double>(), work_dev[0].as<double>(), levels[0].num_points, send_index.template as<int>(), num_send_points, stream));
-        if (not exchange_ops.empty()) fdd::comm().exchange(exchange_ops.data(), (int)exchange_ops.size());
+        fdd::comm().exchange(exchange_ops.data(), (int)exchange_ops.size()); // every rank calls it (a rank without peers passes none): one back-end meets world-wide
         // the rank's own elements: the level-0 slice (:4630); nothing to do when the caller keeps its vector in place (tree_points())
         if (Tu.ptr() != u.ptr()) Tu.copyFrom(u, (size_t)own_points * sizeof(DType));
         if (num_ring_points > 0) FDD_CALL(fdd_gather_indexed(Tu.as<double>() + own_points, recv_all.as<double>(), unpack_index.template as<int>(), nullptr, num_ring_points, stream));
@@ -1176,7 +1176,7 @@ class Subdomain
     }
     void comm_probe_ring()
     {
-        if (not is_composite or exchange_ops.empty()) return;
+        if (not is_composite) return;
         fdd::comm().exchange(exchange_ops.data(), (int)exchange_ops.size());
     }
     double comm_coarse_bytes() const { return is_composite ? (double)coarse_pad * sizeof(DType) * fdd::comm().size : 0.0; }

@@ -74,7 +74,7 @@ class Timer
 
 inline Timer<double> &fdd_timer()
 {
-    static Timer<double> t;
+    static thread_local Timer<double> t;
     return t;
 }
 

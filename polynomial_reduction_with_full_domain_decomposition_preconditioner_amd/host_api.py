@@ -95,6 +95,53 @@ def comm_rccl_from_torch() -> None:
     _H().call("fddh_comm_rccl_init", ident, rank, size)
 
 
+def local_world(size: int):
+    """Handle of an in-process world of `size` ranks (one host thread each, one shared GPU): see comm_local."""
+    w = vp()
+    _H().call("fddh_local_world_create", ctypes.byref(w), int(size))
+    return w
+
+
+def local_world_destroy(world) -> None:
+    _H().call("fddh_local_world_destroy", world)
+
+
+def comm_local(world, rank: int) -> None:
+    """This THREAD becomes rank `rank` of the in-process world (call init(..., use_torch_stream=False) first: the
+    rank's own stream).  Collectives are device-to-device copies / sums between the ranks' buffers."""
+    _H().call("fddh_comm_local", world, int(rank))
+
+
+def run_local_ranks(size: int, fn, device: int = 0, init_device: bool = True):
+    """Run fn(rank, size) on `size` threads of this process, each bound to the GPU as one rank of a local world.
+    Returns the list of results; the first exception of any rank is re-raised."""
+    import threading
+
+    world = local_world(size)
+    results, errors = [None] * size, [None] * size
+
+    def body(r):
+        try:
+            if init_device:
+                init(device, use_torch_stream=False)
+            set_print(False)
+            comm_local(world, r)
+            results[r] = fn(r, size)
+        except BaseException as exc:  # noqa: BLE001 - reported to the caller below
+            errors[r] = exc
+
+    threads = [threading.Thread(target=body, args=(r,), name="fdd-rank-%d" % r) for r in range(size)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    local_world_destroy(world)
+    for e in errors:
+        if e is not None:
+            raise e
+    return results
+
+
 class _DevView:
     """Minimal __cuda_array_interface__ holder so torch can wrap a raw device pointer."""
 

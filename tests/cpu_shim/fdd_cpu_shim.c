@@ -19,7 +19,7 @@
 #include "fdd_hip.h"
 #include "fdd_oracle.h"
 
-static char g_err[256] = "";
+static __thread char g_err[256] = "";
 #define REQ(c)                                                                  \
     do                                                                          \
     {                                                                           \
@@ -253,8 +253,8 @@ int fdd_csr_plan_matvec(const fdd_csr_plan *plan, double *y, const int *p, const
 /* ---- multi-vector forms: the reference's launch-per-vector sequences ---- */
 static const double *shim_unit_weights(int n) /* w == NULL: unit weights */
 {
-    static double *ones = NULL;
-    static int cap = 0;
+    static __thread double *ones = NULL;
+    static __thread int cap = 0;
     if (n > cap)
     {
         free(ones);

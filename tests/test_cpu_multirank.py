@@ -485,3 +485,14 @@ def test_host_layer_multirank_from_mesh_files(cpu_host_lib, tmp_path):
     import torch.multiprocessing as mp
 
     mp.spawn(_worker, args=(2, _free_port(), (4, 4, 4), 3, 2, True, str(tmp_path / "mesh")), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("world,E", [(4, "8,8,4"), (8, "8,8,8")])
+def test_ranks_as_threads_of_one_process(cpu_host_lib, world, E):
+    """The in-process communicator (host/comm.hpp LocalComm: N ranks = N host threads of one process, per-rank state
+    thread_local, collectives as copies / rank-ordered sums between the ranks' buffers) on the composite against the
+    oracle's N-rank world -- the form in which 4 and 8 ranks share the one GPU of the test box (tests/test_gpu_comm.py),
+    here on the CPU stand-in of the kernel C-ABI.  A separate interpreter: the stand-in replaces the product library."""
+    out = subprocess.run([sys.executable, os.path.join(S.HERE, "local_world_checks.py"), "--cpu-shim", str(world), E, "3", "2"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "local world ok" in out.stdout

@@ -277,3 +277,22 @@ def test_two_ranks_on_one_gpu_composite_in_two_dimensions(gpu, tmp_path):
     import torch.multiprocessing as mp
 
     mp.spawn(_two_rank_worker_2d, args=(2, _port(), str(tmp_path / "quad")), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("world,E", [(4, (8, 8, 4)), (8, (8, 8, 8))])
+def test_four_and_eight_ranks_on_one_gpu(gpu, world, E):
+    """2x2x1 and 2x2x2 rank grids on the ONE GPU of the box: the edges shared by four ranks and the corner shared by
+    eight go through the HIP kernels and through Comm::exchange / all-gather / all-reduce on DEVICE buffers (the
+    in-process communicator: each rank a host thread with its own stream; the pool allows at most 6 processes per GPU,
+    so eight ranks cannot be eight processes).  Against the oracle's N-rank world: composite structure, operators, the
+    tree operator with both exchanges, the preconditioner application (GMRES / flexible CG, with and without the
+    point-Jacobi option), the outer solves (identical iteration counts), the float inner solve, the V-cycle inside."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import local_world_checks
+
+    its64, its_amg = local_world_checks.run(world, E, 3, 2)
+    assert its_amg < its64
+    H.init(0, use_torch_stream=True)
+    H.comm_single()
