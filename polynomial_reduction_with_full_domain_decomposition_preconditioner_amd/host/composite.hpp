@@ -50,6 +50,7 @@
 
 #include "comm.hpp"
 #include "config.hpp"
+#include "gll.hpp"
 #include "low_order.hpp"
 
 namespace fdd
@@ -1527,6 +1528,86 @@ inline HostCSR assemble_low_order(const Composite &c, const std::vector<std::vec
             tv.push_back(c.A_sup.val[p]);
         }
     return low_order::from_triplets(c.num_dofs, c.num_dofs, ti, tj, tv);
+}
+
+// The rows of the level-0 (degree-N) region points over the unique dofs, as assemble_low_order uses them: one unit
+// entry on a conforming point, nothing on a Dirichlet point, the piecewise-linear constraint row (Q_fem, :3287-3355)
+// on a point hanging on a lower-degree neighbour.  This is the lattice the geometric levels of the hierarchy coarsen
+// (low_order.hpp); the degree-N elements are the region's first elements, one after the other.
+inline HostCSR lattice_rows(const Composite &c, const std::vector<double> &gll_fine, double epsilon, long long &num_elements)
+{
+    const int dim = c.dim, nse = c.sub_num_ext_dofs;
+    const int first = c.level_first_elem[0], count = c.level_num_elems[0];
+    num_elements = count;
+    HostCSR R;
+    if (count == 0) return R;
+    const int base = c.sub[first].offset, np = c.sub[first].num_points;
+    const long long total = (long long)count * np;
+    std::vector<int> qi, qj;
+    std::vector<double> qv;
+    auto unique_dof = [&](int ext) { return ext >= 0 ? c.Q_int_col[ext] : -1; };
+    for (long long q = 0; q < total; q++)
+    {
+        const int u = unique_dof(c.point_dof[base + q]);
+        if (u < 0) continue;
+        qi.push_back((int)q);
+        qj.push_back(u);
+        qv.push_back(1.0);
+    }
+    auto is_fine = [&](int r) { return r >= first and r < first + count; };
+    std::vector<int> idx_i, idx_j;
+    std::map<int, std::vector<double>> Jf; // by the neighbour's degree
+    auto J_of = [&](const RegionElem &ej, const RegionElem &ei) -> const std::vector<double> & {
+        auto it = Jf.find(ej.N);
+        if (it == Jf.end())
+        {
+            std::vector<double> coarse_nodes(ej.n), w(ej.n);
+            gll::zwgll(coarse_nodes.data(), w.data(), ej.n);
+            it = Jf.emplace(ej.N, interpolator_fem(ej.N, ei.N, coarse_nodes, gll_fine)).first;
+        }
+        return it->second;
+    };
+    for (const EdgeLink &l : c.edge_links)
+    {
+        if (not is_fine(l.elem_i)) continue;
+        const RegionElem &ei = c.sub[l.elem_i], &ej = c.sub[l.elem_j];
+        edge_points(l.eid, ei.n, dim, idx_i);
+        edge_points(l.eid_j, ej.n, dim, idx_j);
+        const std::vector<double> &J = J_of(ej, ei);
+        for (int i = 1; i < ei.n - 1; i++)
+            for (int j = 0; j < ej.n; j++)
+            {
+                const int d = unique_dof(c.point_dof[ej.offset + idx_j[j]]);
+                const double w = J[(size_t)i * ej.n + j];
+                if (d < 0 or not(std::abs(w) > epsilon)) continue;
+                qi.push_back(ei.offset + idx_i[i] - base);
+                qj.push_back(d);
+                qv.push_back(w);
+            }
+    }
+    if (dim == 3)
+        for (const FaceLink &l : c.face_links)
+        {
+            if (not is_fine(l.elem_i)) continue;
+            const RegionElem &ei = c.sub[l.elem_i], &ej = c.sub[l.elem_j];
+            face_points(l.fid, ei.n, idx_i);
+            face_points(l.fid_j, ej.n, idx_j);
+            const std::vector<double> &J = J_of(ej, ei);
+            for (int j = 1; j < ei.n - 1; j++)
+                for (int i = 1; i < ei.n - 1; i++)
+                    for (int q = 0; q < ej.n; q++)
+                        for (int pp = 0; pp < ej.n; pp++)
+                        {
+                            const int d = unique_dof(c.point_dof[ej.offset + idx_j[pp + q * ej.n]]);
+                            const double w = J[(size_t)i * ej.n + pp] * J[(size_t)j * ej.n + q];
+                            if (d < 0 or not(std::abs(w) > epsilon)) continue;
+                            qi.push_back(ei.offset + idx_i[i + j * ei.n] - base);
+                            qj.push_back(d);
+                            qv.push_back(w);
+                        }
+        }
+    (void)nse;
+    return low_order::from_triplets((int)total, c.num_dofs, qi, qj, qv);
 }
 
 } // namespace composite

@@ -415,6 +415,7 @@ struct Options
     double upper_factor = 1.1;
     int power_iterations = 25;
     bool smooth_prolongator = true;
+    bool geometric_levels = true; // with a Lattice: the leading levels coarsen the GLL lattice itself (see geometric_level); false: aggregation from level 0
     int double_aggregation_levels = 0; // > 0: the finest levels aggregate TWICE (aggregates of aggregates, through the tentative Galerkin graph)
                                        // before the interpolator is smoothed: ~70 rows per aggregate on a 7-point stencil instead of ~6, operator
                                        // complexity 2.4 -> 1.1, V-cycle about half the time -- and 5 outer iterations instead of 3 (10^3 elements,
@@ -561,10 +562,235 @@ inline std::vector<double> chebyshev_coefficients(double lambda_max, const Optio
     return coefs;
 }
 
-inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = false)
+// ---------------------------------------------------------------------------------------------------------------
+// Geometric leading levels.  The low-order matrix lives on a LATTICE: the (N+1)^dim GLL points of every degree-N
+// element, joined across element faces.  Its leading levels are coarsened on that lattice, as a geometric multigrid
+// would: per element and direction a symmetric subset of the nodes is kept (end points always: N = 7 keeps nodes
+// {0, 3, 4, 7} of the 8, then {0, 7}, i.e. the degree-1 mesh), interpolation is multi-linear in the element's
+// reference coordinates, coarse operators are Galerkin products.  Rows are short (at most 2^dim entries), coarse
+// operators keep the 27-point shape, the operator complexity of the hierarchy is ~1.3 where smoothed aggregation of
+// the 7-point level-0 matrix gives 2.4 (each of its 7-row aggregates reaches its second neighbours through the
+// smoothed interpolator: ~48 entries per row on level 1).  Below the degree-1 lattice the aggregation takes over.
+// (The reference asks HYPRE BoomerAMG for its hierarchy, subdomain.tpp:3383-3549; this is this build's stand-in.)
+// ---------------------------------------------------------------------------------------------------------------
+struct Lattice
+{
+    int dim = 3;
+    int n = 0;               // lattice points per direction and element
+    std::vector<double> ref; // their reference coordinates in [-1, 1], ascending
+    long long num_elements = 0;
+    // rows: (num_elements * n^dim) lattice points x dofs; a conforming point has one unit entry, a Dirichlet point none,
+    // a hanging point (face / edge of a degree-N element against a lower-degree neighbour) its constraint row
+    HostCSR rows;
+    bool active() const { return n > 2 and num_elements > 0; }
+};
+
+// the nodes a coarser lattice keeps, of n with reference coordinates ref: both ends, symmetric, about half of them
+// (an even count when n is even), those nearest to equispaced targets
+inline std::vector<int> coarse_nodes(int n, const std::vector<double> &ref)
+{
+    if (n <= 4) return {0, n - 1};
+    int m = (n + 1) / 2;
+    if (n % 2 == 0 and m % 2 == 1) m++;
+    std::vector<char> taken(n, 0);
+    std::vector<int> keep;
+    for (int q = 0; q < (m + 1) / 2; q++)
+    {
+        const double target = -1.0 + 2.0 * q / (m - 1);
+        int best = -1;
+        for (int i = 0; i <= (n - 1) / 2; i++)
+            if (not taken[i] and (best < 0 or std::abs(ref[i] - target) < std::abs(ref[best] - target) - 1e-14)) best = i;
+        taken[best] = taken[n - 1 - best] = 1;
+    }
+    for (int i = 0; i < n; i++)
+        if (taken[i]) keep.push_back(i);
+    return keep;
+}
+
+// One geometric level: interpolator P (dofs x coarse dofs) and the coarse lattice.  Coarse dofs = the dofs sitting on
+// kept lattice nodes, plus every dof that is not a conforming lattice dof at all (lower-degree ring elements, superdomain
+// dofs of a composite: carried through unchanged), numbered in the order of the fine dofs.
+inline HostCSR geometric_level(const Lattice &fine, int num_dofs, Lattice &coarse)
+{
+    const int dim = fine.dim, n = fine.n;
+    const std::vector<int> keep = coarse_nodes(n, fine.ref);
+    const int m = (int)keep.size();
+    long long np = 1, npc = 1;
+    for (int d = 0; d < dim; d++)
+    {
+        np *= n;
+        npc *= m;
+    }
+    // 1-D interpolation: node i from kept nodes lo[i], hi[i] with weights wl[i], 1 - wl[i] (a kept node from itself)
+    std::vector<int> lo(n), hi(n), pos(n, -1);
+    std::vector<double> wl(n);
+    for (int a = 0; a < m; a++) pos[keep[a]] = a;
+    for (int i = 0, a = 0; i < n; i++)
+    {
+        if (pos[i] >= 0)
+        {
+            lo[i] = hi[i] = pos[i];
+            wl[i] = 1.0;
+            a = pos[i];
+            continue;
+        }
+        lo[i] = a;
+        hi[i] = a + 1;
+        wl[i] = (fine.ref[keep[a + 1]] - fine.ref[i]) / (fine.ref[keep[a + 1]] - fine.ref[keep[a]]);
+    }
+    const long long total = fine.num_elements * np;
+    // where every conforming dof first sits, and whether some occurrence is on a kept node
+    std::vector<long long> first(num_dofs, -1);
+    std::vector<char> kept(num_dofs, 0);
+    for (long long q = 0; q < total; q++)
+    {
+        if (fine.rows.ptr[q + 1] - fine.rows.ptr[q] != 1 or fine.rows.val[fine.rows.ptr[q]] != 1.0) continue;
+        const int d = fine.rows.col[fine.rows.ptr[q]];
+        if (first[d] < 0) first[d] = q;
+        long long v = q % np;
+        bool all = true;
+        for (int a = 0; a < dim; a++)
+        {
+            all = all and pos[v % n] >= 0;
+            v /= n;
+        }
+        if (all) kept[d] = 1;
+    }
+    std::vector<int> cmap(num_dofs, -1);
+    int nc = 0;
+    for (int d = 0; d < num_dofs; d++)
+        if (first[d] < 0 or kept[d]) cmap[d] = nc++;
+
+    HostCSR P;
+    P.rows = num_dofs;
+    P.cols = nc;
+    P.ptr.assign(num_dofs + 1, 0);
+    const int parts = range_parts(num_dofs);
+    std::vector<std::vector<int>> pcol(parts);
+    std::vector<std::vector<double>> pval(parts);
+    std::vector<int> row_len(num_dofs, 0);
+    parallel_ranges(num_dofs, parts, [&](long long d0, long long d1, int part) {
+        std::vector<int> oc;
+        std::vector<double> ov;
+        std::vector<std::pair<int, double>> row;
+        for (long long d = d0; d < d1; d++)
+        {
+            if (cmap[d] >= 0)
+            {
+                oc.push_back(cmap[d]);
+                ov.push_back(1.0);
+                row_len[d] = 1;
+                continue;
+            }
+            const long long q = first[d], e = q / np;
+            long long v = q % np;
+            int idx[3] = {0, 0, 0};
+            for (int a = 0; a < dim; a++)
+            {
+                idx[a] = (int)(v % n);
+                v /= n;
+            }
+            row.clear();
+            for (int corner = 0; corner < (1 << dim); corner++)
+            {
+                double w = 1.0;
+                long long cq = 0, stride = 1;
+                bool skip = false;
+                for (int a = 0; a < dim; a++)
+                {
+                    const int side = (corner >> a) & 1, i = idx[a];
+                    if (lo[i] == hi[i])
+                    {
+                        if (side) skip = true; // a kept coordinate has one parent in this direction
+                        cq += (long long)keep[lo[i]] * stride;
+                    }
+                    else
+                    {
+                        w *= side ? 1.0 - wl[i] : wl[i];
+                        cq += (long long)keep[side ? hi[i] : lo[i]] * stride;
+                    }
+                    stride *= n;
+                }
+                if (skip) continue;
+                const long long point = e * np + cq;
+                for (int t = fine.rows.ptr[point]; t < fine.rows.ptr[point + 1]; t++)
+                {
+                    const int c = cmap[fine.rows.col[t]];
+                    if (c < 0)
+                    {
+                        fprintf(stderr, "ERROR: low_order::geometric_level: a kept lattice node depends on dof %d, which is not kept\n", fine.rows.col[t]);
+                        exit(EXIT_FAILURE);
+                    }
+                    row.emplace_back(c, w * fine.rows.val[t]);
+                }
+            }
+            std::sort(row.begin(), row.end(), [](const std::pair<int, double> &x, const std::pair<int, double> &y) { return x.first < y.first; });
+            int len = 0;
+            for (size_t t = 0; t < row.size(); t++)
+            {
+                if (t > 0 and row[t].first == row[t - 1].first)
+                    ov.back() += row[t].second;
+                else
+                {
+                    oc.push_back(row[t].first);
+                    ov.push_back(row[t].second);
+                    len++;
+                }
+            }
+            row_len[d] = len;
+        }
+        pcol[part] = std::move(oc);
+        pval[part] = std::move(ov);
+    });
+    for (int d = 0; d < num_dofs; d++) P.ptr[d + 1] = P.ptr[d] + row_len[d];
+    P.col.reserve(P.ptr[num_dofs]);
+    P.val.reserve(P.ptr[num_dofs]);
+    for (int t = 0; t < parts; t++)
+    {
+        P.col.insert(P.col.end(), pcol[t].begin(), pcol[t].end());
+        P.val.insert(P.val.end(), pval[t].begin(), pval[t].end());
+        std::vector<int>().swap(pcol[t]);
+        std::vector<double>().swap(pval[t]);
+    }
+
+    // the coarse lattice: the kept nodes of every element, their rows over the coarse dofs
+    coarse = Lattice();
+    coarse.dim = dim;
+    coarse.n = m;
+    coarse.num_elements = fine.num_elements;
+    coarse.ref.resize(m);
+    for (int a = 0; a < m; a++) coarse.ref[a] = fine.ref[keep[a]];
+    HostCSR &R = coarse.rows;
+    R.rows = (int)(fine.num_elements * npc);
+    R.cols = nc;
+    R.ptr.assign((size_t)R.rows + 1, 0);
+    for (long long e = 0; e < fine.num_elements; e++)
+        for (long long cv = 0; cv < npc; cv++)
+        {
+            long long v = cv, fq = 0, stride = 1;
+            for (int a = 0; a < dim; a++)
+            {
+                fq += (long long)keep[v % m] * stride;
+                v /= m;
+                stride *= n;
+            }
+            const long long point = e * np + fq;
+            for (int t = fine.rows.ptr[point]; t < fine.rows.ptr[point + 1]; t++)
+            {
+                R.col.push_back(cmap[fine.rows.col[t]]);
+                R.val.push_back(fine.rows.val[t]);
+            }
+            R.ptr[e * npc + cv + 1] = (int)R.col.size();
+        }
+    return P;
+}
+
+inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = false, Lattice lattice = Lattice())
 {
     std::vector<Level> levels;
     HostCSR A = std::move(A0);
+    static const int geometric_env = getenv("FDD_TUNE_AMG_GEOMETRIC") ? atoi(getenv("FDD_TUNE_AMG_GEOMETRIC")) : -1; // development override
+    const bool geometric = geometric_env >= 0 ? geometric_env != 0 : o.geometric_levels;
     for (int l = 0; l < o.max_levels; l++)
     {
         Level L;
@@ -578,10 +804,17 @@ inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = fal
 
         bool last = (n <= o.coarsest_size) or (l == o.max_levels - 1);
         HostCSR P;
-        if (not last)
+        if (not last and geometric and lattice.active() and lattice.rows.cols == n)
+        {
+            Lattice next;
+            P = geometric_level(lattice, n, next);
+            lattice = std::move(next);
+            if (verbose) printf("low_order: level %d coarsened on the lattice: %d -> %d rows, %d nodes per direction and element left\n", l, n, P.cols, lattice.n);
+        }
+        else if (not last)
         {
             std::vector<int> agg;
-            int nc = aggregate(A, o.strength * std::pow(0.5, l), agg); // Galerkin operators spread: weaker threshold per level
+            int nc = aggregate(A, o.strength * std::pow(0.5, l), agg); // Galerkin operators spread: weaker threshold per level (a trilinear 27-point stencil has edge / corner entries of 1/16 and 1/32 of its diagonal and no face entries)
             static const int double_levels_env = getenv("FDD_TUNE_AMG_DOUBLE_AGG") ? atoi(getenv("FDD_TUNE_AMG_DOUBLE_AGG")) : -1; // development override
             if (l < (double_levels_env >= 0 ? double_levels_env : o.double_aggregation_levels) and nc > 0 and nc < n)
             {
@@ -602,6 +835,7 @@ inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = fal
                     nc = nc2;
                 }
             }
+            if (verbose) printf("low_order: level %d aggregated: %d -> %d rows\n", l, n, nc);
             if (nc >= n or nc == 0)
                 last = true;
             else

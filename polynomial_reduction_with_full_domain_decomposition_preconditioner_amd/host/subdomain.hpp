@@ -1253,7 +1253,37 @@ class Subdomain
         else
             A = fdd::low_order::assemble_fem(fine_mesh->x.data(), fine_mesh->y.data(), fine_mesh->z.data(), point_dof.data(), num_dofs, poly_degree[0], fine_mesh->num_local_elements, epsilon);
         const double t1 = clock();
-        std::vector<fdd::low_order::Level> lv = fdd::low_order::build(std::move(A), options, verbose);
+        // the lattice the level-0 dofs sit on (the GLL points of the degree-N elements): the leading levels of the
+        // hierarchy coarsen it geometrically (low_order.hpp)
+        fdd::low_order::Lattice lattice;
+        if (options.geometric_levels and poly_degree[0] >= 2)
+        {
+            const int n = poly_degree[0] + 1;
+            lattice.dim = dim;
+            lattice.n = n;
+            lattice.ref.resize(n);
+            std::vector<double> w(n);
+            fdd::gll::zwgll(lattice.ref.data(), w.data(), n);
+            if (is_composite)
+                lattice.rows = fdd::composite::lattice_rows(comp, lattice.ref, (double)epsilon, lattice.num_elements);
+            else
+            {
+                lattice.num_elements = fine_mesh->num_local_elements;
+                const size_t np = (size_t)lattice.num_elements * n * n * n;
+                fdd::low_order::HostCSR &R = lattice.rows;
+                R.rows = (int)np;
+                R.cols = num_dofs;
+                R.ptr.assign(np + 1, 0);
+                R.col.reserve(np);
+                for (size_t q = 0; q < np; q++)
+                {
+                    if (point_dof[q] >= 0) R.col.push_back(point_dof[q]);
+                    R.ptr[q + 1] = (int)R.col.size();
+                }
+                R.val.assign(R.col.size(), 1.0);
+            }
+        }
+        std::vector<fdd::low_order::Level> lv = fdd::low_order::build(std::move(A), options, verbose, std::move(lattice));
         const double t2 = clock();
         amg_hierarchy = amg::Hierarchy();
         for (size_t l = 0; l < lv.size(); l++)

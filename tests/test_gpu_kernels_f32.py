@@ -131,7 +131,7 @@ def test_multi_inner_product_and_axpy_norm_f32(gpu, n, m):
         out = torch.zeros(1, dtype=torch.float64, device=gpu)
         k("fdd_multi_axpy_norm2_scaled_dev_f32", out, ws, dst, dev(y, gpu), dev(c, gpu), -1.0, dx, dsc if with_scale else None, m, n)
         assert np.array_equal(host(dst), ref_dst)  # the stored float vector: same double sum, one rounding
-        assert abs(host(out)[0] - ref_norm) <= 1e-13 * ref_norm + 1e-300
+        assert abs(host(out)[0] - ref_norm) <= 1e-12 * ref_norm + 1e-300  # a serial sum on one side, a tree on the other
 
 
 @pytest.mark.parametrize("n", [1, 129, 4097, 1000003])
