@@ -144,7 +144,7 @@ def cpu_baseline(args, world, P):
     }
 
 
-PMC_FILES = ["profiles/r02_pmc_traffic_c2.json", "profiles/r02_pmc_traffic_c3.json"]  # one per profiled workload
+PMC_FILES = ["profiles/r03_pmc_traffic_c2.json", "profiles/r02_pmc_traffic_c3.json"]  # one per profiled workload
 
 
 def pmc_traffic(kernel_key, elements, degree):
@@ -269,6 +269,12 @@ def run(args, rank, world, max_over_ranks, comm_label):
     from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
     from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
 
+    def progress(what):
+        # a line per phase on stderr: long multi-rank runs stay visibly alive (and a hang can be placed)
+        if rank == 0:
+            print("[bench.py %6.1f s] %s" % (time.perf_counter() - t_start, what), file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
     P = H.rank_grid(world)
     e = args.elements
     E = tuple(e * p for p in P)
@@ -286,6 +292,7 @@ def run(args, rank, world, max_over_ranks, comm_label):
     t_setup = time.perf_counter()
     block_local = args.block_local
     prob = create(block_local)
+    progress("problem set up")
     _, f = prob.make_rhs(function_id=4, seed=1234 + rank)  # rand()/RAND_MAX u*, poisson.cpp:211
     t_setup = time.perf_counter() - t_setup
     sub = prob.sub_info() if not args.no_precond else None
@@ -358,12 +365,14 @@ def run(args, rank, world, max_over_ranks, comm_label):
     configure(args.amg, args.amg_precision)
     dt, last_res, kernels = timed_steps(args.steps, args.warmup, not args.no_kernel_timing)
     value = nodes * args.steps / dt
+    progress("headline steps timed: %.3f ms per step" % (dt / args.steps * 1e3))
 
     # the same K steps with a stopping test (one host synchronisation) per step, as a real solve runs them
     prob.set_flag("lazy_steps", 0)
     dt_tests, _, _ = timed_steps(args.steps, min(args.warmup, 1), False)
     prob.set_flag("lazy_steps", 1)
     headline_tol = None if args.no_time_to_tolerance else to_tolerance()
+    progress("headline solve to tolerance: %s" % (headline_tol,))
 
     # the headline configuration with the preconditioner in single precision (the reference's Float = float)
     headline_f32 = None
@@ -374,6 +383,7 @@ def run(args, rank, world, max_over_ranks, comm_label):
         if not args.no_time_to_tolerance:
             headline_f32["to_1e-7"] = to_tolerance()
         configure(args.amg, args.amg_precision)
+        progress("single-precision preconditioner leg done")
 
     # the headline configuration with point-Jacobi in the inner solver's preconditioner slot (labelled option of this
     # build; DESIGN 5: what four unpreconditioned Krylov steps lack is row scaling, most of all on the composite)
@@ -387,6 +397,7 @@ def run(args, rank, world, max_over_ranks, comm_label):
             point_jacobi["to_1e-7"] = to_tolerance()
         configure(args.amg, args.amg_precision)
 
+    progress("point-Jacobi leg done")
     # N > 1: the block-local comparison point (every rank's own elements only: block-Jacobi) next to the composite, so
     # that an iteration count of the composite is never read without it
     block_local_leg = None
@@ -402,6 +413,7 @@ def run(args, rank, world, max_over_ranks, comm_label):
             block_local_leg["point_jacobi_to_1e-7"] = to_tolerance(other, f_bl)
         other.close()
 
+    progress("block-local leg done")
     table = {}
     for name, st in kernels.items():
         avg_ms = st["ms"] / st["count"]
@@ -460,6 +472,7 @@ def run(args, rank, world, max_over_ranks, comm_label):
             if not args.no_time_to_tolerance:
                 entry["to_1e-7"] = to_tolerance()
             reference_default["f%d" % precision] = entry
+            progress("reference-default leg (f%d) done" % precision)
         reference_default["amg_levels"] = amg_state["levels"]
         reference_default["amg_setup_s"] = amg_state["setup_s"]
         configure(args.amg, args.amg_precision)
@@ -521,6 +534,7 @@ def run(args, rank, world, max_over_ranks, comm_label):
         out["config"]["composite"] = {k: sub[k] for k in ("num_elems", "num_ext_elems", "num_points", "sub_dofs", "sub_ext_dofs", "interface_dofs", "sup_dofs", "sup_ext_dofs", "unique_dofs", "coarse_dofs", "num_peers")}
         out["config"]["composite"]["superdomain_levels"] = prob.sub_composite_levels()
 
+    progress("device legs done; CPU baseline")
     # rank 0 times the oracle on its host cores while the other ranks wait at the barrier below
     out["cpu_baseline"] = cpu_baseline(args, world, P) if (rank == 0 and not args.no_cpu_baseline) else None
     if world > 1:

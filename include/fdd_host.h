@@ -31,6 +31,8 @@ int fddh_init(int device, void *stream, int own_stream);
 int fddh_set_print(int on); /* rank-0 residual history lines (rstdout) */
 int fddh_set_timer(int on); /* named timing regions (timer.hpp); off by default */
 int fddh_timer_total(const char *key, double *seconds);
+/* the same aggregated over the ranks, "max" (the reference's table, poisson.cpp:256, timer.tpp:67) or "sum": collective */
+int fddh_timer_total_over_ranks(const char *key, const char *aggregation, double *seconds);
 
 /* Communicator (MPI_Initialize, poisson.cpp:84-89).  Exactly one of: */
 int fddh_comm_single(void);

@@ -40,6 +40,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -456,6 +457,17 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
     Composite c;
     fdd::Comm &comm = fdd::comm();
     const int proc_id = comm.rank, num_procs = comm.size;
+    // FDD_SETUP_TIMING=1: rank 0 prints the host time of every phase below
+    const bool phase_timing = getenv("FDD_SETUP_TIMING") != nullptr and proc_id == 0;
+    auto phase_clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double phase_t0 = phase_clock();
+    auto phase = [&](const char *what) {
+        if (not phase_timing) return;
+        const double now = phase_clock();
+        printf("composite::build %-28s %8.3f s\n", what, now - phase_t0);
+        fflush(stdout);
+        phase_t0 = now;
+    };
     auto &domain = domains[poly_degree[0]];
     const int dim = domain.mesh.dim;
     const int nv = (dim == 2) ? 4 : 8;
@@ -515,6 +527,7 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
             for (int v = 0; v < nv; v++) v2e[fill[vert_of[(size_t)e * nv + v]]++] = e;
     }
 
+    phase("element graph");
     // ---- computational regions (subdomain.tpp:455-579) ----
     std::vector<int> mark(num_total_elements, 0); // > 0: in the subdomain (work_hst[1] of the reference)
     std::vector<char> reached(num_total_elements, 0);
@@ -641,6 +654,7 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
     }
     const int NP = c.num_sub_ext_points;
 
+    phase("regions");
     // ---- data of the region's elements: own ones from the rank's meshes, the others pulled from their owners
     // (the gs exchanges of subdomain.tpp:644-805) ----
     c.mask.assign(NP, 0.0);
@@ -748,6 +762,7 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
         }
     }
 
+    phase("region data pull");
     // ---- coarse level of the whole domain: geometric factors and masked ids of every element's vertices
     // (subdomain.tpp:1632-1713) ----
     auto &coarse_domain = domains[poly_degree[num_levels - 1]];
@@ -779,6 +794,7 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
         c.Qt_coarse = low_order::from_triplets(num_coarse_dofs, num_total_elements * nv, ti, tj, tv);
     }
 
+    phase("coarse level");
     // ---- interface nodes (subdomain.tpp:810-843): dofs of the subdomain's degree-1 elements that also sit on a
     // superdomain element ----
     std::unordered_set<long long> interface_glo_num;
@@ -803,6 +819,7 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
     }
     c.num_interface_dofs = (int)interface_glo_num.size();
 
+    phase("interface nodes");
     // ---- connectivity of the subdomain region through shared edges and faces (subdomain.tpp:845-878) ----
     const int RE = c.num_sub_ext_elems;
     typedef std::array<long long, 2> EdgeKey;
@@ -827,6 +844,7 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
         for (int fid = 0; fid < num_faces; fid++) face_map[face_key(r, fid)].push_back(r);
     }
 
+    phase("connectivity");
     // ---- region numbering (subdomain.tpp:920-1176) ----
     // key = global id made unique across levels (:921-967), 0 on the hanging side of a non-conforming edge / face
     std::vector<long long> key(NP);
@@ -929,6 +947,7 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
             if (cls[p] >= 0) c.point_dof[p] = dof_of_key[key[p]];
     }
 
+    phase("numbering");
     // ---- the non-conforming Q (subdomain.tpp:1496-1582) ----
     {
         std::vector<int> idx_i, idx_j;
@@ -1006,6 +1025,7 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
         }
     }
 
+    phase("non-conforming Q");
     // ---- superdomain (subdomain.tpp:1715-2576) ----
     if (c.num_sup_elems > 0)
     {
@@ -1165,6 +1185,7 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
         c.A_sup.ptr.assign(1, 0);
     }
 
+    phase("superdomain");
     // ---- interface operators and weights (subdomain.tpp:2581-2747) ----
     {
         const int ns = c.sub_num_dofs, nse = c.sub_num_ext_dofs, nI = c.num_interface_dofs, nu = c.sup_num_dofs, nue = c.sup_num_ext_dofs;
@@ -1223,6 +1244,7 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
         for (int i = 0; i < nI; i++) c.norm_weight[(size_t)nse + i] = 0.0;
         for (int i = nu; i < nue; i++) c.norm_weight[(size_t)nse + i] = 0.0;
     }
+    phase("interface maps and weights");
     return c;
 }
 

@@ -153,6 +153,20 @@ int fddh_timer_total(const char *key, double *seconds)
     }
 }
 
+int fddh_timer_total_over_ranks(const char *key, const char *aggregation, double *seconds)
+{
+    try
+    {
+        if (!key || !aggregation || !seconds) return fail("null argument");
+        *seconds = timer.total(key, aggregation); // collective: all-reduce (max or sum) over the ranks, timer.tpp:67
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return fail("%s", e.what());
+    }
+}
+
 int fddh_comm_single(void)
 {
     try

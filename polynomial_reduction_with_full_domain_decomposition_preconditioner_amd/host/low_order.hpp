@@ -415,6 +415,7 @@ struct Options
     double upper_factor = 1.1;
     int power_iterations = 25;
     bool smooth_prolongator = true;
+    int geometric_min_nodes = 5;  // lattices with fewer nodes per direction and element are left to the aggregation
     bool geometric_levels = true; // with a Lattice: the leading levels coarsen the GLL lattice itself (see geometric_level); false: aggregation from level 0
     int double_aggregation_levels = 0; // > 0: the finest levels aggregate TWICE (aggregates of aggregates, through the tentative Galerkin graph)
                                        // before the interpolator is smoothed: ~70 rows per aggregate on a 7-point stencil instead of ~6, operator
@@ -582,7 +583,7 @@ struct Lattice
     // rows: (num_elements * n^dim) lattice points x dofs; a conforming point has one unit entry, a Dirichlet point none,
     // a hanging point (face / edge of a degree-N element against a lower-degree neighbour) its constraint row
     HostCSR rows;
-    bool active() const { return n > 2 and num_elements > 0; }
+    bool active(int min_nodes = 3) const { return n >= min_nodes and num_elements > 0; }
 };
 
 // the nodes a coarser lattice keeps, of n with reference coordinates ref: both ends, symmetric, about half of them
@@ -596,7 +597,8 @@ inline std::vector<int> coarse_nodes(int n, const std::vector<double> &ref)
     std::vector<int> keep;
     for (int q = 0; q < (m + 1) / 2; q++)
     {
-        const double target = -1.0 + 2.0 * q / (m - 1);
+        static const int gll_targets = getenv("FDD_TUNE_AMG_GLL_TARGETS") ? atoi(getenv("FDD_TUNE_AMG_GLL_TARGETS")) : 0; // development: 1 = Chebyshev-like targets
+        const double target = gll_targets ? -std::cos(3.14159265358979323846 * q / (m - 1)) : -1.0 + 2.0 * q / (m - 1);
         int best = -1;
         for (int i = 0; i <= (n - 1) / 2; i++)
             if (not taken[i] and (best < 0 or std::abs(ref[i] - target) < std::abs(ref[best] - target) - 1e-14)) best = i;
@@ -804,7 +806,8 @@ inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = fal
 
         bool last = (n <= o.coarsest_size) or (l == o.max_levels - 1);
         HostCSR P;
-        if (not last and geometric and lattice.active() and lattice.rows.cols == n)
+        static const int min_nodes_env = getenv("FDD_TUNE_AMG_GEOMETRIC_MIN_NODES") ? atoi(getenv("FDD_TUNE_AMG_GEOMETRIC_MIN_NODES")) : 0; // development override
+        if (not last and geometric and lattice.active(min_nodes_env > 0 ? min_nodes_env : o.geometric_min_nodes) and lattice.rows.cols == n)
         {
             Lattice next;
             P = geometric_level(lattice, n, next);

@@ -38,6 +38,7 @@
 #include <string>
 #include <thread>
 #include <unistd.h>
+#include <vector>
 
 #include "fdd_host.h"
 
@@ -256,14 +257,45 @@ int main(int argc, char *argv[])
         printf("max |u - u*| on rank 0: %.3e\n", err);
         if (its > 0) printf("DOF-updates/s: %.4e\n", (double)info[FDDH_INFO_NUM_TOTAL_NODES] * its / seconds);
 
-        // timing table (poisson.cpp:253-401), per-rank regions of rank 0
-        const char *keys[] = {"domain.inner_products", "domain.residual_norm", "domain.vector_operations", "domain.operator_application", "subdomain.stitching", "subdomain.solver"};
-        printf("\nTiming (rank 0, seconds):\n");
-        for (const char *k : keys)
+    }
+
+    // timing table (poisson.cpp:253-401): the reference's eight rows, each the MAXIMUM over the ranks (aggregation_type
+    // "max", poisson.cpp:256; timer.tpp:67), tree construction / exchange summed over their regions (:322-357).
+    // Collective: every rank takes part in the reductions, rank 0 prints.
+    {
+        struct Row
         {
-            double s = 0.0;
-            fddh_timer_total(k, &s);
-            printf("  %-32s %10.6f\n", k, s);
+            const char *label;
+            std::vector<const char *> keys;
+        };
+        const std::vector<Row> rows = {
+            {"Inner products", {"domain.inner_products"}},
+            {"Residual norm", {"domain.residual_norm"}},
+            {"Vector operations", {"domain.vector_operations"}},
+            {"Operator application", {"domain.operator_application"}},
+            {"Tree construction", {"subdomain.tree_construction.gpu_to_gpu", "subdomain.tree_construction.subdomain", "subdomain.tree_construction.gpu_to_cpu", "subdomain.tree_construction.assemble_coarse", "subdomain.tree_construction.superdomain"}},
+            {"Tree exchange", {"subdomain.tree_exchange.superdomain", "subdomain.tree_exchange.subdomain", "subdomain.tree_exchange.cpu_to_gpu"}},
+            {"Subdomain stitching", {"subdomain.stitching"}},
+            {"Subdomain solver", {"subdomain.solver"}},
+        };
+        std::vector<double> t(rows.size(), 0.0);
+        double total = 0.0;
+        for (size_t r = 0; r < rows.size(); r++)
+        {
+            for (const char *k : rows[r].keys)
+            {
+                double s = 0.0;
+                if (fddh_timer_total_over_ranks(k, "max", &s)) die("fddh_timer_total_over_ranks");
+                t[r] += s;
+            }
+            total += t[r];
+        }
+        if (rank == 0)
+        {
+            printf("\nTimings (maximum over the ranks):\n");
+            printf("-------------------------------------------------------------------------\n");
+            printf("%-21s = %12.08f s ( %6.02f )\n", "Total", total, 100.0);
+            for (size_t r = 0; r < rows.size(); r++) printf("%-21s = %12.08f s ( %6.02f )\n", rows[r].label, t[r], total > 0.0 ? 100.0 * t[r] / total : 0.0);
         }
     }
 
