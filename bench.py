@@ -11,10 +11,16 @@ workload: config C2 per GPU -- 3-D Poisson, 32^3 spectral elements of degree
           generalized_minimum_residual, 4 inner iterations, polynomial
           reduction 6) + stitching dssum.  N ranks = N rank blocks of the
           cube (2 -> 64x32x32, 4 -> 64x64x32, 8 -> 64^3 = config C4), one
-          process per GPU: weak scaling.  With N > 1 every rank preconditions
-          with its full-domain-decomposition composite (own elements, rings
-          of neighbour elements at degrees 7 and 1, graded superdomain);
-          --block-local keeps the own elements only.
+          process per GPU: weak scaling.  With N > 1 `value` is the SAME
+          iteration carried to N ranks: every rank preconditions with the
+          solve on its own elements (block-local) and the interface is
+          exchanged -- the no-V-cycle configuration that converges (at C4's
+          size the composite without the V-cycle does not: DESIGN 5.2).  The
+          full-domain-decomposition composite of every rank (own elements,
+          rings of neighbour elements at degrees 7 and 1, graded superdomain)
+          is built next to it and measured in `composite` (no V-cycle,
+          flagged) and `reference_default` (V-cycle inside: what the
+          reference runs, BASELINE C5).  --composite-headline swaps the two.
 headline: `value` is config C2 as BASELINE.json quotes it -- inner GMRES(4)
           WITHOUT the low-order V-cycle inside.  The reference's default has
           the V-cycle on (subdomain.hpp:231); the same JSON line carries that
@@ -69,7 +75,8 @@ def parse():
     ap.add_argument("--no-time-to-tolerance", action="store_true", help="skip the full solves to 1e-7")
     ap.add_argument("--no-stencil", action="store_true", help="skip the 27-point-stencil SpMV (3.05e8 non-zeros at the default size)")
     ap.add_argument("--force-composite", action="store_true", help="N=1 diagnostic: run the one-rank problem through the composite code path (no rings, no superdomain) to see what that path costs on identical work")
-    ap.add_argument("--block-local", action="store_true", help="N>1: every rank keeps its own elements only (block-Jacobi) instead of the full-domain-decomposition composite")
+    ap.add_argument("--block-local", action="store_true", help="N>1: block-local only (no composite is built: no `composite` / composite `reference_default` legs)")
+    ap.add_argument("--composite-headline", action="store_true", help="N>1: make the full-domain-decomposition composite WITHOUT the V-cycle the headline `value` (rounds 1-2); default: the block-local iteration, which converges, with the composite in `composite` and `reference_default`")
     ap.add_argument("--no-amg-fusion", action="store_true", help="with --amg: the smoother's element-wise kernels as separate launches (the reference's sequence) instead of SpMV epilogues")
     ap.add_argument("--amg-precision", type=int, choices=[64, 32], default=64, help="the reference's `Float` (config.hpp:19-20, AMG/config.hpp:4): the preconditioner (inner Krylov solve and V-cycle) in double (default) or float")
     ap.add_argument("--no-amg-graph", action="store_true", help="with --amg: launch the V-cycle kernel by kernel (so that --kernel-table shows them) instead of replaying its hipGraph")
@@ -103,7 +110,7 @@ def cpu_baseline(args, world, P):
     W = S.OracleWorld([m[0] for m in meshes], N)
     F = sds = None
     if not args.no_precond:
-        if world > 1 and not args.block_local:
+        if world > 1 and args.composite_headline and not args.block_local:  # the configuration `value` is measured on
             F = S.OracleFdd(E, N, red, P, meshes=meshes)
         else:
             sds = [S.OracleSubdomain(None, N, red, meshes=meshes[r]) for r in range(world)]
@@ -290,33 +297,51 @@ def run(args, rank, world, max_over_ranks, comm_label):
             os._exit(1)
 
     t_setup = time.perf_counter()
-    block_local = args.block_local
-    prob = create(block_local)
-    progress("problem set up")
+    # N > 1: two preconditioners of the same outer iteration are built.
+    #   block-local  every rank's own elements only -- the one-rank configuration (BASELINE C2) carried to N ranks
+    #                unchanged, plus the interface exchange: the HEADLINE `value`, because without the V-cycle it is
+    #                the one that converges (C4 size, 8 ranks: 379 iterations; the composite: residual 1.5e-4 after 500,
+    #                DESIGN 5.2) and because its per-rank work is the one-rank work, so the N-rank curve measures the
+    #                exchanges and not a bigger region;
+    #   composite    the full-domain-decomposition region of every rank: carried in `composite` (no V-cycle, flagged)
+    #                and in `reference_default` (V-cycle inside: the configuration the reference runs, BASELINE C5).
+    # --composite-headline makes the composite without the V-cycle the headline, as in rounds 1-2.
+    comp = blk = None
+    if world > 1 and not args.no_precond:
+        blk = create(True)
+        if not args.block_local:
+            comp = create(False)
+        prob = comp if (args.composite_headline and comp is not None) else blk
+    else:
+        prob = create(args.block_local)
+    progress("problem%s set up" % ("s (block-local and composite)" if comp is not None else ""))
     _, f = prob.make_rhs(function_id=4, seed=1234 + rank)  # rand()/RAND_MAX u*, poisson.cpp:211
     t_setup = time.perf_counter() - t_setup
     sub = prob.sub_info() if not args.no_precond else None
     composite = bool(sub and sub["is_composite"])
+    comp_sub = comp.sub_info() if comp is not None else None
 
-    amg_state = {"levels": 0, "setup_s": 0.0}
+    amg_states = {}
 
-    def configure(amg, precision=64, jacobi=False):
+    def configure(amg, precision=64, jacobi=False, problem=None):
         """headline: inner GMRES(4) alone; reference default: the low-order V-cycle inside every inner step;
         jacobi: point-Jacobi in that slot (labelled option of this build)"""
         if args.no_precond:
             return
-        if amg and amg_state["levels"] == 0:
+        problem = problem or prob
+        st = amg_states.setdefault(id(problem), {"levels": 0, "setup_s": 0.0})
+        if amg and st["levels"] == 0:
             t = time.perf_counter()
-            amg_state["levels"] = prob.amg_build()
-            amg_state["setup_s"] = time.perf_counter() - t
+            st["levels"] = problem.amg_build()
+            st["setup_s"] = time.perf_counter() - t
             if args.no_amg_graph:
-                prob.set_flag("amg_graph", 0)
+                problem.set_flag("amg_graph", 0)
             if args.no_amg_fusion:
-                prob.set_flag("amg_fused_smoother", 0)
-        prob.set_flag("sub_use_preconditioner", 1 if amg else (2 if jacobi else 0))
+                problem.set_flag("amg_fused_smoother", 0)
+        problem.set_flag("sub_use_preconditioner", 1 if amg else (2 if jacobi else 0))
         # the reference's PTYPE = Float (config.hpp:19-20): the WHOLE inner solve (element stiffness, gather, Krylov vectors,
         # V-cycle) in double or in float
-        prob.set_flag("preconditioner_precision", precision)
+        problem.set_flag("preconditioner_precision", precision)
 
     info0 = prob.refresh()
     nodes = info0["num_total_nodes"]
@@ -398,22 +423,28 @@ def run(args, rank, world, max_over_ranks, comm_label):
         configure(args.amg, args.amg_precision)
 
     progress("point-Jacobi leg done")
-    # N > 1: the block-local comparison point (every rank's own elements only: block-Jacobi) next to the composite, so
-    # that an iteration count of the composite is never read without it
-    block_local_leg = None
-    if world > 1 and composite and not args.no_reference_default:
-        other = create(True)
-        other.set_flag("sub_use_preconditioner", 0)
-        _, f_bl = other.make_rhs(function_id=4, seed=1234 + rank)
-        db, lrb, _ = timed_steps(args.steps, min(args.warmup, 2), False, problem=other, rhs=f_bl)
-        block_local_leg = {"preconditioner": "BLOCK-LOCAL fdd_gmres4 (own elements only: no neighbour rings / superdomain)", "ms_per_step": db / args.steps * 1e3, "value": nodes * args.steps / db, "last_residual_norm": lrb}
-        if not args.no_time_to_tolerance:
-            block_local_leg["to_1e-7"] = to_tolerance(other, f_bl)
-            other.set_flag("sub_use_preconditioner", 2)
-            block_local_leg["point_jacobi_to_1e-7"] = to_tolerance(other, f_bl)
-        other.close()
 
-    progress("block-local leg done")
+    def leg(problem, label):
+        """the no-V-cycle configuration on the OTHER region of an N-rank run, next to the headline"""
+        configure(False, 64, problem=problem)
+        _, rhs = problem.make_rhs(function_id=4, seed=1234 + rank)
+        d, lr, _ = timed_steps(args.steps, min(args.warmup, 2), False, problem=problem, rhs=rhs)
+        out_leg = {"preconditioner": label, "ms_per_step": d / args.steps * 1e3, "value": nodes * args.steps / d, "last_residual_norm": lr}
+        if not args.no_time_to_tolerance:
+            out_leg["to_1e-7"] = to_tolerance(problem, rhs)
+            configure(False, 64, jacobi=True, problem=problem)
+            out_leg["point_jacobi_to_1e-7"] = to_tolerance(problem, rhs)
+            configure(False, 64, problem=problem)
+        return out_leg
+
+    # N > 1: the other region's figures, so that neither is ever read without the other
+    block_local_leg = composite_leg = None
+    if comp is not None and not args.no_reference_default:
+        if prob is comp:
+            block_local_leg = leg(blk, "BLOCK-LOCAL fdd_gmres4 (own elements only: no neighbour rings / superdomain)")
+        else:
+            composite_leg = leg(comp, "full-domain-decomposition composite, fdd_gmres4 WITHOUT the V-cycle (not a configuration the reference runs: its use_preconditioner is hard-wired true)")
+    progress("comparison leg done")
     table = {}
     for name, st in kernels.items():
         avg_ms = st["ms"] / st["count"]
@@ -461,27 +492,30 @@ def run(args, rank, world, max_over_ranks, comm_label):
             "algorithmic_bytes_per_launch": table[dom]["bytes_per_launch"],
         }
 
-    # ---------------- the reference's default inner preconditioner (V-cycle on), same problem ----------------
+    # ---------------- the reference's default inner preconditioner (V-cycle on): on the composite when there is one ----------------
     reference_default = None
+    ref_prob = comp if comp is not None else prob
     if not args.no_precond and not args.no_reference_default and not args.amg:
-        reference_default = {"preconditioner": "fdd_gmres4 + low-order AMG V-cycle in every inner step (Subdomain::use_preconditioner = true, subdomain.hpp:231)"}
+        reference_default = {"preconditioner": "fdd_gmres4 + low-order AMG V-cycle in every inner step (Subdomain::use_preconditioner = true, subdomain.hpp:231)"
+                                               + (" on the full-domain-decomposition composite of every rank" if comp is not None else "")}
+        _, f_ref = ref_prob.make_rhs(function_id=4, seed=1234 + rank)
         for precision in (64, 32):
-            configure(True, precision)
-            d, lr, _ = timed_steps(args.steps, min(args.warmup, 2), False)
+            configure(True, precision, problem=ref_prob)
+            d, lr, _ = timed_steps(args.steps, min(args.warmup, 2), False, problem=ref_prob, rhs=f_ref)
             entry = {"ms_per_step": d / args.steps * 1e3, "value": nodes * args.steps / d, "last_residual_norm": lr}
             if not args.no_time_to_tolerance:
-                entry["to_1e-7"] = to_tolerance()
+                entry["to_1e-7"] = to_tolerance(ref_prob, f_ref)
             reference_default["f%d" % precision] = entry
             progress("reference-default leg (f%d) done" % precision)
-        reference_default["amg_levels"] = amg_state["levels"]
-        reference_default["amg_setup_s"] = amg_state["setup_s"]
-        configure(args.amg, args.amg_precision)
+        reference_default["amg_levels"] = amg_states[id(ref_prob)]["levels"]
+        reference_default["amg_setup_s"] = amg_states[id(ref_prob)]["setup_s"]
+        configure(args.amg if ref_prob is prob else False, args.amg_precision, problem=ref_prob)
 
     info = prob.refresh()
     if args.no_precond:
         pre_name, pre_text = "none", "no preconditioner"
     else:
-        pre_name = "fdd_gmres4+amg_vcycle(%d levels, f%d)" % (amg_state["levels"], args.amg_precision) if args.amg else "fdd_gmres4"
+        pre_name = "fdd_gmres4+amg_vcycle(%d levels, f%d)" % (amg_states[id(prob)]["levels"], args.amg_precision) if args.amg else ("fdd_gmres4" if (composite or world == 1) else "fdd_gmres4 (block-local)")
         if composite:
             pre_text = "full-domain-decomposition preconditioner (per rank: %d own + %d ring/extended elements, %d superdomain dofs of %d coarse; inner GMRES(4), polynomial reduction %d)" % (
                 info["num_local_elements"], sub["num_ext_elems"] - info["num_local_elements"], sub["sup_dofs"], sub["coarse_dofs"], args.reduction)
@@ -520,6 +554,7 @@ def run(args, rank, world, max_over_ranks, comm_label):
         "preconditioner_in_f32": headline_f32,
         "point_jacobi": point_jacobi,
         "block_local": block_local_leg,
+        "composite": composite_leg,
         "setup_s": t_setup,
         "roofline": roofline,
         "spmv": spmv,
@@ -528,11 +563,11 @@ def run(args, rank, world, max_over_ranks, comm_label):
     }
     if world > 1:
         # the solve path's collectives alone, with the solve's own sizes and buffers (max over ranks)
-        comm = prob.comm_time(20)
+        comm = (comp if comp is not None else prob).comm_time(20)
         out["comm_us"] = {k: {"avg_us": max_over_ranks(v["avg_us"]), "bytes": v["bytes"]} for k, v in comm.items()}
-    if composite:
-        out["config"]["composite"] = {k: sub[k] for k in ("num_elems", "num_ext_elems", "num_points", "sub_dofs", "sub_ext_dofs", "interface_dofs", "sup_dofs", "sup_ext_dofs", "unique_dofs", "coarse_dofs", "num_peers")}
-        out["config"]["composite"]["superdomain_levels"] = prob.sub_composite_levels()
+    if comp is not None:
+        out["config"]["composite"] = {k: comp_sub[k] for k in ("num_elems", "num_ext_elems", "num_points", "sub_dofs", "sub_ext_dofs", "interface_dofs", "sup_dofs", "sup_ext_dofs", "unique_dofs", "coarse_dofs", "num_peers")}
+        out["config"]["composite"]["superdomain_levels"] = comp.sub_composite_levels()
 
     progress("device legs done; CPU baseline")
     # rank 0 times the oracle on its host cores while the other ranks wait at the barrier below
@@ -542,6 +577,9 @@ def run(args, rank, world, max_over_ranks, comm_label):
 
     if rank == 0:
         print(json.dumps(out))
+    for pr in (comp, blk):
+        if pr is not None and pr is not prob:
+            pr.close()
     prob.close()
 
 

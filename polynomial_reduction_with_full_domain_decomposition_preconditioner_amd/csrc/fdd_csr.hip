@@ -817,6 +817,20 @@ static int plan_launch_f32(const fdd_csr_plan *plan, float *y, const int *A_ptr,
 
 static int plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows, int num_cols, int num_nnz, bool f32);
 
+// Host -> device copy of a small setup table, complete on return.  Not hipMemcpy: that runs on the legacy default stream,
+// which is ordered against every other stream of the process -- with several ranks in one process (one host thread
+// each) another rank may be capturing its V-cycle graph at that moment, and the runtime then refuses the copy
+// (hipErrorStreamCaptureImplicit).  A non-blocking stream of the calling thread has no such implicit edges.
+static hipError_t upload_table(void *dst, const void *src, size_t bytes)
+{
+    static thread_local hipStream_t s = nullptr;
+    hipError_t err = hipSuccess;
+    if (s == nullptr) err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
+    return err;
+}
+
 extern "C" {
 
 int fdd_csr_multiply(double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, int n, void *stream)
@@ -921,7 +935,7 @@ static int plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows,
     p->row_blocks_host = blocks;
 
     hipError_t err = hipMalloc((void **)&p->row_blocks_dev, blocks.size() * sizeof(int));
-    if (err == hipSuccess) err = hipMemcpy(p->row_blocks_dev, blocks.data(), blocks.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = upload_table(p->row_blocks_dev, blocks.data(), blocks.size() * sizeof(int));
     if (err != hipSuccess)
     {
         fdd_set_error("fdd_csr_plan_create: %s", hipGetErrorString(err));
@@ -991,9 +1005,9 @@ int fdd_csr_plan_attach_sell(fdd_csr_plan *plan, const int *A_ptr_host, const in
     hipError_t err = hipMalloc((void **)&plan->sell_off_dev, off.size() * sizeof(int));
     if (err == hipSuccess) err = hipMalloc((void **)&plan->sell_col_dev, (size_t)total * sizeof(int));
     if (err == hipSuccess) err = hipMalloc(&plan->sell_val_dev, (size_t)total * vb);
-    if (err == hipSuccess) err = hipMemcpy(plan->sell_off_dev, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = upload_table(plan->sell_off_dev, off.data(), off.size() * sizeof(int));
     if (err == hipSuccess && !order.empty()) err = hipMalloc((void **)&plan->sell_order_dev, order.size() * sizeof(int));
-    if (err == hipSuccess && !order.empty()) err = hipMemcpy(plan->sell_order_dev, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (err == hipSuccess && !order.empty()) err = upload_table(plan->sell_order_dev, order.data(), order.size() * sizeof(int));
     if (err != hipSuccess)
     {
         fdd_set_error("fdd_csr_plan_attach_sell: %s", hipGetErrorString(err));

@@ -98,6 +98,12 @@ def run(world, E, N, red, amg=True):
             u, its_amg, hist = p.solve(f, "fcg")
             assert hist[-1] <= 1e-7 * hist[0] and its_amg < its64
             assert np.abs(u - solves[(0, "fcg")][0][rank]).max() <= 1e-5 * np.abs(u).max()
+            # and the whole preconditioner in float: every rank builds its f32 plans and captures its f32 V-cycle graph
+            # while its peers are somewhere else in theirs (setup copies must not touch the legacy default stream)
+            p.set_flag("preconditioner_precision", 32)
+            u32a, its32a, h32a = p.solve(f, "fcg")
+            assert abs(its32a - its_amg) <= 1 and h32a[-1] <= 1e-7 * h32a[0] * 1.0001
+            p.set_flag("preconditioner_precision", 64)
         ct = p.comm_time(2)
         assert ct["ring_exchange"]["bytes"] > 0 and ct["coarse_allgather"]["bytes"] > 0
         p.close()
