@@ -102,7 +102,8 @@ def cpu_baseline(args, world, P):
     import support as S
 
     N, red = args.degree, args.reduction
-    e = args.cpu_sample_elements if world == 1 else max(4, int(round(0.6 * args.cpu_sample_elements / world ** (1.0 / 3.0))))
+    composite_sample = world > 1 and args.composite_headline and not args.block_local  # the oracle's composites cost a setup of their own: a smaller cube
+    e = args.cpu_sample_elements if world == 1 else max(4, int(round((0.6 if composite_sample else 1.0) * args.cpu_sample_elements / world ** (1.0 / 3.0))))
     E = tuple(e * p for p in P)
     deg = S.level_degrees(N, red)
     t_setup = time.perf_counter()
