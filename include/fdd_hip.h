@@ -196,6 +196,8 @@ int fdd_sub_restriction_2(double *Ju, const double *J_cf, const double *u, int n
 int fdd_sub_restriction_3(double *Ju, const double *J_cf, const double *u, int num_points, int n_f, int n_c, void *stream);          /* subdomain.okl:346-366, subdomain.tpp:4607 */
 /* Fused J^T (x) J^T (x) J^T per element through LDS, 3-D: 8*(n_f^3+n_c^3) B/element */
 int fdd_sub_restriction(double *u_c, const double *J_cf, const double *u_f, int num_elements, int n_f, int n_c, void *stream);
+/* the `dim == 2` branches of restriction_1 and _2 (subdomain.okl:284-344) in one launch, bit-identical to the pair */
+int fdd_sub_restriction_2d(double *u_c, const double *J_cf, const double *u_f, int num_elements, int n_f, int n_c, void *stream);
 
 /* ------------------------------------------------------------------ */
 /* AMG/kernels.cu + AMG/csr_matrix.cpp -- Chebyshev-smoothed V-cycle     */

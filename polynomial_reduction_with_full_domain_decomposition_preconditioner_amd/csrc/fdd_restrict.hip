@@ -248,9 +248,66 @@ __global__ __launch_bounds__(kBlock) void restriction_wave_kernel(double *__rest
     }
 }
 
+// 2-D form of the fused restriction (the `dim == 2` branches of subdomain.okl:284-344 in one launch): an element's n_f^2
+// values go to LDS once, the y contraction (restriction_1's 2-D branch contracts the SECOND index) leaves n_f x n_c
+// there, the x contraction writes the n_c^2 result.  Same statements per output, sums in ascending k: bit-identical to
+// the two-launch form.  kBlock / n_f^2 elements per workgroup (n_f <= 16).
+__global__ __launch_bounds__(kBlock) void restriction_2d_kernel(double *__restrict__ u_c, const double *__restrict__ J_cf, const double *__restrict__ u_f, int num_elements, int n_f, int n_c)
+{
+    extern __shared__ double lds2[];
+    const int nf2 = n_f * n_f, nfc = n_f * n_c, nc2 = n_c * n_c;
+    const int epb = kBlock / nf2;
+    double *sJ = lds2;                      // n_f x n_c
+    double *sU = sJ + nfc;                  // epb x n_f^2
+    double *sT = sU + (size_t)epb * nf2;    // epb x (n_f x n_c)
+    for (int t = threadIdx.x; t < nfc; t += kBlock) sJ[t] = J_cf[t];
+    for (int g = blockIdx.x; g * epb < num_elements; g += gridDim.x)
+    {
+        const int e_loc = threadIdx.x / nf2, v = threadIdx.x - e_loc * nf2;
+        const int e = g * epb + e_loc;
+        const bool on = e_loc < epb and e < num_elements;
+        __syncthreads(); // sJ staged; previous group's sU / sT consumed
+        if (on) sU[e_loc * nf2 + v] = u_f[(size_t)e * nf2 + v];
+        __syncthreads();
+        if (on)
+            for (int o = v; o < nfc; o += nf2)
+            {
+                // restriction_1, dim == 2: Ju(i, j) = sum_k J[j + k n_c] u(i, k), i < n_f, j < n_c
+                const int i = o % n_f, j = o / n_f;
+                double acc = 0.0;
+                for (int k = 0; k < n_f; k++) acc += sJ[j + k * n_c] * sU[e_loc * nf2 + (i + k * n_f)];
+                sT[e_loc * nfc + o] = acc;
+            }
+        __syncthreads();
+        if (on)
+            for (int o = v; o < nc2; o += nf2)
+            {
+                // restriction_2, dim == 2: Ju(i, j) = sum_k T(k, j) J[k n_c + i], i, j < n_c
+                const int i = o % n_c, j = o / n_c;
+                double acc = 0.0;
+                for (int k = 0; k < n_f; k++) acc += sT[e_loc * nfc + (j * n_f + k)] * sJ[k * n_c + i];
+                u_c[(size_t)e * nc2 + o] = acc;
+            }
+    }
+}
+
 } // namespace
 
 extern "C" {
+
+int fdd_sub_restriction_2d(double *u_c, const double *J_cf, const double *u_f, int num_elements, int n_f, int n_c, void *stream)
+{
+    FDD_REQUIRE(num_elements >= 0 && n_f >= 1 && n_c >= 1 && n_c <= n_f && n_f <= 16);
+    if (num_elements == 0) return 0;
+    FDD_REQUIRE(u_c != nullptr && J_cf != nullptr && u_f != nullptr);
+    const int epb = kBlock / (n_f * n_f);
+    const int groups = (num_elements + epb - 1) / epb;
+    const int grid = groups < 16 * FDD_CU_COUNT ? groups : 16 * FDD_CU_COUNT;
+    const size_t lds = sizeof(double) * ((size_t)n_f * n_c + (size_t)epb * ((size_t)n_f * n_f + (size_t)n_f * n_c));
+    hipLaunchKernelGGL(restriction_2d_kernel, dim3(grid), dim3(kBlock), lds, fdd_stream(stream), u_c, J_cf, u_f, num_elements, n_f, n_c);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
 
 int fdd_sub_restriction_1(double *Ju, const double *J_cf, const double *u, int num_points, int n_f, int n_c, int dim, void *stream)
 {

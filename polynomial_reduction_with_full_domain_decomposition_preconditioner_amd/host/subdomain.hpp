@@ -241,10 +241,9 @@ class Subdomain
                 }
                 else
                 {
-                    int np = levels[l].num_elements * (n_f * n_c);
-                    FDD_CALL(fdd_sub_restriction_1(work_dev[1].as<double>(), J.as<double>(), u_f.as<double>(), np, n_f, n_c, dim, fdd::dev().stream));
-                    np = levels[l].num_elements * (n_c * n_c);
-                    FDD_CALL(fdd_sub_restriction_2(u_c.as<double>(), J.as<double>(), work_dev[1].as<double>(), np, n_f, n_c, dim, fdd::dev().stream));
+                    // the two `dim == 2` launches (subdomain.tpp:4593-4596) as one, bit-identical
+                    fdd::ProfileScope prof("restriction_2d_kernel", 8.0 * levels[l].num_elements * ((double)n_f * n_f + (double)n_c * n_c));
+                    FDD_CALL(fdd_sub_restriction_2d(u_c.as<double>(), J.as<double>(), u_f.as<double>(), levels[l].num_elements, n_f, n_c, fdd::dev().stream));
                 }
             }
         }

@@ -228,6 +228,15 @@ int fdd_sub_copy_f64_f32(double *u, const float *v, int n, void *s) { (void)s; o
 int fdd_sub_restriction_1(double *Ju, const double *J, const double *u, int np, int nf, int nc, int dim, void *s) { (void)s; orc_sub_restriction_1(Ju, J, u, np, nf, nc, dim); return 0; }
 int fdd_sub_restriction_2(double *Ju, const double *J, const double *u, int np, int nf, int nc, int dim, void *s) { (void)s; orc_sub_restriction_2(Ju, J, u, np, nf, nc, dim); return 0; }
 int fdd_sub_restriction_3(double *Ju, const double *J, const double *u, int np, int nf, int nc, void *s) { (void)s; orc_sub_restriction_3(Ju, J, u, np, nf, nc); return 0; }
+int fdd_sub_restriction_2d(double *uc, const double *J, const double *uf, int ne, int nf, int nc, void *s)
+{
+    (void)s;
+    double *t = (double *)malloc(sizeof(double) * (size_t)ne * nf * nc + 8);
+    orc_sub_restriction_1(t, J, uf, ne * nf * nc, nf, nc, 2);
+    orc_sub_restriction_2(uc, J, t, ne * nc * nc, nf, nc, 2);
+    free(t);
+    return 0;
+}
 int fdd_sub_restriction(double *uc, const double *J, const double *uf, int ne, int nf, int nc, void *s)
 {
     (void)s;

@@ -726,6 +726,17 @@ def test_restriction_2d(gpu):
     k("fdd_sub_restriction_1", d1, dev(J, gpu), dev(u, gpu), len(w1), n_f, n_c, 2)
     k("fdd_sub_restriction_2", dc, dev(J, gpu), d1, len(uc), n_f, n_c, 2)
     assert np.array_equal(host(d1), w1) and np.array_equal(host(dc), uc)
+    # both `dim == 2` launches as one (fdd_sub_restriction_2d), bit for bit, over the reference's level pairs and beyond
+    for E2, Nf2, Nc2 in ((77, 7, 3), (1, 7, 1), (300, 3, 1), (41, 15, 7), (9, 5, 4), (1000, 2, 1)):
+        nf, nc = Nf2 + 1, Nc2 + 1
+        J2 = np.ascontiguousarray(S.J_cf(Nc2, Nf2))
+        u2 = rnd(E2 * nf * nf, 112 + Nf2)
+        t2, ref2 = np.zeros(E2 * nf * nc), np.zeros(E2 * nc * nc)
+        L.orc_sub_restriction_1(P(t2), P(J2), P(u2), len(t2), nf, nc, 2)
+        L.orc_sub_restriction_2(P(ref2), P(J2), P(t2), len(ref2), nf, nc, 2)
+        out2 = torch.full((len(ref2),), 3.0, dtype=torch.float64, device=gpu)
+        k("fdd_sub_restriction_2d", out2, dev(J2, gpu), dev(u2, gpu), E2, nf, nc)
+        assert np.array_equal(host(out2), ref2), (E2, Nf2, Nc2)
 
 
 # ------------------------------------------------------------------ AMG
