@@ -22,6 +22,7 @@
 #define FDD_LOW_ORDER_HPP
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -811,6 +812,13 @@ inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = fal
     static const int geometric_env = getenv("FDD_TUNE_AMG_GEOMETRIC") ? atoi(getenv("FDD_TUNE_AMG_GEOMETRIC")) : -1; // development override
     const bool geometric = geometric_env >= 0 ? geometric_env != 0 : o.geometric_levels;
     int geometric_done = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now();
+    auto lap = [&](const char *what, int l) {
+        const double t = now();
+        if (verbose) printf("low_order:   level %d %-24s %7.3f s\n", l, what, t - t_mark);
+        t_mark = t;
+    };
     for (int l = 0; l < o.max_levels; l++)
     {
         Level L;
@@ -821,6 +829,7 @@ inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = fal
         const double lmax = max_eigenvalue_scaled(A, L.D, o.power_iterations);
         L.coefs = chebyshev_coefficients(lmax, o);
         if (verbose) printf("low_order: level %d rows %d nnz %lld lambda_max(DAD) %.4f\n", l, n, A.nnz(), lmax);
+        lap("diagonal + lambda_max", l);
 
         bool last = (n <= o.coarsest_size) or (l == o.max_levels - 1);
         HostCSR P;
@@ -901,9 +910,13 @@ inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = fal
             levels.push_back(std::move(L));
             break;
         }
+        lap("interpolator", l);
         HostCSR R = transpose(P);
+        lap("transpose", l);
         HostCSR AP = multiply(A, P);
+        lap("A P", l);
         HostCSR Ac = multiply(R, AP);
+        lap("R (A P)", l);
         L.A = std::move(A);
         L.P = std::move(P);
         levels.push_back(std::move(L));

@@ -191,3 +191,54 @@ print("ok", its)
 """ % (S.ROOT, S.HERE, HOST_CPU_SO)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_geometric_leading_levels_of_the_hierarchy():
+    """Round 3: the leading levels of the low-order hierarchy coarsen the GLL lattice itself (host/low_order.hpp:
+    geometric_level).  3^3 elements of degree 7: the level sizes are the lattices' interior node counts (20^3 -> 8^3 -> 2^3:
+    8, 4 and 2 lattice nodes per direction and element, Dirichlet shell removed), the interpolators are partitions of unity away from the Dirichlet boundary and
+    reproduce a linear function there (multi-linear interpolation in reference coordinates on an affine mesh), coarse
+    operators are Galerkin, the operator complexity stays below 1.45 and a V-cycle-preconditioned solve converges."""
+    subprocess.check_call(["make", "-C", S.ORACLE_DIR, "-s"])
+    subprocess.check_call(["make", "-C", SHIM_DIR, "-s"])
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import support as S
+from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H, lib
+lib._host = lib._Lib(%r, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
+H.init(0, use_torch_stream=False); H.comm_single(); H.set_print(False)
+E, N = 3, 7
+p = H.Problem.box((E, E, E), (1, 1, 1), N, 6, True)
+assert p.amg_build(coarsest_size=30) >= 3
+L = p.amg_levels()
+sizes = [lv["A"].shape[0] for lv in L]
+assert sizes[:3] == [(E * 7 - 1) ** 3, (E * 3 - 1) ** 3, (E - 1) ** 3], sizes   # 8, 4 and 2 lattice nodes per direction and element
+nnz = [lv["A"].nnz for lv in L]
+assert sum(nnz) / nnz[0] <= 1.45, sum(nnz) / nnz[0]
+# coordinates of the level-0 dofs
+dof = p.sub_point_dofs()
+x, y, z = (p.mesh_array(c) for c in "xyz")
+has = dof >= 0
+g = np.zeros(sizes[0]); g[dof[has]] = (2 * x - y + 3 * z + 0.5)[has]
+for l in range(2):
+    P = L[l]["P"].tocsr()
+    assert P.shape == (sizes[l], sizes[l + 1]) and np.diff(P.indptr).max() <= 8 and P.data.min() >= 0
+    rs = np.asarray(P.sum(axis=1)).ravel()
+    assert rs.max() <= 1 + 1e-13
+    inner = np.abs(rs - 1) <= 1e-13                      # every parent is a dof: the row is a partition of unity
+    assert inner.sum() >= 8
+    ident = (np.diff(P.indptr) == 1) & (P.data[np.minimum(P.indptr[:-1], len(P.data) - 1)] == 1.0)
+    gc = np.zeros(sizes[l + 1]); gc[P.indices[P.indptr[:-1][ident]]] = g[ident]   # kept nodes carry their own values
+    assert np.abs((P @ gc - g)[inner]).max() <= 1e-12 * np.abs(g).max()            # linear functions are reproduced
+    G = (P.T @ L[l]["A"] @ P).tocsr()
+    assert abs(G - L[l + 1]["A"]).max() <= 1e-12 * abs(G).max()
+    g = gc
+_, f = p.make_rhs(function_id=4, seed=1234)
+u, its, hist = p.solve(f, "fcg")
+assert hist[-1] <= 1e-7 * hist[0] and its <= 5, (its, hist[-1] / hist[0])
+print("ok", sizes, its)
+""" % (S.ROOT, S.HERE, HOST_CPU_SO)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
