@@ -39,6 +39,9 @@ namespace
 #ifndef FDD_MFMA_UNCOND_PREFETCH
 #define FDD_MFMA_UNCOND_PREFETCH 1 // 0: prefetch only when there is a next element (development A/B)
 #endif
+#ifndef FDD_MFMA_STAGGER
+#define FDD_MFMA_STAGGER 0 // > 0: workgroups with an odd index start that many x 8k cycles late (development A/B: de-phase the CUs' load bursts)
+#endif
 #ifndef FDD_MFMA_TRACE
 #define FDD_MFMA_TRACE 0 // 1: wave 0 of workgroup 0 accumulates the cycles spent in each phase and prints them (development)
 #endif
@@ -188,6 +191,10 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
         return (d < 0) ? 0.0 : (u_scale ? uscale * v : v);
     };
 
+#if FDD_MFMA_STAGGER > 0
+    if (blockIdx.x & 1)
+        for (int w_ = 0; w_ < FDD_MFMA_STAGGER; w_++) __builtin_amdgcn_s_sleep(127);
+#endif
     double ru[kPts], rg[FDD_NUM_GEOM_FACTS][kPts];
     int rd[kGather ? kPts : 1];
     int e = blockIdx.x;
