@@ -296,3 +296,28 @@ def test_four_and_eight_ranks_on_one_gpu(gpu, world, E):
     assert its_amg < its64
     H.init(0, use_torch_stream=True)
     H.comm_single()
+
+
+def test_bench_line_of_an_n_rank_run(gpu):
+    """bench.py's N-rank line end to end on the one GPU (4 ranks as threads of one process, tiny problem): the keys the
+    driver and the judge read -- the block-local headline, the composite's legs with `converged`, the reference default
+    on the composite, `cpu_baseline` and `comm_us` at N > 1."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-ranks", "4", "--elements", "4", "--steps", "3", "--warmup", "1", "--cpu-sample-elements", "6", "--cpu-sample-steps", "3"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 4 and line["scaling"] == "weak" and line["value"] > 0
+    assert "BLOCK-LOCAL" in line["config"]["workload"] and line["config"]["rank_grid"] == [2, 2, 1]
+    assert line["to_1e-7"]["converged"] is True
+    comp = line["composite"]
+    assert comp is not None and isinstance(comp["to_1e-7"]["converged"], bool) and isinstance(comp["point_jacobi_to_1e-7"]["converged"], bool)
+    rd = line["reference_default"]
+    assert "composite" in rd["preconditioner"] and rd["f64"]["to_1e-7"]["converged"] is True and rd["f64"]["to_1e-7"]["iterations"] < line["to_1e-7"]["iterations"]
+    assert line["cpu_baseline"]["cores"] == 1 and "4 ranks" in line["cpu_baseline"]["sample"]
+    assert set(line["comm_us"]) == {"allreduce_3_scalars", "interface_pair_allreduce", "coarse_allgather", "ring_exchange"}
+    assert line["config"]["composite"]["num_peers"] == 3
