@@ -230,6 +230,9 @@ int fdd_csr_plan_create_f32(fdd_csr_plan **plan, const int *A_ptr_host, int num_
 int fdd_csr_plan_matvec_to_f32(const fdd_csr_plan *plan, float *y, const float *y_in, const int *A_ptr, const int *A_col, const float *A_val, const float *x, float alpha, float beta, void *stream);
 int fdd_amg_smooth_residual_matvec_f32(const fdd_csr_plan *plan, float *work, float *Sr, const int *A_ptr, const int *A_col, const float *A_val, const float *u, const float *f, const float *D_val, float coef, void *stream);
 int fdd_amg_smooth_polynomial_matvec_f32(const fdd_csr_plan *plan, float *work_out, const int *A_ptr, const int *A_col, const float *A_val, const float *work_in, const float *Sr, const float *D_val, float coef, void *stream);
+/* the update from u = 0 (pre-smoothing): u = 0 + D*(coef*Sr + D*(A work_in)), u not read -- the bits of the update on a zeroed u */
+int fdd_amg_smooth_update_matvec_from_zero(const fdd_csr_plan *plan, double *u, const int *A_ptr, const int *A_col, const double *A_val, const double *work_in, const double *Sr, const double *D_val, double coef, void *stream);
+int fdd_amg_smooth_update_matvec_from_zero_f32(const fdd_csr_plan *plan, float *u, const int *A_ptr, const int *A_col, const float *A_val, const float *work_in, const float *Sr, const float *D_val, float coef, void *stream);
 int fdd_amg_smooth_update_matvec_f32(const fdd_csr_plan *plan, float *u, const int *A_ptr, const int *A_col, const float *A_val, const float *work_in, const float *Sr, const float *D_val, float coef, void *stream);
 int fdd_amg_smooth_start_f32(float *work, float *Sr, const float *f, const float *D_val, float coef, int size, void *stream);
 int fdd_amg_vector_set_to_value_f32(float *data, float value, int size, void *stream);

@@ -131,6 +131,23 @@ struct EpiSmoothUpdateT
         return o.c + o.b * w;
     }
 };
+// the same from u = 0 (every pre-smoothing of a V-cycle): u = 0 + D*w without reading u -- the bits of the update above on
+// a zeroed vector -- so that the level's u need not be set to zero first
+template <typename T>
+struct EpiSmoothUpdateZeroT
+{
+    static constexpr bool kFreeOrder = true;
+    typedef Opnd2<T> Opnd;
+    const T *r, *D;
+    T coef;
+    __device__ Opnd operand(int row, const T *) const { return Opnd{r[row], D[row]}; }
+    __device__ T finish(T s, Opnd o, int) const
+    {
+        const T v = (T(1) * s) * o.b;
+        const T w = coef * o.a + v;
+        return T(0) + o.b * w;
+    }
+};
 typedef EpiSmoothResidualT<double> EpiSmoothResidual;
 typedef EpiSmoothPolyT<double> EpiSmoothPoly;
 typedef EpiSmoothUpdateT<double> EpiSmoothUpdate;
@@ -1242,6 +1259,15 @@ int fdd_amg_smooth_update_matvec(const fdd_csr_plan *plan, double *u, const int 
     return plan_launch(plan, u, A_ptr, A_col, A_val, work_in, EpiSmoothUpdate{Sr, D_val, coef}, stream);
 }
 
+// u = 0 + D*(coef*Sr + D*(A work_in)): the update above from a zero u, which is not read
+int fdd_amg_smooth_update_matvec_from_zero(const fdd_csr_plan *plan, double *u, const int *A_ptr, const int *A_col, const double *A_val, const double *work_in, const double *Sr, const double *D_val, double coef, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr);
+    if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
+    FDD_REQUIRE(u != nullptr && A_ptr != nullptr && work_in != nullptr && Sr != nullptr && D_val != nullptr && u != work_in);
+    return plan_launch(plan, u, A_ptr, A_col, A_val, work_in, EpiSmoothUpdateZeroT<double>{Sr, D_val, coef}, stream);
+}
+
 // ---- Float = float (AMG/config.hpp:4): the V-cycle's SpMV and fused smoother on f32 values and vectors ----
 int fdd_csr_plan_matvec_to_f32(const fdd_csr_plan *plan, float *y, const float *y_in, const int *A_ptr, const int *A_col, const float *A_val, const float *x, float alpha, float beta, void *stream)
 {
@@ -1273,6 +1299,14 @@ int fdd_amg_smooth_update_matvec_f32(const fdd_csr_plan *plan, float *u, const i
     if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
     FDD_REQUIRE(u != nullptr && A_ptr != nullptr && A_val != nullptr && work_in != nullptr && Sr != nullptr && D_val != nullptr && u != work_in);
     return plan_launch_f32(plan, u, A_ptr, A_col, A_val, work_in, EpiSmoothUpdateT<float>{Sr, D_val, coef}, stream);
+}
+
+int fdd_amg_smooth_update_matvec_from_zero_f32(const fdd_csr_plan *plan, float *u, const int *A_ptr, const int *A_col, const float *A_val, const float *work_in, const float *Sr, const float *D_val, float coef, void *stream)
+{
+    FDD_REQUIRE(plan != nullptr);
+    if (plan->num_rows == 0 || plan->num_cols == 0) return 0;
+    FDD_REQUIRE(u != nullptr && A_ptr != nullptr && A_val != nullptr && work_in != nullptr && Sr != nullptr && D_val != nullptr && u != work_in);
+    return plan_launch_f32(plan, u, A_ptr, A_col, A_val, work_in, EpiSmoothUpdateZeroT<float>{Sr, D_val, coef}, stream);
 }
 
 } // extern "C"

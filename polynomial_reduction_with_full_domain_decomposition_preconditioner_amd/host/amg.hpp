@@ -75,7 +75,10 @@ class Hierarchy
                 L.A.smooth_polynomial(*out, *in, L.r, L.D_val, L.coefs[p]);
                 std::swap(in, out);
             }
-            L.A.smooth_update(L.u, *in, L.r, L.D_val, L.coefs[0]);
+            if (u_is_zero)
+                L.A.smooth_update_from_zero(L.u, *in, L.r, L.D_val, L.coefs[0]); // u = 0 + D w: u is not read, and was not zeroed (vcycle_launches)
+            else
+                L.A.smooth_update(L.u, *in, L.r, L.D_val, L.coefs[0]);
             return;
         }
         // scaled_residual (:34-39): work = f - A u without the copy "work = f" in front of the SpMV; from u = 0 it is f
@@ -97,13 +100,16 @@ class Hierarchy
     {
         const int nl = (int)levels.size();
         void *s = fdd::dev().stream;
-        FDD_CALL(fdd_amg_vector_set_to_value(levels[0].u.as<double>(), 0.0, levels[0].n, s)); // :4012
+        // the fused pre-smoother writes u = 0 + D w without reading u: the reference's zeroing of u (:4012, :4026, :4058)
+        // would be 8 B per row written and read back for nothing
+        const bool smoother_writes_u = fused_smoother and cheby_order >= 2;
+        if (not smoother_writes_u or nl == 1) FDD_CALL(fdd_amg_vector_set_to_value(levels[0].u.as<double>(), 0.0, levels[0].n, s)); // :4012
         for (int iter = 0; iter < num_vcycles; iter++)
         {
             for (int l = 0; l < nl - 1; l++)
             {
                 Level &L = levels[l];
-                if (l > 0) FDD_CALL(fdd_amg_vector_set_to_value(L.u.as<double>(), 0.0, L.n, s));
+                if (l > 0 and not smoother_writes_u) FDD_CALL(fdd_amg_vector_set_to_value(L.u.as<double>(), 0.0, L.n, s));
                 smooth(l, l > 0 or iter == 0);
                 L.A.matvec_to(L.v, L.f, L.u, -1.0, 1.0); // v = f - A u
                 L.R.matvec(levels[l + 1].f, L.v, 1.0, 0.0);
@@ -189,7 +195,10 @@ class Hierarchy
             FDD_CALL(fdd_amg_smooth_polynomial_matvec_f32(L.A_plan32, out->as<float>(), ptr, col, val, in->as<float>(), L.r32.as<float>(), D, (float)L.coefs[p], s));
             std::swap(in, out);
         }
-        FDD_CALL(fdd_amg_smooth_update_matvec_f32(L.A_plan32, L.u32.as<float>(), ptr, col, val, in->as<float>(), L.r32.as<float>(), D, (float)L.coefs[0], s));
+        if (u_is_zero)
+            FDD_CALL(fdd_amg_smooth_update_matvec_from_zero_f32(L.A_plan32, L.u32.as<float>(), ptr, col, val, in->as<float>(), L.r32.as<float>(), D, (float)L.coefs[0], s));
+        else
+            FDD_CALL(fdd_amg_smooth_update_matvec_f32(L.A_plan32, L.u32.as<float>(), ptr, col, val, in->as<float>(), L.r32.as<float>(), D, (float)L.coefs[0], s));
     }
 
     void vcycle_launches32()
@@ -197,13 +206,13 @@ class Hierarchy
         const int nl = (int)levels.size();
         void *s = fdd::dev().stream;
         if (not f32_io) FDD_CALL(fdd_sub_copy_f32_f64(levels[0].f32.as<float>(), levels[0].f.as<double>(), levels[0].n, s));
-        FDD_CALL(fdd_amg_vector_set_to_value_f32(levels[0].u32.as<float>(), 0.0f, levels[0].n, s));
+        // the pre-smoother writes u = 0 + D w without reading u (smooth32): no zeroing of u
+        if (nl == 1) FDD_CALL(fdd_amg_vector_set_to_value_f32(levels[0].u32.as<float>(), 0.0f, levels[0].n, s));
         for (int iter = 0; iter < num_vcycles; iter++)
         {
             for (int l = 0; l < nl - 1; l++)
             {
                 Level &L = levels[l];
-                if (l > 0) FDD_CALL(fdd_amg_vector_set_to_value_f32(L.u32.as<float>(), 0.0f, L.n, s));
                 smooth32(l, l > 0 or iter == 0);
                 matvec32(L.A_plan32, L.A, L.A_val32, L.v32, &L.f32, L.u32, -1.0f, 1.0f);
                 matvec32(L.R_plan32, L.R, L.R_val32, levels[l + 1].f32, nullptr, L.v32, 1.0f, 0.0f);

@@ -189,6 +189,15 @@ class CSR_Matrix
         FDD_CALL(fdd_amg_smooth_update_matvec(plan, u.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), work_in.as<double>(), Sr.as<double>(), D.as<double>(), coef, fdd::dev().stream));
     }
 
+    // the same from u = 0, which is not read (pre-smoothing)
+    void smooth_update_from_zero(fdd::memory &u, fdd::memory &work_in, fdd::memory &Sr, fdd::memory &D, double coef)
+    {
+        if ((num_rows == 0) or (num_cols == 0)) return;
+        initialization_check();
+        fdd::ProfileScope prof(sell ? "sell_kernel<EpiSmoothUpdate>" : plan_kind == 0 ? "csr_row_kernel<EpiSmoothUpdate>" : "csr_block_kernel<EpiSmoothUpdate>", algorithmic_bytes(true) + 8.0 * num_rows);
+        FDD_CALL(fdd_amg_smooth_update_matvec_from_zero(plan, u.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), work_in.as<double>(), Sr.as<double>(), D.as<double>(), coef, fdd::dev().stream));
+    }
+
   private:
     // host mirrors -> HBM + the SpMV plan
     void upload()

@@ -716,6 +716,17 @@ int fdd_amg_smooth_polynomial_matvec_f32(const fdd_csr_plan *plan, float *work_o
     return 0;
 }
 
+int fdd_amg_smooth_update_matvec_from_zero(const fdd_csr_plan *plan, double *u, const int *p, const int *c, const double *v, const double *work_in, const double *Sr, const double *D, double coef, void *s)
+{
+    for (int i = 0; i < plan->num_rows; i++) u[i] = 0.0;
+    return fdd_amg_smooth_update_matvec(plan, u, p, c, v, work_in, Sr, D, coef, s);
+}
+int fdd_amg_smooth_update_matvec_f32(const fdd_csr_plan *plan, float *u, const int *p, const int *c, const float *v, const float *work_in, const float *Sr, const float *D, float coef, void *s);
+int fdd_amg_smooth_update_matvec_from_zero_f32(const fdd_csr_plan *plan, float *u, const int *p, const int *c, const float *v, const float *work_in, const float *Sr, const float *D, float coef, void *s)
+{
+    for (int i = 0; i < plan->num_rows; i++) u[i] = 0.0f;
+    return fdd_amg_smooth_update_matvec_f32(plan, u, p, c, v, work_in, Sr, D, coef, s);
+}
 int fdd_amg_smooth_update_matvec_f32(const fdd_csr_plan *plan, float *u, const int *p, const int *c, const float *v, const float *work_in, const float *Sr, const float *D, float coef, void *s)
 {
     (void)s;

@@ -1224,6 +1224,13 @@ def test_amg_smoother_fused_into_spmv(gpu, shape):
         du = dev(u, gpu)
         k("fdd_amg_smooth_update_matvec", plan, du, dp, dc, dv, dev(w_in, gpu), dev(Sr, gpu), dD, coef)
         assert same(host(du), u2), shape
+
+        # the same from u = 0 (pre-smoothing): u is written, not read -- the bits of the update on a zeroed vector
+        u0 = np.zeros(n)
+        L.orc_amg_main_update_field(P(u0), P(w1), P(D), n)
+        du0 = torch.full((n,), float("nan"), dtype=torch.float64, device=gpu)
+        k("fdd_amg_smooth_update_matvec_from_zero", plan, du0, dp, dc, dv, dev(w_in, gpu), dev(Sr, gpu), dD, coef)
+        assert same(host(du0), u0), shape
     finally:
         lib.hip().call("fdd_csr_plan_destroy", plan)
 
@@ -1303,6 +1310,9 @@ def test_f32_spmv_and_fused_smoother(gpu, shape):
         du = t32(u0)
         k("fdd_amg_smooth_update_matvec_f32", plan, du, dp, dc, dv, dx, t32(Sr_in), dD, float(coef))
         assert np.array_equal(du.cpu().numpy(), (u0 + (D * w).astype(f32)).astype(f32))
+        dz = torch.full((n,), float("nan"), dtype=torch.float32, device=gpu)
+        k("fdd_amg_smooth_update_matvec_from_zero_f32", plan, dz, dp, dc, dv, dx, t32(Sr_in), dD, float(coef))
+        assert np.array_equal(dz.cpu().numpy(), (f32(0) + (D * w).astype(f32)).astype(f32))
         # set
         d = nan()
         k("fdd_amg_vector_set_to_value_f32", d, 0.25, n)
