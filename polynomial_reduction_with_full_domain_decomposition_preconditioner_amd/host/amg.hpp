@@ -19,8 +19,9 @@
 #ifndef FDD_AMG_HPP
 #define FDD_AMG_HPP
 
-#include <utility>
 #include <chrono>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "config.hpp"
@@ -49,8 +50,17 @@ class Hierarchy
 {
   private:
     bool finalized = false;
-    void *graph = nullptr;
+    // one captured graph per OUTPUT vector of the cycle (vcycle_into: the caller's Krylov vectors stand in for
+    // levels[0].u, so that the correction is written where it is wanted instead of being copied there)
+    std::map<const void *, void *> graphs;
     bool graph_failed = false;
+
+    void destroy_graphs()
+    {
+        for (auto &kv : graphs)
+            if (kv.second != nullptr) (void)fdd_graph_destroy(kv.second);
+        graphs.clear();
+    }
     CSR_Matrix<double> coarse_inverse;
 
     // Chebyshev smoother, device branches of subdomain.tpp:19-83
@@ -239,11 +249,7 @@ class Hierarchy
 
     void set_f32_io(bool on)
     {
-        if (on != f32_io and graph != nullptr)
-        {
-            (void)fdd_graph_destroy(graph);
-            graph = nullptr;
-        }
+        if (on != f32_io) destroy_graphs();
         f32_io = on;
     }
     fdd::memory &rhs32()
@@ -258,11 +264,7 @@ class Hierarchy
     {
         if (bits != 64 and bits != 32) return false;
         if (bits == 32 and cheby_order < 2) return false;
-        if (bits != precision and graph != nullptr)
-        {
-            (void)fdd_graph_destroy(graph);
-            graph = nullptr;
-        }
+        if (bits != precision) destroy_graphs();
         precision = bits;
         return true;
     }
@@ -347,6 +349,7 @@ class Hierarchy
         if (f32) prepare32();
         if (use_graph and not graph_failed)
         {
+            void *&graph = graphs[(f32 and f32_io) ? levels[0].u32.ptr() : levels[0].u.ptr()];
             if (graph == nullptr)
             {
                 // captured once on a private stream (the caller's may be the default stream, which
@@ -382,6 +385,19 @@ class Hierarchy
             vcycle_launches32();
         else
             vcycle_launches();
+    }
+
+    // The same cycle with its correction written into `out` (at least fine_size() entries of the cycle's output
+    // type: double, or float under f32_io) instead of levels[0].u / u32: the caller's vector stands in for the level's
+    // for the duration of the call.  The first call with a given vector captures a graph of its own.
+    void vcycle_into(fdd::memory &out)
+    {
+        fdd::memory &slot = (precision == 32 and f32_io) ? levels[0].u32 : levels[0].u;
+        if (precision == 32) prepare32();
+        const fdd::memory saved = slot;
+        slot = fdd::memory(out.ptr(), (size_t)levels[0].n, (precision == 32 and f32_io) ? sizeof(float) : sizeof(double), false);
+        vcycle();
+        slot = saved;
     }
 };
 

@@ -1071,8 +1071,7 @@ class Subdomain
                 {
                     fdd::memory &rhs = amg_hierarchy.rhs32();
                     FDD_CALL(fdd_vector_scaling_dev_f32(rhs.template as<float>(), inv_dev + j, W[j], nd, stream));
-                    amg_hierarchy.vcycle();
-                    sp.ZA[j].copyFrom(amg_hierarchy.solution32(), (size_t)nd * sizeof(float));
+                    amg_hierarchy.vcycle_into(sp.ZA[j]);
                     operator_dofs_f32(sp.qa, sp.ZA[j]);
                 }
                 else if (jacobi)
@@ -2288,8 +2287,7 @@ class Subdomain
                     // z~_j = V(inv_j W_j): the V-cycle wants the normalised vector in its own buffer anyway
                     amg::Level &fine = amg_checked();
                     FDD_CALL(fdd_vector_scaling_dev(fine.f.as<double>(), inv_dev + j, W[j], nd, stream));
-                    amg_hierarchy.vcycle();
-                    ZA[j].copyFrom(fine.u, (size_t)nd * sizeof(DType));
+                    amg_hierarchy.vcycle_into(ZA[j]); // the correction lands in the preconditioned basis vector itself
                     operator_dofs(qa, ZA[j]);
                 }
                 else if (jacobi)
