@@ -37,9 +37,11 @@ roofline: the device kernel family with the largest total time in the timed
           bytes per BASELINE.md section 4.
 cpu_baseline: the CPU oracle (serial restatement of the reference's
           OCCA-Serial path) timed on this box's host cores on a bounded sample
-          by rank 0, at every N: the oracle's N-rank world (all ranks'
-          composites simulated in one process, one core) on a smaller cube
-          with the same rank grid.  A reported baseline, not a target.
+          by rank 0, at every N.  One rank: the oracle's own solver on one
+          core.  N ranks: one process = one core per rank (`cores: N`), the
+          restated kernels under the same host-layer solver, gloo for MPI
+          (tests/cpu_baseline_ranks.py), on a smaller cube with the same rank
+          grid.  A reported baseline, not a target.
 legs    : every time-to-tolerance object carries `converged` (the reference's
           500-iteration cap can be hit first).  At N > 1 the line also carries
           the block-local comparison point (`block_local`) next to the
@@ -91,11 +93,17 @@ def parse():
 
 
 def cpu_baseline(args, world, P):
-    """Oracle timed on host cores: same solver structure, same rank grid, on a smaller cube.  One rank: the
-    single-subdomain preconditioner; N ranks: the oracle's N-rank world -- every rank's full-domain-decomposition
-    composite (or its own elements only with --block-local), ring pull and coarse all-gather included -- simulated in
-    this one process on one core (SURVEY 8(d) asks for one core per subdomain; the oracle is a serial program, so the
-    count that was really used is what `cores` states)."""
+    """Oracle timed on host cores: same solver structure, same rank grid, on a smaller cube.
+    One rank: the oracle's own serial solver (single-subdomain preconditioner), one core.
+    N ranks: ONE PROCESS = ONE CORE PER RANK, as BASELINE.md section 2 / SURVEY 8(d) ask (tests/cpu_baseline_ranks.py: the
+    serial C restatement of the kernels behind the kernel C-ABI, a gloo group where MPI stood, the same host-layer solver
+    and preconditioner as `value`); if that child run is not possible (no CPU build of the host layer on this box), the
+    oracle's N-rank world simulated serially in this process on one core.  `cores` states what was really used."""
+    if world > 1:
+        try:
+            return cpu_baseline_ranks(args, world, P)
+        except Exception as exc:  # the fallback below says so in its sample text
+            print("bench.py: per-rank CPU baseline unavailable (%s); serial simulation instead" % exc, file=sys.stderr, flush=True)
     import numpy as np
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -149,6 +157,29 @@ def cpu_baseline(args, world, P):
         "kind": "port",
         "sample": f"{E[0]}x{E[1]}x{E[2]} elements ({e}^3 per rank, {world} rank{'s' if world > 1 else ''} simulated serially in one process), N={N}, {steps} outer PCG iterations, "
                   f"{kind} (inner GMRES(4)), serial C oracle, {dt:.1f} s (+ {t_setup:.1f} s of oracle setup outside the clock)",
+    }
+
+
+def cpu_baseline_ranks(args, world, P):
+    import subprocess
+
+    composite = args.composite_headline and not args.block_local
+    e = max(4, int(round((0.4 if composite else 0.6) * args.cpu_sample_elements)))
+    steps = args.cpu_sample_steps
+    script = os.path.join(ROOT, "tests", "cpu_baseline_ranks.py")
+    out = subprocess.run([sys.executable, script, str(world), str(e), str(args.degree), str(args.reduction), str(steps), "0" if composite else "1"], capture_output=True, text=True, timeout=900)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr[-400:])
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    E = r["elements"]
+    return {
+        "value": r["nodes"] * r["steps"] / r["seconds"],
+        "unit": "DOF-updates/s",
+        "cores": world,
+        "kind": "port",
+        "sample": f"{E[0]}x{E[1]}x{E[2]} elements ({e}^3 per rank), N={args.degree}, {steps} outer PCG iterations, {world} ranks = {world} processes = {world} host cores (one per subdomain), "
+                  f"{'full-domain-decomposition composite' if composite else 'block-local FDD preconditioner'} (inner GMRES(4)), the serial C restatement of the kernels under the host layer's solver, gloo in place of MPI, "
+                  f"{r['seconds']:.1f} s (+ {r['setup_seconds']:.1f} s of setup outside the clock)",
     }
 
 
