@@ -2,7 +2,7 @@
 """Hierarchy of the low-order preconditioner: operator complexity and outer PCG iterations to 1e-7 (reference-default
 preconditioner: V-cycle inside every inner GMRES step) for the geometric leading levels against plain smoothed
 aggregation (FDD_TUNE_AMG_GEOMETRIC=0), on the CPU stand-in of the kernel C-ABI (test infrastructure).
-python tools/amg_hierarchy_compare.py [elements per direction] [N] [geometric 0/1]"""
+python tests/amg_hierarchy_compare.py [elements per direction] [N] [geometric 0/1]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

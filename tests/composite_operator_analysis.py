@@ -10,7 +10,7 @@ tests/composite_iteration_counts.py), for one rank of an R-rank box:
      residual reduction overall and BY CLASS, for block-local, the composite, and the composite after symmetric
      diagonal scaling D^-1/2 A D^-1/2.
 
-python tools/composite_operator_analysis.py [ranks] [E per rank] [N]
+python tests/composite_operator_analysis.py [ranks] [E per rank] [N]
 """
 import json
 import os

@@ -1,6 +1,10 @@
+#!/usr/bin/env python3
+"""Outer iterations on the rod of DESIGN 5.3 (Dirichlet ends only, strips of 4 elements of degree 2 per rank) for a given superdomain
+overlap and number of inner Krylov steps: what the iteration growth with the rank count is made of.  Test infrastructure (CPU
+stand-in of the kernel C-ABI under a gloo group).  python tests/rod_iteration_experiment.py <ranks> <superdomain overlap> <inner steps>"""
 import os, sys, socket, json, tempfile
 import numpy as np
-ROOT="/root/repo"; sys.path.insert(0, ROOT); sys.path.insert(0, ROOT+"/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 def worker(rank, world, port, mesh_dir, N, red, w, sup_ov, inner, omega_env):
     os.environ["MASTER_ADDR"]="127.0.0.1"; os.environ["MASTER_PORT"]=str(port)
     import torch.distributed as dist
