@@ -38,10 +38,11 @@ roofline: the device kernel family with the largest total time in the timed
 cpu_baseline: the CPU oracle (serial restatement of the reference's
           OCCA-Serial path) timed on this box's host cores on a bounded sample
           by rank 0, at every N.  One rank: the oracle's own solver on one
-          core.  N ranks: one process = one core per rank (`cores: N`), the
-          restated kernels under the same host-layer solver, gloo for MPI
-          (tests/cpu_baseline_ranks.py), on a smaller cube with the same rank
-          grid.  A reported baseline, not a target.
+          core.  N ranks: one host core per rank (`cores: N`: the ranks are the
+          threads of one child process that loads no GPU library), the restated
+          kernels under the same host-layer solver (tests/cpu_baseline_ranks.py),
+          on a smaller cube with the same rank grid.  A reported baseline, not
+          a target.
 legs    : every time-to-tolerance object carries `converged` (the reference's
           500-iteration cap can be hit first).  At N > 1 the line also carries
           the block-local comparison point (`block_local`) next to the
@@ -95,10 +96,11 @@ def parse():
 def cpu_baseline(args, world, P):
     """Oracle timed on host cores: same solver structure, same rank grid, on a smaller cube.
     One rank: the oracle's own serial solver (single-subdomain preconditioner), one core.
-    N ranks: ONE PROCESS = ONE CORE PER RANK, as BASELINE.md section 2 / SURVEY 8(d) ask (tests/cpu_baseline_ranks.py: the
-    serial C restatement of the kernels behind the kernel C-ABI, a gloo group where MPI stood, the same host-layer solver
-    and preconditioner as `value`); if that child run is not possible (no CPU build of the host layer on this box), the
-    oracle's N-rank world simulated serially in this process on one core.  `cores` states what was really used."""
+    N ranks: ONE HOST CORE PER RANK, as BASELINE.md section 2 / SURVEY 8(d) ask (tests/cpu_baseline_ranks.py, a child
+    process without any GPU library: every rank a host thread on the serial C restatement of the kernels behind the kernel
+    C-ABI, the in-process communicator where MPI stood, the same host-layer solver and preconditioner as `value`); if that
+    child run is not possible (no CPU build of the host layer on this box), the oracle's N-rank world simulated serially in
+    this process on one core.  `cores` states what was really used."""
     if world > 1:
         try:
             return cpu_baseline_ranks(args, world, P)
@@ -177,8 +179,8 @@ def cpu_baseline_ranks(args, world, P):
         "unit": "DOF-updates/s",
         "cores": world,
         "kind": "port",
-        "sample": f"{E[0]}x{E[1]}x{E[2]} elements ({e}^3 per rank), N={args.degree}, {steps} outer PCG iterations, {world} ranks = {world} processes = {world} host cores (one per subdomain), "
-                  f"{'full-domain-decomposition composite' if composite else 'block-local FDD preconditioner'} (inner GMRES(4)), the serial C restatement of the kernels under the host layer's solver, gloo in place of MPI, "
+        "sample": f"{E[0]}x{E[1]}x{E[2]} elements ({e}^3 per rank), N={args.degree}, {steps} outer PCG iterations, {world} ranks = {world} host threads of one child process = {world} host cores (one per subdomain), "
+                  f"{'full-domain-decomposition composite' if composite else 'block-local FDD preconditioner'} (inner GMRES(4)), the serial C restatement of the kernels under the host layer's solver, the in-process communicator in place of MPI, "
                   f"{r['seconds']:.1f} s (+ {r['setup_seconds']:.1f} s of setup outside the clock)",
     }
 

@@ -433,6 +433,7 @@ struct Options
     double upper_factor = 1.1;
     int power_iterations = 25;
     bool smooth_prolongator = true;
+    double geometric_eig_ratio = 0.15; // lower end of the Chebyshev smoother's interval, as a fraction of lambda_max, on the levels coarsened on the lattice
     int geometric_min_nodes = 5;  // lattices with fewer nodes per direction and element are left to the aggregation
     bool geometric_levels = true; // with a Lattice: the leading levels coarsen the GLL lattice itself (see geometric_level); false: aggregation from level 0
     int double_aggregation_levels = 0; // > 0: the finest levels aggregate TWICE (aggregates of aggregates, through the tentative Galerkin graph)
@@ -827,7 +828,15 @@ inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = fal
         L.D.resize(n);
         for (int i = 0; i < n; i++) L.D[i] = 1.0 / std::sqrt(d[i]);
         const double lmax = max_eigenvalue_scaled(A, L.D, o.power_iterations);
-        L.coefs = chebyshev_coefficients(lmax, o);
+        {
+            // the levels that are coarsened on the lattice lose 2.33 nodes per direction in one step (N = 7), more than an
+            // aggregation level: the smoother in front of such a step has to reach further down the spectrum
+            static const double geo_ratio_env = getenv("FDD_TUNE_AMG_GEOMETRIC_EIG_RATIO") ? atof(getenv("FDD_TUNE_AMG_GEOMETRIC_EIG_RATIO")) : 0.0; // development override
+            Options ol = o;
+            const bool lattice_next = geometric and lattice.active(geometric_done > 0 ? 3 : o.geometric_min_nodes) and lattice.rows.cols == n and n > o.coarsest_size;
+            if (lattice_next) ol.eig_ratio = geo_ratio_env > 0.0 ? geo_ratio_env : o.geometric_eig_ratio;
+            L.coefs = chebyshev_coefficients(lmax, ol);
+        }
         if (verbose) printf("low_order: level %d rows %d nnz %lld lambda_max(DAD) %.4f\n", l, n, A.nnz(), lmax);
         lap("diagonal + lambda_max", l);
 
