@@ -166,7 +166,7 @@ def cpu_baseline_ranks(args, world, P):
     import subprocess
 
     composite = args.composite_headline and not args.block_local
-    e = max(4, int(round((0.4 if composite else 0.6) * args.cpu_sample_elements)))
+    e = max(4, int(round((0.6 if composite else 1.0) * args.cpu_sample_elements)))  # per rank: about 10 s of work on every core
     steps = args.cpu_sample_steps
     script = os.path.join(ROOT, "tests", "cpu_baseline_ranks.py")
     out = subprocess.run([sys.executable, script, str(world), str(e), str(args.degree), str(args.reduction), str(steps), "0" if composite else "1"], capture_output=True, text=True, timeout=900)
