@@ -242,3 +242,43 @@ print("ok", sizes, its)
 """ % (S.ROOT, S.HERE, HOST_CPU_SO)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def test_geometric_hierarchy_on_a_deformed_mesh(tmp_path):
+    """The lattice-coarsened levels on a non-affine mesh read from the reference's files (interpolation is multi-linear in
+    the elements' REFERENCE coordinates; the low-order matrix has up to 15 entries per row there): Galerkin levels, row
+    sums of one away from the Dirichlet boundary, and the reference-default preconditioner (V-cycle inside the inner
+    GMRES) converging in a handful of outer iterations to the manufactured solution."""
+    subprocess.check_call(["make", "-C", S.ORACLE_DIR, "-s"])
+    subprocess.check_call(["make", "-C", SHIM_DIR, "-s"])
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import support as S
+from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H, lib
+lib._host = lib._Lib(%r, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
+H.init(0, use_torch_stream=False); H.comm_single(); H.set_print(False)
+E, N, red, d = (3, 2, 2), 7, 6, %r
+for deg in S.level_degrees(N, red):
+    S.write_mesh_files(d, S.DeformedMesh(E, deg, 0.05))
+p = H.Problem.from_directory(d, N, red)
+assert p.amg_build(coarsest_size=30) >= 3
+L = p.amg_levels()
+sizes = [lv["A"].shape[0] for lv in L]
+assert sizes[:3] == [20 * 13 * 13, 8 * 5 * 5, 2 * 1 * 1], sizes
+assert np.diff(L[0]["A"].indptr).max() > 7          # the deformed cells couple more than the 7-point neighbours
+for l in range(2):
+    P = L[l]["P"].tocsr()
+    rs = np.asarray(P.sum(axis=1)).ravel()
+    assert rs.max() <= 1 + 1e-13 and (np.abs(rs - 1) <= 1e-13).sum() >= 2
+    G = (P.T @ L[l]["A"] @ P).tocsr()
+    assert abs(G - L[l + 1]["A"]).max() <= 1e-12 * abs(G).max()
+u_star, f = p.make_rhs_from(S.seeded_uniform(p.n, 1234))
+u, its, hist = p.solve(f, "fcg")
+assert hist[-1] <= 1e-7 * hist[0] and its <= 6, (its, hist[-1] / hist[0])
+assert np.abs(u - u_star).max() <= 1e-5 * np.abs(u_star).max()
+print("ok", sizes, its)
+""" % (S.ROOT, S.HERE, HOST_CPU_SO, str(tmp_path / "curved"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
