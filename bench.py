@@ -37,7 +37,7 @@ roofline: the device kernel family with the largest total time in the timed
           bytes per BASELINE.md section 4.
 cpu_baseline: the CPU oracle (serial restatement of the reference's
           OCCA-Serial path) timed on this box's host cores on a bounded sample
-          by rank 0, at every N.  One rank: the oracle's own solver on one
+          by rank 0, at every N.  One rank: the CPU oracle's own solver on one
           core.  N ranks: one host core per rank (`cores: N`: the ranks are the
           threads of one child process that loads no GPU library), the restated
           kernels under the same host-layer solver (tests/cpu_baseline_ranks.py),
