@@ -143,7 +143,8 @@ class Hierarchy
     fdd::memory coarse_inverse_val32;
     fdd_csr_plan *coarse_plan32 = nullptr;
 
-    static fdd::memory to_f32(const std::vector<double> &v)
+    template <typename Vec>
+    static fdd::memory to_f32(const Vec &v)
     {
         std::vector<float> t(v.begin(), v.end());
         fdd::memory m = fdd::dev().malloc<float>(std::max<size_t>(t.size(), 1));
@@ -276,22 +277,44 @@ class Hierarchy
     // CSR arrays on the host; P_* null on the coarsest level
     void add_level(int n, const int *A_ptr, const int *A_col, const double *A_val, const double *D_val, const double *coefs_, int n_coarse, const int *P_ptr, const int *P_col, const double *P_val)
     {
+        Level &L = new_level(n);
+        L.A.assemble_from_csr(n, n, A_ptr, A_col, A_val);
+        if (P_ptr) L.P.assemble_from_csr(n, n_coarse, P_ptr, P_col, P_val);
+        finish_level(L, D_val, coefs_, P_ptr != nullptr);
+    }
+
+    // the same with the host arrays of the level handed over instead of copied (Subdomain::amg_build's own hierarchy)
+    void add_level_adopt(int n, std::vector<int> &&A_ptr, fdd::low_order::pod_vector<int> &&A_col, fdd::low_order::pod_vector<double> &&A_val, const double *D_val, const double *coefs_, int n_coarse, std::vector<int> &&P_ptr,
+                         fdd::low_order::pod_vector<int> &&P_col, fdd::low_order::pod_vector<double> &&P_val)
+    {
+        Level &L = new_level(n);
+        const bool has_P = not P_ptr.empty();
+        L.A.adopt_csr(n, n, std::move(A_ptr), std::move(A_col), std::move(A_val));
+        if (has_P) L.P.adopt_csr(n, n_coarse, std::move(P_ptr), std::move(P_col), std::move(P_val));
+        finish_level(L, D_val, coefs_, has_P);
+    }
+
+  private:
+
+    Level &new_level(int n)
+    {
         if (levels.capacity() < 32) levels.reserve(32); // a growing vector would copy every level built so far, host mirrors included
         levels.emplace_back();
-        Level &L = levels.back();
-        L.n = n;
-        L.A.assemble_from_csr(n, n, A_ptr, A_col, A_val);
-        if (P_ptr)
-        {
-            L.P.assemble_from_csr(n, n_coarse, P_ptr, P_col, P_val);
-            L.P.transpose(L.R); // R_fem[l] = P^T (subdomain.tpp:3526-3545)
-        }
+        levels.back().n = n;
+        return levels.back();
+    }
+    void finish_level(Level &L, const double *D_val, const double *coefs_, bool has_P)
+    {
+        const int n = L.n;
+        if (has_P) L.P.transpose(L.R); // R_fem[l] = P^T (subdomain.tpp:3526-3545)
         L.D_val = fdd::dev().malloc<double>(n);
         L.D_val.copyFrom(D_val, (size_t)n * sizeof(double));
         L.D_hst.assign(D_val, D_val + n);
         L.coefs.assign(coefs_, coefs_ + cheby_order);
         for (fdd::memory *m : {&L.f, &L.u, &L.r, &L.v, &L.w, &L.work}) *m = fdd::dev().malloc<double>(n);
     }
+
+  public:
 
     void finalize()
     {

@@ -909,42 +909,46 @@ inline Composite build(DomainMap &domains, const std::vector<int> &poly_degree, 
     // in two classes takes the lower one, as the shifted ids of the reference would.
     c.point_dof.assign(NP, -1);
     {
-        std::unordered_map<long long, int> key_class;
-        key_class.reserve((size_t)NP);
+        // every distinct key gets a slot (open addressing: 18 million points at C4's size, and a node-based hash map
+        // spends 4 s there); the points remember their slot, so class and dof are array reads afterwards
+        fdd::KeySlots slots((size_t)NP);
+        std::vector<int> slot_of_point(NP, -1);
+        std::vector<signed char> slot_class;
         for (int p = 0; p < NP; p++)
             if (cls[p] >= 0)
             {
-                auto it = key_class.find(key[p]);
-                if (it == key_class.end())
-                    key_class[key[p]] = cls[p];
+                const int sl = slots.find_or_insert(key[p]);
+                slot_of_point[p] = sl;
+                if (sl == (int)slot_class.size())
+                    slot_class.push_back((signed char)cls[p]);
                 else
-                    it->second = std::min(it->second, cls[p]);
+                    slot_class[sl] = std::min(slot_class[sl], (signed char)cls[p]);
             }
+        const int num_slots = (int)slot_class.size();
+        std::vector<int> slot_dof(num_slots, -1);
         // leading dofs: regular keys on the rank's own elements, in the Domain's node order
-        std::unordered_map<long long, int> dof_of_key;
-        dof_of_key.reserve(key_class.size());
         int count = 0;
         {
             const int own_points = (int)own_point_node.size();
-            std::vector<long long> key_of_node(own_num_nodes, 0);
+            std::vector<int> slot_of_node(own_num_nodes, -1);
             for (int p = 0; p < own_points and p < NP; p++)
-                if (cls[p] >= 0 and key_class[key[p]] == 0) key_of_node[own_point_node[p]] = key[p];
+                if (cls[p] >= 0 and slot_class[slot_of_point[p]] == 0) slot_of_node[own_point_node[p]] = slot_of_point[p];
             for (int nd = 0; nd < own_num_nodes; nd++)
-                if (key_of_node[nd] != 0 and not dof_of_key.count(key_of_node[nd])) dof_of_key[key_of_node[nd]] = count++;
+                if (slot_of_node[nd] >= 0 and slot_dof[slot_of_node[nd]] < 0) slot_dof[slot_of_node[nd]] = count++;
             c.num_own_dofs = count;
         }
         for (int want = 0; want < 3; want++)
         {
-            std::vector<long long> keys;
-            for (auto &kv : key_class)
-                if (kv.second == want and not dof_of_key.count(kv.first)) keys.push_back(kv.first);
+            std::vector<std::pair<long long, int>> keys; // (key, slot) of the class's keys without a dof yet, ascending key
+            for (int sl = 0; sl < num_slots; sl++)
+                if (slot_class[sl] == want and slot_dof[sl] < 0) keys.emplace_back(slots.key_of_slot(sl), sl);
             std::sort(keys.begin(), keys.end());
-            for (long long k : keys) dof_of_key[k] = count++;
+            for (const std::pair<long long, int> &k : keys) slot_dof[k.second] = count++;
             if (want == 1) c.sub_num_dofs = count;
         }
         c.sub_num_ext_dofs = count;
         for (int p = 0; p < NP; p++)
-            if (cls[p] >= 0) c.point_dof[p] = dof_of_key[key[p]];
+            if (cls[p] >= 0) c.point_dof[p] = slot_dof[slot_of_point[p]];
     }
 
     phase("numbering");

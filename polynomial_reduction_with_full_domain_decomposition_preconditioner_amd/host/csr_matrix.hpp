@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "config.hpp"
+#include "host_parallel.hpp"
 
 template <typename DType>
 class CSR_Matrix
@@ -56,8 +57,8 @@ class CSR_Matrix
 
     // host mirrors (valid after assemble)
     std::vector<int> ptr_hst;
-    std::vector<int> col_hst;
-    std::vector<DType> val_hst;
+    fdd::low_order::pod_vector<int> col_hst; // resize() leaves new entries uninitialised (host_parallel.hpp)
+    fdd::low_order::pod_vector<DType> val_hst;
 
     CSR_Matrix() {}
     CSR_Matrix(int num_rows_, int num_cols_) { initialize(num_rows_, num_cols_); }
@@ -140,6 +141,17 @@ class CSR_Matrix
         ptr_hst.assign(ptr_, ptr_ + num_rows + 1);
         col_hst.assign(col_, col_ + ptr_[num_rows]);
         val_hst.assign(val_, val_ + ptr_[num_rows]);
+        upload();
+    }
+
+    // the same, taking the caller's arrays over instead of copying them (the setup's level matrices: a gigabyte at C2)
+    void adopt_csr(int num_rows_, int num_cols_, std::vector<int> &&ptr_, fdd::low_order::pod_vector<int> &&col_, fdd::low_order::pod_vector<DType> &&val_)
+    {
+        initialize(num_rows_, num_cols_);
+        if ((num_rows == 0) or (num_cols == 0) or (ptr_[num_rows] == 0)) return;
+        ptr_hst = std::move(ptr_);
+        col_hst = std::move(col_);
+        val_hst = std::move(val_);
         upload();
     }
 
@@ -238,8 +250,8 @@ class CSR_Matrix
     void release_host()
     {
         std::vector<int>().swap(ptr_hst);
-        std::vector<int>().swap(col_hst);
-        std::vector<DType>().swap(val_hst);
+        fdd::low_order::pod_vector<int>().swap(col_hst);
+        fdd::low_order::pod_vector<DType>().swap(val_hst);
     }
 
     // ... and fetch them back from the device copies when a later setup step wants to walk the matrix again
@@ -271,24 +283,36 @@ class CSR_Matrix
         // What add_entry + assemble (csr_matrix.tpp:288-300) produces, by a counting transpose instead of a sort of
         // tuples: this matrix's rows are in ascending order with sorted, duplicate-free columns, so the transposed
         // rows come out sorted and duplicate-free; entries assemble would drop (|v| <= tolerance) are dropped here.
+        // Ranges of the transposed rows on the host threads: a thread scans this matrix in row order and places the
+        // entries of ITS columns (the serial loop's result).
         std::vector<int> tp(num_cols + 1, 0);
-        for (int i = 0; i < num_rows; i++)
-            for (int j = ptr_hst[i]; j < ptr_hst[i + 1]; j++)
-                if (std::abs(val_hst[j]) > At.sparse_tolerance) tp[col_hst[j] + 1]++;
+        const DType tol = At.sparse_tolerance;
+        const int parts = fdd::low_order::range_parts(num_cols);
+        fdd::low_order::parallel_ranges(num_cols, parts, [&](long long c0, long long c1, int) {
+            const int nnz = ptr_hst[num_rows];
+            for (int j = 0; j < nnz; j++)
+            {
+                const int c = col_hst[j];
+                if (c >= c0 and c < c1 and std::abs(val_hst[j]) > tol) tp[c + 1]++;
+            }
+        });
         for (int c = 0; c < num_cols; c++) tp[c + 1] += tp[c];
-        std::vector<int> tc(tp[num_cols]);
-        std::vector<DType> tv(tp[num_cols]);
-        std::vector<int> next(tp.begin(), tp.end() - 1);
-        for (int i = 0; i < num_rows; i++)
-            for (int j = ptr_hst[i]; j < ptr_hst[i + 1]; j++)
-                if (std::abs(val_hst[j]) > At.sparse_tolerance)
+        fdd::low_order::pod_vector<int> tc(tp[num_cols]);
+        fdd::low_order::pod_vector<DType> tv(tp[num_cols]);
+        fdd::low_order::parallel_ranges(num_cols, parts, [&](long long c0, long long c1, int) {
+            std::vector<int> next(tp.begin() + c0, tp.begin() + c1);
+            for (int i = 0; i < num_rows; i++)
+                for (int j = ptr_hst[i]; j < ptr_hst[i + 1]; j++)
                 {
-                    const int k = next[col_hst[j]]++;
+                    const int c = col_hst[j];
+                    if (c < c0 or c >= c1 or not(std::abs(val_hst[j]) > tol)) continue;
+                    const int k = next[c - c0]++;
                     tc[k] = i;
                     tv[k] = val_hst[j];
                 }
+        });
         if (tp[num_cols] == 0) return;
-        At.assemble_from_csr(num_cols, num_rows, tp.data(), tc.data(), tv.data());
+        At.adopt_csr(num_cols, num_rows, std::move(tp), std::move(tc), std::move(tv));
     }
 
     void diagonal(fdd::memory D)

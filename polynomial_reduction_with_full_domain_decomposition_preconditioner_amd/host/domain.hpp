@@ -412,6 +412,7 @@ class Domain
     {
         mesh = std::move(mesh_);
         poly_degree = mesh.poly_degree;
+        fdd::SetupTimer timing("Domain::initialize", fdd::comm().rank == 0);
         fdd::globals().dim = mesh.dim; // `dim` is a global set by the last mesh read (config.hpp:48)
         const int dim = mesh.dim;
 
@@ -450,6 +451,7 @@ class Domain
             G_ptrs[g] = geom_fact[g].as<double>();
         }
 
+        timing.lap("elements, mask and factors to the device");
         // ---- communication / local numbering (domain.tpp:233-302) ----
         rstdout("Setting up domain stitching handle...\n");
 
@@ -459,15 +461,11 @@ class Domain
         std::vector<int> tid(num_local_points);
         int num_tmp = 0;
         {
-            std::unordered_map<long long, int> first;
-            first.reserve((size_t)num_local_points);
-            for (int p = 0; p < num_local_points; p++)
-            {
-                auto ins = first.try_emplace(mesh.glo_num[p], num_tmp);
-                if (ins.second) num_tmp++;
-                tid[p] = ins.first->second;
-            }
+            fdd::KeySlots first((size_t)num_local_points);
+            for (int p = 0; p < num_local_points; p++) tid[p] = first.find_or_insert(mesh.glo_num[p]);
+            num_tmp = first.size();
         }
+        timing.lap("temporary node ids");
         std::vector<int> local_node_degree(num_tmp, 0);
         for (int p = 0; p < num_local_points; p++) local_node_degree[tid[p]]++;
 
@@ -502,6 +500,7 @@ class Domain
         }
 
         num_local_nodes = num_tmp;
+        timing.lap("node numbering");
 
         // gs_setup (domain.tpp:283-284): dense interface slots shared by all ranks
         {
@@ -526,11 +525,26 @@ class Domain
             num_total_nodes = (long long)std::llround(owned) + num_interface_slots;
         }
 
-        Q.initialize(num_local_points, num_local_nodes);
-        Q.reserve(num_local_points);
-        for (int p = 0; p < num_local_points; p++) Q.add_entry(p, local_node_idx[tid[p]], 1.0);
-        Q.assemble();
+        timing.lap("interface slots");
+        {
+            // one unit entry per point, rows in order: what add_entry + assemble (domain.tpp:286-296) produce, written directly
+            std::vector<int> q_ptr((size_t)num_local_points + 1);
+            fdd::low_order::pod_vector<int> q_col((size_t)num_local_points);
+            fdd::low_order::pod_vector<DType> q_val((size_t)num_local_points);
+            fdd::low_order::parallel_ranges(num_local_points, fdd::low_order::range_parts(num_local_points), [&](long long p0, long long p1, int) {
+                for (long long p = p0; p < p1; p++)
+                {
+                    q_ptr[p] = (int)p;
+                    q_col[p] = local_node_idx[tid[p]];
+                    q_val[p] = (DType)1.0;
+                }
+            });
+            q_ptr[num_local_points] = num_local_points;
+            Q.adopt_csr(num_local_points, num_local_nodes, std::move(q_ptr), std::move(q_col), std::move(q_val));
+        }
+        timing.lap("Q");
         Q.transpose(Qt);
+        timing.lap("Qt");
 
         reduce_ws = fdd::dev().malloc<double>(fdd_reduce_workspace_doubles());
         scalars = fdd::dev().malloc<double>(8);

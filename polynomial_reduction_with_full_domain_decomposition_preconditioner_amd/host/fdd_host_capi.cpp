@@ -64,8 +64,19 @@ static std::vector<int> level_degrees(int N, int reduction)
     return d;
 }
 
+// FDD_SETUP_TIMING=1: rank 0 prints the host time of the setup's parts
+static double setup_clock() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void setup_lap(const char *what, int degree, double &mark)
+{
+    static const bool on = getenv("FDD_SETUP_TIMING") != nullptr;
+    const double t = setup_clock();
+    if (on and fdd::comm().rank == 0) printf("setup: %-28s N = %-2d %8.3f s\n", what, degree, t - mark);
+    mark = t;
+}
+
 static void finish_problem(fddh_problem *p, int flags, int sub_overlap, int sup_overlap)
 {
+    double mark = setup_clock();
     const int with_subdomain = flags & FDDH_WITH_SUBDOMAIN;
     Domain<SType> &dom = p->fine();
     p->a = fdd::dev().malloc<double>(dom.num_local_points);
@@ -78,6 +89,7 @@ static void finish_problem(fddh_problem *p, int flags, int sub_overlap, int sup_
         p->subdomain->block_local = (flags & FDDH_BLOCK_LOCAL) != 0;
         p->subdomain->force_composite = (flags & FDDH_FORCE_COMPOSITE) != 0;
         p->subdomain->initialize(p->domains, p->poly_degree, p->poly_reduction, sub_overlap, sup_overlap);
+        setup_lap("Subdomain::initialize", p->poly_degree, mark);
         p->sa = fdd::dev().malloc<double>(p->subdomain->num_values);
         p->sb = fdd::dev().malloc<double>(p->subdomain->num_values);
         dom.use_preconditioner = true;
@@ -451,7 +463,11 @@ int fddh_problem_create_box_ex(fddh_problem **out, const int E[3], const int P[3
         for (int deg : p->degrees)
         {
             rstdout("Setting up domain \"N = %d\" object...\n", deg);
-            p->domains[deg].initialize(fdd::make_box_mesh<SType>(spec, deg, fdd::comm().rank));
+            double mark = setup_clock();
+            MeshData<SType> mesh = fdd::make_box_mesh<SType>(spec, deg, fdd::comm().rank);
+            setup_lap("box mesh", deg, mark);
+            p->domains[deg].initialize(std::move(mesh));
+            setup_lap("Domain::initialize", deg, mark);
         }
         // `dim` follows the last mesh read in the reference; keep the fine one current
         fdd::globals().dim = p->fine().mesh.dim;

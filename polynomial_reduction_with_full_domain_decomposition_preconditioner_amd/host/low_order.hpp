@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,82 +31,88 @@
 #include <thread>
 #include <vector>
 
+#include "host_parallel.hpp"
+
 namespace fdd
 {
 namespace low_order
 {
 
-// Setup runs on the host cores of the rank (one rank per GPU: 16 of them on a one-GPU box): contiguous index
-// ranges on std::thread, results concatenated in range order, so every output is the one the serial loop gives.
-// FDD_HOST_THREADS overrides the count (1 = serial).
-inline int host_threads()
-{
-    if (const char *e = getenv("FDD_HOST_THREADS")) return std::max(1, atoi(e));
-    unsigned hw = std::thread::hardware_concurrency();
-    // several ranks on the node (LOCAL_WORLD_SIZE from the launcher): each takes its share of the cores
-    if (const char *e = getenv("LOCAL_WORLD_SIZE"))
-    {
-        const int local = atoi(e);
-        if (local > 1) hw = std::max(1u, hw / (unsigned)local);
-    }
-    return (int)std::min(16u, std::max(1u, hw));
-}
-
-// f(begin, end, part) for `parts` contiguous ranges covering [0, n)
-template <typename F>
-inline void parallel_ranges(long long n, int parts, F f)
-{
-    if (parts <= 1 or n < 2 * parts)
-    {
-        f(0LL, n, 0);
-        return;
-    }
-    std::vector<std::thread> pool;
-    for (int t = 0; t < parts; t++) pool.emplace_back(f, n * t / parts, n * (t + 1) / parts, t);
-    for (std::thread &th : pool) th.join();
-}
-
-inline int range_parts(long long n)
-{
-    const int t = host_threads();
-    return (n < 2 * t) ? 1 : t;
-}
-
 struct HostCSR
 {
     int rows = 0, cols = 0;
-    std::vector<int> ptr, col;
-    std::vector<double> val;
+    std::vector<int> ptr;
+    pod_vector<int> col; // resize() does not initialise (host_parallel.hpp)
+    pod_vector<double> val;
     long long nnz() const { return (long long)col.size(); }
 };
 
-// rows of (row, col, val) triplets -> CSR with duplicates summed, columns sorted
-inline HostCSR from_triplets(int rows, int cols, std::vector<int> &ti, std::vector<int> &tj, std::vector<double> &tv)
+// rows of (row, col, val) triplets -> CSR with duplicates summed, columns sorted.  The triplets come in `parts` lists
+// (one per producer thread, in order); every step runs on row ranges: a thread counts / places the triplets of ITS rows
+// while scanning the lists in order, so a row's entries arrive in the order of the one concatenated list.
+struct TripletParts
+{
+    std::vector<std::vector<int>> ti, tj;
+    std::vector<std::vector<double>> tv;
+    std::vector<int> row_min, row_max; // per list: the rows it touches (lists whose range misses a thread's rows are skipped)
+    explicit TripletParts(int parts) : ti(parts), tj(parts), tv(parts), row_min(parts, 0), row_max(parts, -1) {}
+    void set(int part, std::vector<int> &&i, std::vector<int> &&j, std::vector<double> &&v)
+    {
+        int lo = INT_MAX, hi = -1;
+        for (int r : i)
+        {
+            lo = std::min(lo, r);
+            hi = std::max(hi, r);
+        }
+        row_min[part] = lo;
+        row_max[part] = hi;
+        ti[part] = std::move(i);
+        tj[part] = std::move(j);
+        tv[part] = std::move(v);
+    }
+};
+
+inline HostCSR from_triplets(int rows, int cols, TripletParts &T)
 {
     HostCSR A;
     A.rows = rows;
     A.cols = cols;
     A.ptr.assign(rows + 1, 0);
-    const size_t n = ti.size();
-    for (size_t t = 0; t < n; t++) A.ptr[ti[t] + 1]++;
-    for (int i = 0; i < rows; i++) A.ptr[i + 1] += A.ptr[i];
-    std::vector<int> cj(n);
-    std::vector<double> cv(n);
-    {
-        std::vector<int> fill(A.ptr.begin(), A.ptr.end() - 1);
-        for (size_t t = 0; t < n; t++)
+    size_t n = 0;
+    for (const std::vector<int> &v : T.ti) n += v.size();
+    const int lists = (int)T.ti.size();
+    const int parts = range_parts(rows);
+    parallel_ranges(rows, parts, [&](long long r0, long long r1, int) {
+        for (int l = 0; l < lists; l++)
         {
-            const int p = fill[ti[t]]++;
-            cj[p] = tj[t];
-            cv[p] = tv[t];
+            if (T.row_max[l] < r0 or T.row_min[l] >= r1) continue;
+            for (int r : T.ti[l])
+                if (r >= r0 and r < r1) A.ptr[r + 1]++;
         }
-    }
-    std::vector<int>().swap(ti);
-    std::vector<int>().swap(tj);
-    std::vector<double>().swap(tv);
+    });
+    for (int i = 0; i < rows; i++) A.ptr[i + 1] += A.ptr[i];
+    pod_vector<int> cj(n);
+    pod_vector<double> cv(n);
+    parallel_ranges(rows, parts, [&](long long r0, long long r1, int) {
+        std::vector<int> fill(A.ptr.begin() + r0, A.ptr.begin() + r1);
+        for (int l = 0; l < lists; l++)
+        {
+            if (T.row_max[l] < r0 or T.row_min[l] >= r1) continue;
+            const std::vector<int> &ti = T.ti[l], &tj = T.tj[l];
+            const std::vector<double> &tv = T.tv[l];
+            for (size_t t = 0; t < ti.size(); t++)
+            {
+                const int r = ti[t];
+                if (r < r0 or r >= r1) continue;
+                const int p = fill[r - r0]++;
+                cj[p] = tj[t];
+                cv[p] = tv[t];
+            }
+        }
+    });
+    T = TripletParts(0);
     // sort each row by column (stable: insertion order of equal columns is kept) and merge duplicates;
     // row ranges in parallel, pieces concatenated in row order
-    const int parts = range_parts(rows);
     std::vector<std::vector<int>> pcol(parts);
     std::vector<std::vector<double>> pval(parts);
     std::vector<int> row_len(rows, 0);
@@ -113,17 +120,39 @@ inline HostCSR from_triplets(int rows, int cols, std::vector<int> &ti, std::vect
         std::vector<int> order;
         std::vector<int> oc; // thread-local while growing (the headers in pcol / pval share cache lines), moved out at the end
         std::vector<double> ov;
+        oc.reserve((size_t)(A.ptr[r1] - A.ptr[r0]));
+        ov.reserve((size_t)(A.ptr[r1] - A.ptr[r0]));
         for (long long i = r0; i < r1; i++)
         {
             const int a = A.ptr[i], b = A.ptr[i + 1];
-            order.resize(b - a);
-            for (int k = 0; k < b - a; k++) order[k] = a + k;
-            std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return cj[p] < cj[q]; });
+            const bool short_row = (b - a) <= 64; // the usual case (a few entries per element): insertion sort in place, stable too
+            if (short_row)
+            {
+                for (int k = a + 1; k < b; k++)
+                {
+                    const int c = cj[k];
+                    const double v = cv[k];
+                    int q = k - 1;
+                    for (; q >= a and cj[q] > c; q--)
+                    {
+                        cj[q + 1] = cj[q];
+                        cv[q + 1] = cv[q];
+                    }
+                    cj[q + 1] = c;
+                    cv[q + 1] = v;
+                }
+            }
+            else
+            {
+                order.resize(b - a);
+                for (int k = 0; k < b - a; k++) order[k] = a + k;
+                std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return cj[p] < cj[q]; });
+            }
             int last = -1;
             const size_t before = oc.size();
             for (int k = 0; k < b - a; k++)
             {
-                const int p = order[k];
+                const int p = short_row ? a + k : order[k];
                 if (cj[p] != last)
                 {
                     oc.push_back(cj[p]);
@@ -140,16 +169,16 @@ inline HostCSR from_triplets(int rows, int cols, std::vector<int> &ti, std::vect
     });
     A.ptr[0] = 0; // the old pointers (into cj / cv) are no longer needed
     for (int i = 0; i < rows; i++) A.ptr[i + 1] = A.ptr[i] + row_len[i];
-    A.col.reserve(A.ptr[rows]);
-    A.val.reserve(A.ptr[rows]);
-    for (int t = 0; t < parts; t++)
-    {
-        A.col.insert(A.col.end(), pcol[t].begin(), pcol[t].end());
-        A.val.insert(A.val.end(), pval[t].begin(), pval[t].end());
-        std::vector<int>().swap(pcol[t]);
-        std::vector<double>().swap(pval[t]);
-    }
+    concatenate(A.col, pcol);
+    concatenate(A.val, pval);
     return A;
+}
+
+inline HostCSR from_triplets(int rows, int cols, std::vector<int> &ti, std::vector<int> &tj, std::vector<double> &tv)
+{
+    TripletParts T(1);
+    T.set(0, std::move(ti), std::move(tj), std::move(tv));
+    return from_triplets(rows, cols, T);
 }
 
 // subdomain.tpp:2823-3060: P1 stiffness of the 6 tetrahedra of every GLL sub-cell, summed on the dofs.
@@ -168,8 +197,8 @@ inline HostCSR assemble_fem(const double *x, const double *y, const double *z, c
     // stencil (a vertex pair of a cell differs by at most one step per direction) and only then emitted as triplets:
     // 6 * 16 entries per cell would be 10^9 triplets (17 GB) at 32^3 elements of degree 7.
     const int parts = range_parts(num_elements);
-    std::vector<std::vector<int>> pti(parts), ptj(parts);
-    std::vector<std::vector<double>> ptv(parts);
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    TripletParts T(parts);
     parallel_ranges(num_elements, parts, [&](long long e0, long long e1, int part) {
     std::vector<int> ti, tj; // thread-local while growing, moved out at the end
     std::vector<double> tv;
@@ -215,14 +244,21 @@ inline HostCSR assemble_fem(const double *x, const double *y, const double *z, c
                                 G[m][nn] = g;
                             }
                         // A_tet = sum_mn D_m^T G_mn D_n over the 4 (identical) quadrature points (subdomain.tpp:3009-3027)
+                        // Dref's entries are 0 and +-1 (row m: +1 in column m, -1 in column 3): the terms with a zero factor
+                        // add +-0 and are skipped, the others are +-G_mn exactly, added in the reference's order (m, n, q)
                         double At[4][4];
                         for (int i = 0; i < 4; i++)
                             for (int j = 0; j < 4; j++)
                             {
                                 double a = 0.0;
-                                for (int m = 0; m < 3; m++)
-                                    for (int nn = 0; nn < 3; nn++)
-                                        for (int q = 0; q < 4; q++) a += Dref[m][i] * (G[m][nn] * Dref[nn][j]);
+                                const int m0 = (i < 3) ? i : 0, m1 = (i < 3) ? i + 1 : 3, n0 = (j < 3) ? j : 0, n1 = (j < 3) ? j + 1 : 3;
+                                const bool minus = (i < 3) != (j < 3);
+                                for (int m = m0; m < m1; m++)
+                                    for (int nn = n0; nn < n1; nn++)
+                                    {
+                                        const double g = minus ? -G[m][nn] : G[m][nn];
+                                        for (int q = 0; q < 4; q++) a += g;
+                                    }
                                 At[i][j] = a;
                             }
                         for (int i = 0; i < 4; i++)
@@ -254,27 +290,14 @@ inline HostCSR assemble_fem(const double *x, const double *y, const double *z, c
             }
         }
     }
-    pti[part] = std::move(ti);
-    ptj[part] = std::move(tj);
-    ptv[part] = std::move(tv);
+    T.set(part, std::move(ti), std::move(tj), std::move(tv));
     });
-    std::vector<int> ti, tj;
-    std::vector<double> tv;
-    size_t total = 0;
-    for (int t = 0; t < parts; t++) total += pti[t].size();
-    ti.reserve(total);
-    tj.reserve(total);
-    tv.reserve(total);
-    for (int t = 0; t < parts; t++)
-    {
-        ti.insert(ti.end(), pti[t].begin(), pti[t].end());
-        tj.insert(tj.end(), ptj[t].begin(), ptj[t].end());
-        tv.insert(tv.end(), ptv[t].begin(), ptv[t].end());
-        std::vector<int>().swap(pti[t]);
-        std::vector<int>().swap(ptj[t]);
-        std::vector<double>().swap(ptv[t]);
-    }
-    return from_triplets(num_dofs, num_dofs, ti, tj, tv);
+    static const bool timing = getenv("FDD_SETUP_TIMING") != nullptr;
+    const auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t1 = clock();
+    HostCSR A = from_triplets(num_dofs, num_dofs, T);
+    if (timing) printf("low_order: FEM matrix: element stencils %.3f s, rows from triplets %.3f s\n", t1 - t0, clock() - t1);
+    return A;
 }
 
 // C = A * B (Gustavson, one dense accumulator row)
@@ -326,45 +349,50 @@ inline HostCSR multiply(const HostCSR &A, const HostCSR &B)
         pval[part] = std::move(ov);
     });
     for (int i = 0; i < A.rows; i++) C.ptr[i + 1] = C.ptr[i] + row_len[i];
-    C.col.reserve(C.ptr[A.rows]);
-    C.val.reserve(C.ptr[A.rows]);
-    for (int t = 0; t < parts; t++)
-    {
-        C.col.insert(C.col.end(), pcol[t].begin(), pcol[t].end());
-        C.val.insert(C.val.end(), pval[t].begin(), pval[t].end());
-        std::vector<int>().swap(pcol[t]);
-        std::vector<double>().swap(pval[t]);
-    }
+    concatenate(C.col, pcol);
+    concatenate(C.val, pval);
     return C;
 }
 
+// T = A^T.  Ranges of T's rows (A's columns) in parallel: a thread scans A in row order and places the entries of ITS
+// columns, so every row of T comes out in ascending column order, as from the serial loop.
 inline HostCSR transpose(const HostCSR &A)
 {
     HostCSR T;
     T.rows = A.cols;
     T.cols = A.rows;
-    T.ptr.assign(T.rows + 1, 0);
-    for (int c : A.col) T.ptr[c + 1]++;
+    T.ptr.assign((size_t)T.rows + 1, 0);
+    const int parts = range_parts(T.rows);
+    parallel_ranges(T.rows, parts, [&](long long c0, long long c1, int) {
+        for (int c : A.col)
+            if (c >= c0 and c < c1) T.ptr[c + 1]++;
+    });
     for (int i = 0; i < T.rows; i++) T.ptr[i + 1] += T.ptr[i];
     T.col.resize(A.col.size());
     T.val.resize(A.val.size());
-    std::vector<int> fill(T.ptr.begin(), T.ptr.end() - 1);
-    for (int i = 0; i < A.rows; i++)
-        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
-        {
-            const int q = fill[A.col[p]]++;
-            T.col[q] = i;
-            T.val[q] = A.val[p];
-        }
+    parallel_ranges(T.rows, parts, [&](long long c0, long long c1, int) {
+        std::vector<int> fill(T.ptr.begin() + c0, T.ptr.begin() + c1);
+        for (int i = 0; i < A.rows; i++)
+            for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+            {
+                const int c = A.col[p];
+                if (c < c0 or c >= c1) continue;
+                const int q = fill[c - c0]++;
+                T.col[q] = i;
+                T.val[q] = A.val[p];
+            }
+    });
     return T;
 }
 
 inline std::vector<double> diagonal(const HostCSR &A)
 {
     std::vector<double> d(A.rows, 0.0);
-    for (int i = 0; i < A.rows; i++)
-        for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
-            if (A.col[p] == i) d[i] = A.val[p];
+    parallel_ranges(A.rows, range_parts(A.rows), [&](long long r0, long long r1, int) {
+        for (long long i = r0; i < r1; i++)
+            for (int p = A.ptr[i]; p < A.ptr[i + 1]; p++)
+                if (A.col[p] == i) d[i] = A.val[p];
+    });
     return d;
 }
 
@@ -381,18 +409,31 @@ inline void spmv(std::vector<double> &y, const HostCSR &A, const std::vector<dou
     });
 }
 
+// the power iteration's start vector: deterministic, no symmetry
+inline std::vector<double> power_iteration_start(int n)
+{
+    std::vector<double> v(n);
+    parallel_ranges(n, range_parts(n), [&](long long i0, long long i1, int) {
+        for (long long i = i0; i < i1; i++) v[i] = 1.0 + 0.5 * std::sin(0.7 * (int)i + 0.3);
+    });
+    return v;
+}
+
 // largest eigenvalue of D A D, D = diag(A)^-1/2, by power iteration from a fixed start
 inline double max_eigenvalue_scaled(const HostCSR &A, const std::vector<double> &D, int iterations)
 {
     const int n = A.rows;
-    std::vector<double> v(n), w(n), t(n);
-    for (int i = 0; i < n; i++) v[i] = 1.0 + 0.5 * std::sin(0.7 * i + 0.3); // deterministic, no symmetry
-    // the vector loops run on the host threads; partial sums are combined in range order (deterministic for a thread count)
+    std::vector<double> v = power_iteration_start(n), w(n), t(n);
+    // the vector loops run on the host threads; sums are formed over fixed chunks of 65536 entries and the chunk sums
+    // added in order, whatever the thread count: the hierarchy does not depend on the number of cores
     const int parts = range_parts(n);
-    std::vector<double> partial(std::max(parts, 1));
+    const long long chunk = 65536, chunks = (n + chunk - 1) / chunk;
+    std::vector<double> partial((size_t)std::max(chunks, 1LL));
     auto reduce = [&](const std::function<double(long long, long long)> &f) {
         std::fill(partial.begin(), partial.end(), 0.0);
-        parallel_ranges(n, parts, [&](long long i0, long long i1, int part) { partial[part] = f(i0, i1); });
+        parallel_ranges(chunks, (chunks < 2 * parts) ? 1 : parts, [&](long long c0, long long c1, int) {
+            for (long long c = c0; c < c1; c++) partial[c] = f(c * chunk, std::min((long long)n, (c + 1) * chunk));
+        });
         double s = 0.0;
         for (double x : partial) s += x;
         return s;
@@ -432,6 +473,9 @@ struct Options
     double eig_ratio = 0.3;       // smoother targets [eig_ratio, 1.1] * lambda_max (hypre's Chebyshev defaults)
     double upper_factor = 1.1;
     int power_iterations = 25;
+    // lambda_max(D A D) of a level by `power_iterations` steps of the power iteration from the fixed start vector below;
+    // unset: on the host threads (max_eigenvalue_scaled).  Subdomain::amg_build runs the same iteration on the device.
+    std::function<double(const HostCSR &, const std::vector<double> &, int)> lambda_max;
     bool smooth_prolongator = true;
     double geometric_eig_ratio = 0.15; // lower end of the Chebyshev smoother's interval, as a fraction of lambda_max, on the levels coarsened on the lattice
     int geometric_min_nodes = 5;  // lattices with fewer nodes per direction and element are left to the aggregation
@@ -663,20 +707,32 @@ inline HostCSR geometric_level(const Lattice &fine, int num_dofs, Lattice &coars
     // where every conforming dof first sits, and whether some occurrence is on a kept node
     std::vector<long long> first(num_dofs, -1);
     std::vector<char> kept(num_dofs, 0);
-    for (long long q = 0; q < total; q++)
+    std::vector<char> node_kept((size_t)np, 0); // lattice node of an element: kept in every direction
+    for (long long v0 = 0; v0 < np; v0++)
     {
-        if (fine.rows.ptr[q + 1] - fine.rows.ptr[q] != 1 or fine.rows.val[fine.rows.ptr[q]] != 1.0) continue;
-        const int d = fine.rows.col[fine.rows.ptr[q]];
-        if (first[d] < 0) first[d] = q;
-        long long v = q % np;
+        long long v = v0;
         bool all = true;
         for (int a = 0; a < dim; a++)
         {
             all = all and pos[v % n] >= 0;
             v /= n;
         }
-        if (all) kept[d] = 1;
+        node_kept[v0] = all;
     }
+    // ranges of dofs in parallel, each thread scanning the points in order for ITS dofs (first = the serial loop's)
+    parallel_ranges(num_dofs, range_parts(num_dofs), [&](long long d0, long long d1, int) {
+        const int *rp = fine.rows.ptr.data(), *rc = fine.rows.col.data();
+        const double *rv = fine.rows.val.data();
+        for (long long q = 0; q < total; q++)
+        {
+            const int t = rp[q];
+            if (rp[q + 1] - t != 1) continue;
+            const int d = rc[t];
+            if (d < d0 or d >= d1 or rv[t] != 1.0) continue;
+            if (first[d] < 0) first[d] = q;
+            if (node_kept[q % np]) kept[d] = 1;
+        }
+    });
     std::vector<int> cmap(num_dofs, -1);
     int nc = 0;
     for (int d = 0; d < num_dofs; d++)
@@ -764,15 +820,8 @@ inline HostCSR geometric_level(const Lattice &fine, int num_dofs, Lattice &coars
         pval[part] = std::move(ov);
     });
     for (int d = 0; d < num_dofs; d++) P.ptr[d + 1] = P.ptr[d] + row_len[d];
-    P.col.reserve(P.ptr[num_dofs]);
-    P.val.reserve(P.ptr[num_dofs]);
-    for (int t = 0; t < parts; t++)
-    {
-        P.col.insert(P.col.end(), pcol[t].begin(), pcol[t].end());
-        P.val.insert(P.val.end(), pval[t].begin(), pval[t].end());
-        std::vector<int>().swap(pcol[t]);
-        std::vector<double>().swap(pval[t]);
-    }
+    concatenate(P.col, pcol);
+    concatenate(P.val, pval);
 
     // the coarse lattice: the kept nodes of every element, their rows over the coarse dofs
     coarse = Lattice();
@@ -785,24 +834,43 @@ inline HostCSR geometric_level(const Lattice &fine, int num_dofs, Lattice &coars
     R.rows = (int)(fine.num_elements * npc);
     R.cols = nc;
     R.ptr.assign((size_t)R.rows + 1, 0);
-    for (long long e = 0; e < fine.num_elements; e++)
-        for (long long cv = 0; cv < npc; cv++)
+    std::vector<long long> fine_node((size_t)npc); // kept node cv of an element -> its fine lattice node
+    for (long long cv = 0; cv < npc; cv++)
+    {
+        long long v = cv, fq = 0, stride = 1;
+        for (int a = 0; a < dim; a++)
         {
-            long long v = cv, fq = 0, stride = 1;
-            for (int a = 0; a < dim; a++)
-            {
-                fq += (long long)keep[v % m] * stride;
-                v /= m;
-                stride *= n;
-            }
-            const long long point = e * np + fq;
-            for (int t = fine.rows.ptr[point]; t < fine.rows.ptr[point + 1]; t++)
-            {
-                R.col.push_back(cmap[fine.rows.col[t]]);
-                R.val.push_back(fine.rows.val[t]);
-            }
-            R.ptr[e * npc + cv + 1] = (int)R.col.size();
+            fq += (long long)keep[v % m] * stride;
+            v /= m;
+            stride *= n;
         }
+        fine_node[cv] = fq;
+    }
+    const int eparts = range_parts(fine.num_elements);
+    parallel_ranges(fine.num_elements, eparts, [&](long long e0, long long e1, int) {
+        for (long long e = e0; e < e1; e++)
+            for (long long cv = 0; cv < npc; cv++)
+            {
+                const long long point = e * np + fine_node[cv];
+                R.ptr[e * npc + cv + 1] = fine.rows.ptr[point + 1] - fine.rows.ptr[point];
+            }
+    });
+    for (long long q = 0; q < R.rows; q++) R.ptr[q + 1] += R.ptr[q];
+    R.col.resize((size_t)R.ptr[R.rows]);
+    R.val.resize((size_t)R.ptr[R.rows]);
+    parallel_ranges(fine.num_elements, eparts, [&](long long e0, long long e1, int) {
+        for (long long e = e0; e < e1; e++)
+            for (long long cv = 0; cv < npc; cv++)
+            {
+                const long long point = e * np + fine_node[cv];
+                int out = R.ptr[e * npc + cv];
+                for (int t = fine.rows.ptr[point]; t < fine.rows.ptr[point + 1]; t++, out++)
+                {
+                    R.col[out] = cmap[fine.rows.col[t]];
+                    R.val[out] = fine.rows.val[t];
+                }
+            }
+    });
     return P;
 }
 
@@ -826,8 +894,10 @@ inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = fal
         const int n = A.rows;
         std::vector<double> d = diagonal(A);
         L.D.resize(n);
-        for (int i = 0; i < n; i++) L.D[i] = 1.0 / std::sqrt(d[i]);
-        const double lmax = max_eigenvalue_scaled(A, L.D, o.power_iterations);
+        parallel_ranges(n, range_parts(n), [&](long long i0, long long i1, int) {
+            for (long long i = i0; i < i1; i++) L.D[i] = 1.0 / std::sqrt(d[i]);
+        });
+        const double lmax = o.lambda_max ? o.lambda_max(A, L.D, o.power_iterations) : max_eigenvalue_scaled(A, L.D, o.power_iterations);
         {
             // the levels that are coarsened on the lattice lose 2.33 nodes per direction in one step (N = 7), more than an
             // aggregation level: the smoother in front of such a step has to reach further down the spectrum

@@ -897,7 +897,8 @@ class Subdomain
         fdd::memory qa, ua, fa, q_pts, slaves, st_tmp;
     } sp;
 
-    static fdd::memory to_float(const std::vector<double> &v)
+    template <typename Vec>
+    static fdd::memory to_float(const Vec &v)
     {
         std::vector<float> t(v.begin(), v.end());
         fdd::memory m = fdd::dev().malloc<float>(std::max<size_t>(t.size(), 1));
@@ -1221,6 +1222,53 @@ class Subdomain
     }
     void amg_finalize() { amg_hierarchy.finalize(); }
 
+    // lambda_max(D A D) of a level matrix of the setup: low_order::max_eigenvalue_scaled's power iteration (same start
+    // vector, same count) with the SpMV and the vector work on the device -- 25 passes over a level-0 matrix of a
+    // gigabyte are 0.5 s on the host's memory bus and 10 ms here.  One scalar comes back at the end.
+    double device_lambda_max(const fdd::low_order::HostCSR &M, const std::vector<double> &D, int iterations)
+    {
+        const int n = M.rows;
+        const size_t nnz = (size_t)M.nnz();
+        if (n == 0 or nnz == 0 or iterations <= 0) return 1.0;
+        fdd::device_t &dv = fdd::dev();
+        void *stream = dv.stream;
+        static const bool timing = getenv("FDD_SETUP_TIMING") != nullptr;
+        const auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = clock();
+        fdd::memory ptr = dv.malloc<int>((size_t)n + 1), col = dv.malloc<int>(nnz), val = dv.malloc<double>(nnz);
+        ptr.copyFrom(M.ptr.data(), ((size_t)n + 1) * sizeof(int));
+        col.copyFrom(M.col.data(), nnz * sizeof(int));
+        val.copyFrom(M.val.data(), nnz * sizeof(double));
+        const double t1 = clock();
+        fdd_csr_plan *plan = nullptr;
+        FDD_CALL(fdd_csr_plan_create(&plan, M.ptr.data(), n, n, (int)nnz));
+        const double t2 = clock();
+        fdd::memory v = dv.malloc<double>(n), vn = dv.malloc<double>(n), t = dv.malloc<double>(n), w = dv.malloc<double>(n), Dd = dv.malloc<double>(n);
+        fdd::memory ws = dv.malloc<double>(fdd_reduce_workspace_doubles()), sc = dv.malloc<double>(2);
+        {
+            const std::vector<double> start = fdd::low_order::power_iteration_start(n);
+            v.copyFrom(start.data(), (size_t)n * sizeof(double));
+            Dd.copyFrom(D.data(), (size_t)n * sizeof(double));
+        }
+        double *scp = sc.as<double>();
+        const double t3 = clock();
+        for (int it = 0; it < iterations; it++)
+        {
+            FDD_CALL(fdd_sub_inner_product(scp, ws.as<double>(), v.as<double>(), v.as<double>(), n, stream));
+            FDD_CALL(fdd_vector_scaling_rsqrt_dev(vn.as<double>(), scp, v.as<double>(), n, stream));                 // vn = v / |v|
+            FDD_CALL(fdd_vector_diagonal_scaling_dev(t.as<double>(), Dd.as<double>(), nullptr, vn.as<double>(), n, stream)); // t = D vn
+            FDD_CALL(fdd_csr_plan_matvec(plan, w.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), t.as<double>(), 1.0, 0.0, stream));
+            FDD_CALL(fdd_vector_diagonal_scaling_dev(v.as<double>(), Dd.as<double>(), nullptr, w.as<double>(), n, stream)); // v = D A D vn
+            FDD_CALL(fdd_sub_inner_product(scp + 1, ws.as<double>(), v.as<double>(), vn.as<double>(), n, stream));
+        }
+        double lambda = 1.0;
+        sc.slice(1, 1).copyTo(&lambda, sizeof(double));
+        if (timing and n > 100000) printf("low_order:   lambda_max on the device: matrix up %.3f s, plan %.3f s, vectors %.3f s, %d iterations %.3f s\n", t1 - t0, t2 - t1, t3 - t2, iterations, clock() - t3);
+        FDD_CALL(fdd_csr_plan_destroy(plan));
+        for (fdd::memory *m : {&ptr, &col, &val, &v, &vn, &t, &w, &Dd, &ws, &sc}) m->free();
+        return lambda;
+    }
+
     // Build the low-order FEM matrix of the region and an AMG hierarchy for it on the host and attach it
     // (stands in for subdomain.tpp:2749-3549, see low_order.hpp).  Returns the number of levels.
     int amg_build(fdd::low_order::Options options, bool verbose = false)
@@ -1272,23 +1320,28 @@ class Subdomain
                 R.rows = (int)np;
                 R.cols = num_dofs;
                 R.ptr.assign(np + 1, 0);
-                R.col.reserve(np);
-                for (size_t q = 0; q < np; q++)
-                {
-                    if (point_dof[q] >= 0) R.col.push_back(point_dof[q]);
-                    R.ptr[q + 1] = (int)R.col.size();
-                }
+                for (size_t q = 0; q < np; q++) R.ptr[q + 1] = R.ptr[q] + (point_dof[q] >= 0 ? 1 : 0);
+                R.col.resize((size_t)R.ptr[np]);
+                fdd::low_order::parallel_ranges((long long)np, fdd::low_order::range_parts((long long)np), [&](long long q0, long long q1, int) {
+                    for (long long q = q0; q < q1; q++)
+                        if (point_dof[q] >= 0) R.col[R.ptr[q]] = point_dof[q];
+                });
                 R.val.assign(R.col.size(), 1.0);
             }
         }
+        options.lambda_max = [this](const fdd::low_order::HostCSR &M, const std::vector<double> &D, int iterations) { return device_lambda_max(M, D, iterations); };
         std::vector<fdd::low_order::Level> lv = fdd::low_order::build(std::move(A), options, verbose, std::move(lattice));
         const double t2 = clock();
         amg_hierarchy = amg::Hierarchy();
         for (size_t l = 0; l < lv.size(); l++)
         {
             const bool coarsest = (l + 1 == lv.size());
-            amg_add_level(lv[l].A.rows, lv[l].A.ptr.data(), lv[l].A.col.data(), lv[l].A.val.data(), lv[l].D.data(), lv[l].coefs.data(), coarsest ? 0 : lv[l].P.cols, coarsest ? nullptr : lv[l].P.ptr.data(),
-                          coarsest ? nullptr : lv[l].P.col.data(), coarsest ? nullptr : lv[l].P.val.data());
+            amg_hierarchy.cheby_order = cheby_order;
+            amg_hierarchy.num_vcycles = num_vcycles;
+            fdd::low_order::Level &L = lv[l];
+            if (coarsest) L.P = fdd::low_order::HostCSR();
+            const int n = L.A.rows, nc = L.P.cols;
+            amg_hierarchy.add_level_adopt(n, std::move(L.A.ptr), std::move(L.A.col), std::move(L.A.val), L.D.data(), L.coefs.data(), nc, std::move(L.P.ptr), std::move(L.P.col), std::move(L.P.val));
             lv[l] = fdd::low_order::Level(); // free the host copy as we go
         }
         if (verbose) printf("low_order: FEM matrix %.2f s, hierarchy %.2f s, levels to the device %.2f s (%d host threads)\n", t1 - t0, t2 - t1, clock() - t2, fdd::low_order::host_threads());
@@ -1461,7 +1514,7 @@ class Subdomain
         // is a monotone compaction instead of a scattered permutation.
         std::vector<double> tmp(P);
         {
-            const std::vector<int> &node = domain.scatter_matrix().col_hst; // one entry per point
+            const auto &node = domain.scatter_matrix().col_hst; // one entry per point
             std::vector<int> dof_of_node(domain.num_local_nodes, 0);
             for (int p = 0; p < P; p++)
                 if (domain.mesh.p_mask[p] > 0.0) dof_of_node[node[p]] = 1;
@@ -1578,9 +1631,11 @@ class Subdomain
     template <typename PType>
     void initialize_composite(std::unordered_map<int, PType> &domains, PType &domain)
     {
+        fdd::SetupTimer setup_timing("Subdomain::initialize_composite", fdd::comm().rank == 0);
         std::map<std::pair<int, int>, std::vector<double>> J;
         for (auto &kv : J_cf) J[kv.first] = kv.second.first;
-        comp = fdd::composite::build(domains, poly_degree, subdomain_overlap, superdomain_overlap, (double)epsilon, J, D_hat[num_levels - 1].first, domain.scatter_matrix().col_hst, domain.num_local_nodes, grading);
+        comp = fdd::composite::build(domains, poly_degree, subdomain_overlap, superdomain_overlap, (double)epsilon, J, D_hat[num_levels - 1].first, std::vector<int>(domain.scatter_matrix().col_hst.begin(), domain.scatter_matrix().col_hst.end()), domain.num_local_nodes, grading);
+        setup_timing.lap("composite::build");
         const fdd::composite::Composite &c = comp;
 
         own_points = levels[0].num_points;
@@ -1610,6 +1665,7 @@ class Subdomain
             subdomain_operator.G_ptrs[g] = subdomain_operator.geom_fact[g].template as<double>();
         }
 
+        setup_timing.lap("region geometry to the device");
         // level-sorted element lists (subdomain.tpp:1603-1630 sorted by level): the region is ordered by level, so
         // every degree is one contiguous run of elements
         subdomain_operator.level_lists.clear();
@@ -1636,6 +1692,7 @@ class Subdomain
         subdomain_operator.num_points = NP;
         subdomain_operator.num_extended_dofs = nse;
 
+        setup_timing.lap("Q and Qt");
         point_dof = c.point_dof;
         point_dof_dev = fdd::dev().malloc<int>(std::max(NP, 1));
         point_dof_dev.copyFrom(point_dof.data(), (size_t)NP * sizeof(int));
@@ -1667,6 +1724,7 @@ class Subdomain
             coarse_all = fdd::dev().malloc<DType>(std::max((size_t)R * coarse_pad, (size_t)1));
         }
 
+        setup_timing.lap("superdomain operators");
         // interface maps and weights (subdomain.tpp:2581-2747)
         num_interface_dofs = c.num_interface_dofs;
         num_dofs = c.num_dofs;
@@ -1678,6 +1736,7 @@ class Subdomain
         norm_weight.copyFrom(norm_weight_hst.data(), norm_weight_hst.size() * sizeof(DType));
         norm_weight_is_one = false;
 
+        setup_timing.lap("interface maps and weights");
         // solve-time ring pull: what this rank packs for its peers and where the answers land
         {
             std::vector<int> sidx, uidx((size_t)std::max(num_ring_points, 1), 0);
@@ -1726,8 +1785,10 @@ class Subdomain
             for (int w = 0; w < 3; w++) work_dev[w] = fdd::dev().malloc<DType>(W);
         }
 
+        setup_timing.lap("exchange plan, work arrays");
         setup_composite_dofs();
 
+        setup_timing.lap("setup_composite_dofs");
         // the per-point arrays the solve path no longer needs
         for (int g = 0; g < NUM_GEOM_FACTS; g++) std::vector<double>().swap(comp.G[g]);
         std::vector<int>().swap(comp.Q_row);

@@ -282,3 +282,20 @@ print("ok", sizes, its)
 """ % (S.ROOT, S.HERE, HOST_CPU_SO, str(tmp_path / "curved"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def test_hierarchy_does_not_depend_on_the_thread_count(tmp_path):
+    """The setup runs on the rank's host threads (host/host_parallel.hpp: row ranges, pieces joined in order, reductions
+    over fixed chunks): every level (A, P) of the hierarchy of two boxes and of a deformed mesh is the same bit for bit
+    on 1, 3 and 8 threads (tests/amg_hierarchy_hash.py prints their SHA-1)."""
+    subprocess.check_call(["make", "-C", S.ORACLE_DIR, "-s"])
+    subprocess.check_call(["make", "-C", SHIM_DIR, "-s"])
+    outs = []
+    for threads in (1, 3, 8):
+        env = dict(os.environ, FDD_HOST_THREADS=str(threads))
+        out = subprocess.run([sys.executable, os.path.join(S.HERE, "amg_hierarchy_hash.py"), str(tmp_path / ("t%d" % threads))], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if ":" in l and len(l.split(":")[-1].strip()) == 40]
+        assert len(lines) == 3, out.stdout
+        outs.append(lines)
+    assert outs[0] == outs[1] == outs[2], outs
