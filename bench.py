@@ -48,7 +48,10 @@ legs    : every time-to-tolerance object carries `converged` (the reference's
           the block-local comparison point (`block_local`) next to the
           composite, and at every N the headline configuration with
           point-Jacobi in the inner solver's preconditioner slot
-          (`point_jacobi`, a labelled option of this build).
+          (`point_jacobi`, a labelled option of this build) and with the
+          affine-elements option (`affine_geometry`: the six factor arrays
+          formed in the kernel instead of streamed -- also a labelled option,
+          never the headline).
 """
 import argparse
 import ctypes
@@ -458,6 +461,31 @@ def run(args, rank, world, max_over_ranks, comm_label):
 
     progress("point-Jacobi leg done")
 
+    # the headline configuration with the affine-elements option (a labelled option of this build, NOT the headline: the
+    # reference always streams the six factor arrays, 48 of the stiffness kernel's 64 bytes per point).  Every element of
+    # the bench's box mesh is an affine image of the reference cube, so its factors are six numbers per element times the
+    # GLL weights; the option checks that on the mesh's own arrays and then forms them in the kernel instead of reading them.
+    affine_leg = None
+    if not args.no_precond and not args.no_reference_default and not args.amg:
+        prob.set_flag("affine_geometry", 1)
+        ainfo = prob.affine_info()
+        if ainfo["fine_domain"] and ainfo["sub_lists_affine"] > 0:
+            da, lra, _ = timed_steps(args.steps, min(args.warmup, 2), False)
+            affine_leg = {"what": "headline configuration with element-wise constant (affine) geometry: the six factor arrays are not streamed (option of this build, not in the reference; results equal to rounding)",
+                          "ms_per_step": da / args.steps * 1e3, "value": nodes * args.steps / da, "last_residual_norm": lra, "max_deviation_of_the_mesh_factors": ainfo["max_deviation"],
+                          "sub_lists_affine": ainfo["sub_lists_affine"], "sub_lists": ainfo["sub_lists"]}
+            if not args.no_time_to_tolerance:
+                affine_leg["to_1e-7"] = to_tolerance()
+            if args.amg_precision == 64:
+                configure(args.amg, 32)
+                d32a, _, _ = timed_steps(args.steps, min(args.warmup, 2), False)
+                affine_leg["preconditioner_in_f32"] = {"ms_per_step": d32a / args.steps * 1e3, "value": nodes * args.steps / d32a}
+                configure(args.amg, args.amg_precision)
+        else:
+            affine_leg = {"what": "the mesh's factor arrays are not of the affine form", "max_deviation_of_the_mesh_factors": ainfo["max_deviation"]}
+        prob.set_flag("affine_geometry", 0)
+    progress("affine-geometry leg done")
+
     def leg(problem, label):
         """the no-V-cycle configuration on the OTHER region of an N-rank run, next to the headline"""
         configure(False, 64, problem=problem)
@@ -587,6 +615,7 @@ def run(args, rank, world, max_over_ranks, comm_label):
         "to_1e-7": headline_tol,
         "preconditioner_in_f32": headline_f32,
         "point_jacobi": point_jacobi,
+        "affine_geometry": affine_leg,
         "block_local": block_local_leg,
         "composite": composite_leg,
         "setup_s": t_setup,

@@ -289,6 +289,19 @@ int fdd_multi_lincomb_limited_dev(double *q, int q_is_zero, const double *coeffs
 int fdd_sqrt_sum_dev(double *out, const double *parts_dev, int nparts, void *stream); /* out[0] = sqrt(sum parts): a residual norm appended to a device-side history */
 /* ---- single-precision preconditioner (the reference's PTYPE = Float = float, config.hpp:19-20, poisson.cpp:206): the
  * kernels of the dof-space inner solve on float vectors.  Device-resident scalars and reduction accumulators stay double. ---- */
+/* The same operator on elements that are AFFINE images of the reference cube (every element of a box mesh), an option of
+ * this build: the six factors of a point are formed from six numbers per element and the GLL weights,
+ *   G_f(e; i, j, k) = elem_factors[6 e + f] * (w_i w_j) w_k,     gll_weights[0 .. poly_degree],
+ * instead of being streamed (48 of the 64 bytes per point of domain.okl:5-98 are not read).  point_dof == NULL: u = v
+ * point by point (Domain); otherwise gathered and scaled as above (v_scale_dev may be NULL).  The host layer uses it only
+ * where the mesh's own factor arrays have that form to rounding (Stiffness_Operator::affine); results agree with the
+ * streamed form to a few ulp of the factors, not bit for bit. */
+int fdd_stiffness_matrix_affine(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *elem_factors, const double *gll_weights, const int *elem_offset, int num_elements, int poly_degree, void *stream);
+/* Do the factor arrays have that form?  Per element e of the list: elem_factors[6 e + f] = G_f / W at the element's middle
+ * point, deviation[e] = max over points and factors of |G_f(p) - elem_factors[6 e + f] W(p)| / (max_f |elem_factors| W(p)),
+ * W(p) = (w_i w_j) w_k.  3-D elements. */
+int fdd_stiffness_affine_detect(double *elem_factors, double *deviation, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, const double *gll_weights, int num_elements, int poly_degree, void *stream);
+int fdd_stiffness_matrix_affine_f32(float *Au, const float *v, const double *v_scale_dev, const int *point_dof, const float *D_hat, const float *elem_factors, const float *gll_weights, const int *elem_offset, int num_elements, int poly_degree, void *stream);
 int fdd_sub_stiffness_matrix_gather_scaled_f32(float *Au, const float *v, const double *v_scale_dev, const int *point_dof, const float *D_hat, const float *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
 int fdd_multi_inner_product_scaled_f32(double *out, double *ws, const float *a, const float *const *b, const double *b_scale_dev, int m, int n, void *stream); /* out[k] = sum a * (s_k b_k), k < m <= 8 */
 int fdd_multi_axpy_norm2_scaled_dev_f32(double *out, double *ws, float *dst, const float *y, const double *coeffs_dev, double sign, const float *const *x, const double *x_scale_dev, int m, int n, void *stream); /* dst = y + sign sum c_k (s_k x_k); out = |dst|^2 */

@@ -171,6 +171,12 @@ int fddh_problem_set_options(fddh_problem *p, int max_iterations, double toleran
  *   "amg_graph"                1: the V-cycle is replayed as one hipGraph when the stream allows capture (default)
  *   "amg_fused_smoother"       1: the smoother's element-wise kernels run as SpMV epilogues, bit-identical (default); 0: the reference's launch sequence 
  *   "amg_precision"            64 (default) or 32: the reference's `Float` (AMG/config.hpp:4): the V-cycle in double or in float */
+/* Flag "affine_geometry" (an option of this build, off by default; the reference always streams the six factor
+ * arrays): after fddh_problem_set_flag(p, "affine_geometry", 1), which of the operators run on the kernel that forms the
+ * factors from six numbers per element (fdd_hip.h: fdd_stiffness_matrix_affine) -- the fine Domain's node-space operator,
+ * and how many of the Subdomain's level lists -- and the largest relative deviation of the mesh's own factor arrays
+ * from that form (-1 before the flag was ever set).  Any argument may be NULL. */
+int fddh_problem_affine_info(fddh_problem *p, int *fine_domain_affine, int *sub_lists_affine, int *sub_lists, double *max_deviation);
 int fddh_problem_set_flag(fddh_problem *p, const char *name, int value);
 
 /* Low-order AMG preconditioner of the inner solve (Subdomain::low_order_preconditioner,

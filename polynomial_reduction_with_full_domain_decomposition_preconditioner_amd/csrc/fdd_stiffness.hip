@@ -256,7 +256,12 @@ __device__ __forceinline__ void element_sync()
 // kGather: u is read through point_dof (u[e,i,j,k] = v[point_dof[...]], 0 where
 // the point has no dof): the boolean scatter Q of Subdomain fused into the load.
 // T: double, or float for the single-precision preconditioner (the reference's PTYPE = Float, config.hpp:19-20)
-template <typename T, int n, bool kGather, bool kNTStore>
+// kAffine: the six factors of a point are NOT streamed (48 of the 64 B per point) but formed from six numbers per element
+// and the GLL weights, G_f(e; i, j, k) = c_f(e) * (w_i w_j) w_k -- what they are on an element that is an affine image
+// of the reference cube (every element of a box mesh).  G.g[0] then points to c (element-major, 6 per element of this
+// list), G.g[1] to the n weights.  An option of this build (the reference always streams G): the host layer offers it
+// only where the mesh's own factor arrays satisfy the product form to rounding (host/element.hpp: affine_factors).
+template <typename T, int n, bool kGather, bool kNTStore, bool kAffine = false>
 __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel_t(T *__restrict__ Au, const T *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ u_scale, const T *__restrict__ D_hat, GPtrsT<T> G, const int *__restrict__ elem_offset, int num_elements)
 {
     using C = FusedCfg<n>;
@@ -297,6 +302,9 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel_t(T *__restrict
     // flight before D_hat is staged.
     constexpr int kPF = 1; // slabs of geometric factors in flight (2 measured no faster at n = 8: the kernel is not latency-bound)
     T r_u[n], r_3[n], gq[kPF][FDD_NUM_GEOM_FACTS];
+    T cf[FDD_NUM_GEOM_FACTS], wij = T(0); // kAffine: the element's six numbers, w_i w_j of this lane
+#pragma unroll
+    for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) cf[f] = T(0);
 #pragma unroll
     for (int k = 0; k < n; k++) r_u[k] = T(0);
 #pragma unroll
@@ -330,10 +338,19 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel_t(T *__restrict
 #pragma unroll
             for (int k = 0; k < n; k++) r_u[k] = __builtin_nontemporal_load(up + (ij + k * nn));
         }
+        if (kAffine)
+        {
 #pragma unroll
-        for (int s = 0; s < kPF; s++)
+            for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) cf[f] = G.g[0][(size_t)elem * FDD_NUM_GEOM_FACTS + f];
+            wij = G.g[1][i] * G.g[1][j];
+        }
+        else
+        {
 #pragma unroll
-            for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) gq[s][f] = __builtin_nontemporal_load(G.g[f] + base + (ij + s * nn));
+            for (int s = 0; s < kPF; s++)
+#pragma unroll
+                for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) gq[s][f] = __builtin_nontemporal_load(G.g[f] + base + (ij + s * nn));
+        }
     }
 
     for (int t = tid; t < n * n; t += kBlock) s_D[t] = D_hat[t];
@@ -376,9 +393,18 @@ __global__ __launch_bounds__(kBlock) void fused_stiffness_kernel_t(T *__restrict
             if ((n % kPF != 0) && k >= n) continue;
             // this slot's factors move to g; slab k + kPF is requested into the slot
             T g[FDD_NUM_GEOM_FACTS];
+            if (kAffine)
+            {
+                const T w3 = wij * G.g[1][k]; // w_k: wave-uniform address
 #pragma unroll
-            for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) g[f] = gq[s][f];
-            if (active && k + kPF < n)
+                for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) g[f] = cf[f] * w3;
+            }
+            else
+            {
+#pragma unroll
+                for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) g[f] = gq[s][f];
+            }
+            if (!kAffine && active && k + kPF < n)
             {
                 const int off = ij + (k + kPF) * nn;
 #pragma unroll
@@ -471,6 +497,96 @@ int launch_fused_t(T *Au, const T *u, const int *point_dof, const double *u_scal
         hipLaunchKernelGGL((fused_stiffness_kernel_t<T, n, false, false>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
     FDD_LAUNCH_CHECK();
     return 0;
+}
+
+// One workgroup per element: c_f = G_f(p0) / W(p0) at the element's middle point, and the largest deviation of any
+// factor of any point from c_f W(p), relative to max_f |c_f| W(p); W(p) = (w_i w_j) w_k as the kernel above forms it.
+__global__ __launch_bounds__(kBlock) void affine_detect_kernel(double *__restrict__ c_out, double *__restrict__ deviation, GPtrs G, const int *__restrict__ elem_offset, const double *__restrict__ w, int n, int num_elements)
+{
+    __shared__ double s_c[FDD_NUM_GEOM_FACTS];
+    __shared__ double s_max[kBlock / FDD_WAVE];
+    const int e = blockIdx.x;
+    if (e >= num_elements) return;
+    const int n3 = n * n * n;
+    const size_t base = elem_offset ? (size_t)elem_offset[e] : (size_t)e * n3;
+    if (threadIdx.x < FDD_NUM_GEOM_FACTS)
+    {
+        const int m = n / 2, p0 = m + m * n + m * n * n;
+        s_c[threadIdx.x] = G.g[threadIdx.x][base + p0] / ((w[m] * w[m]) * w[m]);
+    }
+    __syncthreads();
+    double scale = 0.0;
+#pragma unroll
+    for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) scale = fmax(scale, fabs(s_c[f]));
+    double worst = 0.0;
+    for (int p = threadIdx.x; p < n3; p += kBlock)
+    {
+        const int i = p % n, j = (p / n) % n, k = p / (n * n);
+        const double W = (w[i] * w[j]) * w[k];
+#pragma unroll
+        for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) worst = fmax(worst, fabs(G.g[f][base + p] - s_c[f] * W) / (scale * W));
+    }
+    if (!(scale > 0.0)) worst = 1.0; // all factors zero in the middle: not a usable element
+#pragma unroll
+    for (int off = FDD_WAVE / 2; off > 0; off >>= 1) worst = fmax(worst, __shfl_down(worst, off, FDD_WAVE));
+    if ((threadIdx.x & (FDD_WAVE - 1)) == 0) s_max[threadIdx.x / FDD_WAVE] = worst;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        for (int v = 1; v < kBlock / FDD_WAVE; v++) worst = fmax(worst, s_max[v]);
+        deviation[e] = worst;
+#pragma unroll
+        for (int f = 0; f < FDD_NUM_GEOM_FACTS; f++) c_out[(size_t)e * FDD_NUM_GEOM_FACTS + f] = s_c[f];
+    }
+}
+
+template <typename T, int n>
+int launch_fused_affine_t(T *Au, const T *u, const int *point_dof, const double *u_scale, const T *D_hat, const T *elem_factors, const T *gll_weights, const int *elem_offset, int num_elements, void *stream)
+{
+    using C = FusedCfg<n>;
+    const int grid = (num_elements + C::epb - 1) / C::epb;
+    GPtrsT<T> g;
+    for (int k = 0; k < FDD_NUM_GEOM_FACTS; k++) g.g[k] = nullptr;
+    g.g[0] = elem_factors;
+    g.g[1] = gll_weights;
+    if (point_dof)
+        hipLaunchKernelGGL((fused_stiffness_kernel_t<T, n, true, true, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements);
+    else
+        hipLaunchKernelGGL((fused_stiffness_kernel_t<T, n, false, true, true>), dim3(grid), dim3(kBlock), 0, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+int fused_dispatch_affine(T *Au, const T *u, const int *point_dof, const double *u_scale, const T *D_hat, const T *elem_factors, const T *gll_weights, const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    FDD_REQUIRE(num_elements >= 0);
+    if (num_elements == 0) return 0;
+    FDD_REQUIRE(Au != nullptr && u != nullptr && D_hat != nullptr && elem_factors != nullptr && gll_weights != nullptr);
+    switch (poly_degree + 1)
+    {
+#define FDD_AFFINE_CASE(N_) \
+    case N_: return launch_fused_affine_t<T, N_>(Au, u, point_dof, u_scale, D_hat, elem_factors, gll_weights, elem_offset, num_elements, stream);
+        FDD_AFFINE_CASE(2)
+        FDD_AFFINE_CASE(3)
+        FDD_AFFINE_CASE(4)
+        FDD_AFFINE_CASE(5)
+        FDD_AFFINE_CASE(6)
+        FDD_AFFINE_CASE(7)
+        FDD_AFFINE_CASE(8)
+        FDD_AFFINE_CASE(9)
+        FDD_AFFINE_CASE(10)
+        FDD_AFFINE_CASE(11)
+        FDD_AFFINE_CASE(12)
+        FDD_AFFINE_CASE(13)
+        FDD_AFFINE_CASE(14)
+        FDD_AFFINE_CASE(15)
+        FDD_AFFINE_CASE(16)
+#undef FDD_AFFINE_CASE
+    default:
+        fdd_set_error("fused stiffness kernel supports poly_degree 1..15, got %d", poly_degree);
+        return FDD_ERR_UNSUPPORTED;
+    }
 }
 
 template <int n>
@@ -803,6 +919,32 @@ int fdd_sub_stiffness_matrix_gather_scaled(double *Au, const double *v, const do
 {
     FDD_REQUIRE(point_dof != nullptr);
     return fused_dispatch(Au, v, point_dof, v_scale_dev, D_hat, G, elem_offset, num_elements, poly_degree, stream);
+}
+
+int fdd_stiffness_matrix_affine(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *elem_factors, const double *gll_weights, const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    return fused_dispatch_affine<double>(Au, v, point_dof, v_scale_dev, D_hat, elem_factors, gll_weights, elem_offset, num_elements, poly_degree, stream);
+}
+
+int fdd_stiffness_affine_detect(double *elem_factors, double *deviation, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, const double *gll_weights, int num_elements, int poly_degree, void *stream)
+{
+    FDD_REQUIRE(num_elements >= 0 && poly_degree >= 1);
+    if (num_elements == 0) return 0;
+    FDD_REQUIRE(elem_factors != nullptr && deviation != nullptr && G != nullptr && gll_weights != nullptr);
+    GPtrs g;
+    for (int k = 0; k < FDD_NUM_GEOM_FACTS; k++)
+    {
+        FDD_REQUIRE(G[k] != nullptr);
+        g.g[k] = G[k];
+    }
+    hipLaunchKernelGGL(affine_detect_kernel, dim3(num_elements), dim3(kBlock), 0, fdd_stream(stream), elem_factors, deviation, g, elem_offset, gll_weights, poly_degree + 1, num_elements);
+    FDD_LAUNCH_CHECK();
+    return 0;
+}
+
+int fdd_stiffness_matrix_affine_f32(float *Au, const float *v, const double *v_scale_dev, const int *point_dof, const float *D_hat, const float *elem_factors, const float *gll_weights, const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    return fused_dispatch_affine<float>(Au, v, point_dof, v_scale_dev, D_hat, elem_factors, gll_weights, elem_offset, num_elements, poly_degree, stream);
 }
 
 int fdd_sub_stiffness_matrix_gather_scaled_f32(float *Au, const float *v, const double *v_scale_dev, const int *point_dof, const float *D_hat, const float *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)

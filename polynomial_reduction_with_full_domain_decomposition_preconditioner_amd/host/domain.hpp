@@ -776,9 +776,50 @@ class Domain
         Qt.gather_scatter(nullptr, t.as<double>(), v.as<double>(), nullptr, nullptr, 0, num_local_nodes, 1);
     }
 
+    // ---- affine elements (an option of this build; the reference always streams the six factor arrays) ----
+    // Where every element of the mesh is an affine image of the reference cube (a box mesh), the factors of a point are
+    // c_f(e) (w_i w_j) w_k: the kernel forms them from six numbers per element and does not read 48 of its 64 bytes per
+    // point.  set_affine_geometry(true) checks the mesh's OWN factor arrays against that form on the device
+    // (fdd_stiffness_affine_detect) and switches the node-space operator over only if every element passes.
+    static constexpr double affine_tolerance = 64.0 * 2.220446049250313e-16;
+    bool affine_geometry = false; // in use
+    bool affine_checked = false;
+    double affine_deviation = -1.0; // largest relative deviation found (-1: not checked)
+    fdd::memory affine_c, affine_w;
+    bool set_affine_geometry(bool on)
+    {
+        affine_geometry = false;
+        if (not on) return true;
+        if (mesh.dim != 3 or poly_degree > 10 or num_local_elements == 0) return false; // degrees >= 11 run on the matrix cores, which stream
+        if (not affine_checked)
+        {
+            const int n = poly_degree + 1;
+            std::vector<double> z(n), w(n), dev_hst(num_local_elements);
+            fdd::gll::zwgll(z.data(), w.data(), n);
+            affine_w = fdd::dev().malloc<double>(n);
+            affine_w.copyFrom(w.data(), (size_t)n * sizeof(double));
+            affine_c = fdd::dev().malloc<double>((size_t)num_local_elements * NUM_GEOM_FACTS);
+            fdd::memory dev_dev = fdd::dev().malloc<double>(num_local_elements);
+            FDD_CALL(fdd_stiffness_affine_detect(affine_c.as<double>(), dev_dev.as<double>(), G_ptrs, nullptr, affine_w.as<double>(), num_local_elements, poly_degree, fdd::dev().stream));
+            dev_dev.copyTo(dev_hst.data(), dev_hst.size() * sizeof(double));
+            dev_dev.free();
+            affine_deviation = 0.0;
+            for (double x : dev_hst) affine_deviation = (x == x) ? std::max(affine_deviation, x) : 1.0;
+            affine_checked = true;
+        }
+        affine_geometry = affine_deviation <= affine_tolerance;
+        return affine_geometry;
+    }
+
     // q (points) = A_local (Q p~)
     void stiffness_from_nodes(fdd::memory &q, fdd::memory &pn)
     {
+        if (affine_geometry)
+        {
+            fdd::ProfileScope prof("fused_stiffness_kernel<gather,affine>", 12.0 * num_local_points + 8.0 * num_local_nodes);
+            FDD_CALL(fdd_stiffness_matrix_affine(q.as<double>(), pn.as<double>(), nullptr, point_node_dev.as<int>(), D_hat.as<double>(), affine_c.as<double>(), affine_w.as<double>(), nullptr, num_local_elements, poly_degree, fdd::dev().stream));
+            return;
+        }
         if (poly_degree >= 11 and mfma_stiffness)
         {
             fdd::ProfileScope prof("mfma_stiffness_kernel<gather>", 60.0 * num_local_points + 8.0 * num_local_nodes);

@@ -811,6 +811,33 @@ int fddh_problem_set_options(fddh_problem *p, int max_iterations, double toleran
     }
 }
 
+int fddh_problem_affine_info(fddh_problem *p, int *fine_domain_affine, int *sub_lists_affine, int *sub_lists, double *max_deviation)
+{
+    try
+    {
+        if (!p) return fail("null argument");
+        Domain<SType> &dom = p->fine();
+        double worst = dom.affine_deviation;
+        int lists = 0, affine = 0;
+        if (p->subdomain)
+            for (auto &ll : p->subdomain->operator_lists())
+            {
+                lists++;
+                if (ll.affine) affine++;
+                worst = std::max(worst, ll.affine_deviation);
+            }
+        if (fine_domain_affine) *fine_domain_affine = dom.affine_geometry ? 1 : 0;
+        if (sub_lists_affine) *sub_lists_affine = affine;
+        if (sub_lists) *sub_lists = lists;
+        if (max_deviation) *max_deviation = worst;
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return fail("%s", e.what());
+    }
+}
+
 int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
 {
     try
@@ -854,6 +881,13 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
             if (!p->subdomain) return fail("problem was created without a Subdomain");
             p->subdomain->use_preconditioner = value == 1;
             p->subdomain->use_jacobi = value == 2;
+        }
+        else if (s == "affine_geometry")
+        {
+            // an option of this build: elements that are affine images of the reference cube do not stream their factor
+            // arrays (fdd_stiffness_matrix_affine); only where the mesh's own arrays have that form (fddh_problem_affine_info)
+            for (auto &kv : p->domains) kv.second.set_affine_geometry(value != 0);
+            if (p->subdomain) p->subdomain->set_affine_geometry(value != 0);
         }
         else if (s == "amg_graph")
         {

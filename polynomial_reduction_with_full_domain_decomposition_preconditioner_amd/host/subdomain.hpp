@@ -87,6 +87,10 @@ struct Stiffness_Operator // subdomain.hpp:46-70
         int first_offset = 0;
         fdd::memory elem_offset; // int[num_elements] when not contiguous
         const double *G[NUM_GEOM_FACTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // geometric factors of the list's first point (contiguous lists)
+        // affine elements (an option, Subdomain::set_affine_geometry): six numbers per element + the GLL weights stand for the factor arrays
+        bool affine = false;
+        double affine_deviation = -1.0;
+        fdd::memory affine_c, affine_w, affine_c32, affine_w32;
     };
     std::vector<LevelList> level_lists;
 };
@@ -964,6 +968,12 @@ class Subdomain
         {
             auto &ll = subdomain_operator.level_lists[k];
             const double n3 = (double)(ll.poly_degree + 1) * (ll.poly_degree + 1) * (ll.poly_degree + 1);
+            if (ll.affine)
+            {
+                fdd::ProfileScope prof("fused_stiffness_kernel<gather,f32,affine>", (8.0 * n3) * ll.num_elements + 4.0 * subdomain_operator.num_extended_dofs);
+                FDD_CALL(fdd_stiffness_matrix_affine_f32(q + ll.first_offset, x, scale_dev, point_dof_dev.template as<int>() + ll.first_offset, sp.D_hat[ll.level].template as<float>(), ll.affine_c32.template as<float>(), ll.affine_w32.template as<float>(), nullptr, ll.num_elements, ll.poly_degree, stream));
+                continue;
+            }
             fdd::ProfileScope prof("fused_stiffness_kernel<gather,f32>", (32.0 * n3) * ll.num_elements + 4.0 * subdomain_operator.num_extended_dofs);
             const float *Gs[NUM_GEOM_FACTS];
             for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = sp.G[k][g].template as<float>();
@@ -2199,12 +2209,73 @@ class Subdomain
         return true;
     }
 
+    // ---- affine elements (an option of this build, see Domain::set_affine_geometry) ----
+    // Every level list of the region (own elements, rings at their reduced degrees) is checked on its own: a list whose
+    // factor arrays all have the form c_f(e) (w_i w_j) w_k to rounding runs on the kernel that does not stream them.
+    // Returns the number of lists switched over.
+    bool affine_geometry = false;
+    const std::vector<typename Stiffness_Operator<DType>::LevelList> &operator_lists() const { return subdomain_operator.level_lists; }
+    int set_affine_geometry(bool on)
+    {
+        int count = 0;
+        affine_geometry = false;
+        for (auto &ll : subdomain_operator.level_lists)
+        {
+            if (not on or dim != 3 or ll.poly_degree > 10 or ll.num_elements == 0)
+            {
+                ll.affine = false;
+                continue;
+            }
+            if (ll.affine_deviation < 0.0)
+            {
+                const int n = ll.poly_degree + 1;
+                std::vector<double> z(n), w(n), dev_hst(ll.num_elements);
+                fdd::gll::zwgll(z.data(), w.data(), n);
+                ll.affine_w = fdd::dev().malloc<double>(n);
+                ll.affine_w.copyFrom(w.data(), (size_t)n * sizeof(double));
+                ll.affine_c = fdd::dev().malloc<double>((size_t)ll.num_elements * NUM_GEOM_FACTS);
+                fdd::memory dev_dev = fdd::dev().malloc<double>(ll.num_elements);
+                if (ll.contiguous)
+                {
+                    const double *Gs[NUM_GEOM_FACTS];
+                    for (int g = 0; g < NUM_GEOM_FACTS; g++) Gs[g] = ll.G[g];
+                    FDD_CALL(fdd_stiffness_affine_detect(ll.affine_c.template as<double>(), dev_dev.template as<double>(), Gs, nullptr, ll.affine_w.template as<double>(), ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                }
+                else
+                    FDD_CALL(fdd_stiffness_affine_detect(ll.affine_c.template as<double>(), dev_dev.template as<double>(), subdomain_operator.G_ptrs, ll.elem_offset.template as<int>(), ll.affine_w.template as<double>(), ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                dev_dev.copyTo(dev_hst.data(), dev_hst.size() * sizeof(double));
+                dev_dev.free();
+                ll.affine_deviation = 0.0;
+                for (double x : dev_hst) ll.affine_deviation = (x == x) ? std::max(ll.affine_deviation, x) : 1.0;
+                // float copies for the single-precision inner solve
+                std::vector<double> c_hst((size_t)ll.num_elements * NUM_GEOM_FACTS);
+                ll.affine_c.copyTo(c_hst.data(), c_hst.size() * sizeof(double));
+                ll.affine_c32 = to_float(c_hst);
+                ll.affine_w32 = to_float(w);
+            }
+            ll.affine = ll.affine_deviation <= PType_affine_tolerance();
+            if (ll.affine) count++;
+        }
+        affine_geometry = count > 0;
+        return count;
+    }
+    static constexpr double PType_affine_tolerance() { return 64.0 * 2.220446049250313e-16; }
+
     // q (points) = A_local (Q (s z~)), s = *scale_dev when given (a basis vector kept unnormalised)
     void stiffness_from_dofs(fdd::memory &q, fdd::memory &za, const double *scale_dev = nullptr)
     {
         for (auto &ll : subdomain_operator.level_lists)
         {
             const double n3 = (double)(ll.poly_degree + 1) * (ll.poly_degree + 1) * (ll.poly_degree + 1);
+            if (ll.affine)
+            {
+                fdd::ProfileScope prof("fused_stiffness_kernel<gather,affine>", (12.0 * n3) * ll.num_elements + 8.0 * subdomain_operator.num_extended_dofs);
+                if (ll.contiguous)
+                    FDD_CALL(fdd_stiffness_matrix_affine(q.as<double>() + ll.first_offset, za.as<double>(), scale_dev, point_dof_dev.template as<int>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), ll.affine_c.template as<double>(), ll.affine_w.template as<double>(), nullptr, ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                else
+                    FDD_CALL(fdd_stiffness_matrix_affine(q.as<double>(), za.as<double>(), scale_dev, point_dof_dev.template as<int>(), subdomain_operator.D_hat[ll.level].template as<double>(), ll.affine_c.template as<double>(), ll.affine_w.template as<double>(), ll.elem_offset.template as<int>(), ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                continue;
+            }
             if (ll.poly_degree >= 11 and mfma_stiffness)
             {
                 fdd::ProfileScope prof("mfma_stiffness_kernel<gather>", (60.0 * n3) * ll.num_elements + 8.0 * subdomain_operator.num_extended_dofs);

@@ -369,6 +369,13 @@ class Problem:
     def set_flag(self, name, value):
         _H().call("fddh_problem_set_flag", self.h, name.encode(), int(value))
 
+    def affine_info(self):
+        """after set_flag("affine_geometry", 1): which operators run without streaming the factor arrays (an option of
+        this build) and how far the mesh's own factors are from the form c_f(e) (w_i w_j) w_k"""
+        dom, aff, lists, dev = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_double(-1.0)
+        _H().call("fddh_problem_affine_info", self.h, ctypes.byref(dom), ctypes.byref(aff), ctypes.byref(lists), ctypes.byref(dev))
+        return {"fine_domain": bool(dom.value), "sub_lists_affine": aff.value, "sub_lists": lists.value, "max_deviation": dev.value}
+
     def dssum(self, u, mask=True, weight=False):
         out = np.zeros(self.n)
         _H().call("fddh_problem_dssum", self.h, _dp(out), _dp(np.ascontiguousarray(u)), int(mask), int(weight))

@@ -852,3 +852,96 @@ int fdd_gather_rows_f32(float *t, const int *ptr, const int *col, const float *u
 int fdd_csr_plan_gather_f32(const fdd_csr_plan *plan, float *t, const int *ptr, const int *col, const float *u, int row_lo, int row_hi, void *s) { (void)plan; return fdd_gather_rows_f32(t, ptr, col, u, row_lo, row_hi, s); }
 int fdd_gather_indexed_f32(float *out, const float *in, const int *idx, int n, void *s) { (void)s; for (int i = 0; i < n; i++) out[i] = idx[i] < 0 ? 0.0f : in[idx[i]]; return 0; }
 int fdd_gather_indexed_f32_f64(double *out, const float *in, const int *idx, int n, void *s) { (void)s; for (int i = 0; i < n; i++) out[i] = idx[i] < 0 ? 0.0 : (double)in[idx[i]]; return 0; }
+
+/* ---- affine elements (an option of the build): the factor arrays rebuilt from six numbers per element, then the streamed kernels ---- */
+static size_t affine_span(const int *eo, int ne, int n3)
+{
+    size_t maxp = 0;
+    for (int e = 0; e < ne; e++)
+    {
+        size_t o = eo ? (size_t)eo[e] : (size_t)e * n3;
+        if (o + n3 > maxp) maxp = o + n3;
+    }
+    return maxp;
+}
+
+int fdd_stiffness_matrix_affine(double *Au, const double *v, const double *vscale, const int *pd, const double *D, const double *c, const double *w, const int *eo, int ne, int N, void *s)
+{
+    if (ne <= 0) return 0;
+    const int n = N + 1, n3 = n * n * n;
+    const size_t span = affine_span(eo, ne, n3);
+    double *G[6];
+    for (int f = 0; f < 6; f++) G[f] = (double *)calloc(span + 1, sizeof(double));
+    for (int e = 0; e < ne; e++)
+    {
+        const size_t o = eo ? (size_t)eo[e] : (size_t)e * n3;
+        for (int k = 0; k < n; k++)
+            for (int j = 0; j < n; j++)
+                for (int i = 0; i < n; i++)
+                {
+                    const double W = (w[i] * w[j]) * w[k];
+                    for (int f = 0; f < 6; f++) G[f][o + i + j * n + k * n * n] = c[(size_t)e * 6 + f] * W;
+                }
+    }
+    const double *Gc[6] = {G[0], G[1], G[2], G[3], G[4], G[5]};
+    int rc;
+    if (pd)
+        rc = fdd_sub_stiffness_matrix_gather_scaled(Au, v, vscale, pd, D, Gc, eo, ne, N, s);
+    else
+        rc = fdd_sub_stiffness_matrix(Au, v, D, Gc, eo, ne, N, s);
+    for (int f = 0; f < 6; f++) free(G[f]);
+    return rc;
+}
+
+int fdd_stiffness_matrix_affine_f32(float *Au, const float *v, const double *vscale, const int *pd, const float *D, const float *c, const float *w, const int *eo, int ne, int N, void *s)
+{
+    if (ne <= 0) return 0;
+    if (!pd) return 1; /* the float inner solve always gathers */
+    const int n = N + 1, n3 = n * n * n;
+    const size_t span = affine_span(eo, ne, n3);
+    float *G[6];
+    for (int f = 0; f < 6; f++) G[f] = (float *)calloc(span + 1, sizeof(float));
+    for (int e = 0; e < ne; e++)
+    {
+        const size_t o = eo ? (size_t)eo[e] : (size_t)e * n3;
+        for (int k = 0; k < n; k++)
+            for (int j = 0; j < n; j++)
+                for (int i = 0; i < n; i++)
+                {
+                    const float W = (w[i] * w[j]) * w[k];
+                    for (int f = 0; f < 6; f++) G[f][o + i + j * n + k * n * n] = c[(size_t)e * 6 + f] * W;
+                }
+    }
+    const float *Gc[6] = {G[0], G[1], G[2], G[3], G[4], G[5]};
+    int rc = fdd_sub_stiffness_matrix_gather_scaled_f32(Au, v, vscale, pd, D, Gc, eo, ne, N, s);
+    for (int f = 0; f < 6; f++) free(G[f]);
+    return rc;
+}
+
+int fdd_stiffness_affine_detect(double *c, double *deviation, const double *const G[6], const int *eo, const double *w, int ne, int N, void *s)
+{
+    (void)s;
+    const int n = N + 1, n3 = n * n * n, m = n / 2, p0 = m + m * n + m * n * n;
+    for (int e = 0; e < ne; e++)
+    {
+        const size_t o = eo ? (size_t)eo[e] : (size_t)e * n3;
+        double scale = 0.0, worst = 0.0;
+        for (int f = 0; f < 6; f++)
+        {
+            c[(size_t)e * 6 + f] = G[f][o + p0] / ((w[m] * w[m]) * w[m]);
+            if (fabs(c[(size_t)e * 6 + f]) > scale) scale = fabs(c[(size_t)e * 6 + f]);
+        }
+        for (int p = 0; p < n3; p++)
+        {
+            const int i = p % n, j = (p / n) % n, k = p / (n * n);
+            const double W = (w[i] * w[j]) * w[k];
+            for (int f = 0; f < 6; f++)
+            {
+                const double d = fabs(G[f][o + p] - c[(size_t)e * 6 + f] * W) / (scale * W);
+                if (d > worst) worst = d;
+            }
+        }
+        deviation[e] = (scale > 0.0) ? worst : 1.0;
+    }
+    return 0;
+}

@@ -90,6 +90,14 @@ def run(world, E, N, red, amg=True):
         u32, its32, h32 = p.solve(f, "fcg")
         assert abs(its32 - its64) <= 1 and h32[-1] <= 1e-7 * h32[0] * 1.0001
         p.set_flag("preconditioner_precision", 64)
+        # the affine-elements option on the composite: every level list of the region (own elements, rings at their reduced
+        # degrees, the degree-1 far field) is checked on its own and runs without streaming its factor arrays
+        p.set_flag("affine_geometry", 1)
+        info = p.affine_info()
+        assert info["fine_domain"] and info["sub_lists_affine"] == info["sub_lists"] >= 2 and info["max_deviation"] <= 64 * np.finfo(float).eps, info
+        ua, itsa, ha = p.solve(f, "fcg")
+        assert itsa == its64 and np.abs(ua - solves[(0, "fcg")][0][rank]).max() <= 1e-8 * np.abs(ua).max()
+        p.set_flag("affine_geometry", 0)
         its_amg = None
         if amg:
             # the reference's default: the low-order V-cycle inside every inner step, hierarchy built by the host layer

@@ -533,3 +533,67 @@ def test_point_jacobi_option(setup, E, N, red):
         sd.close()
         W.close()
         p.close()
+
+
+def test_affine_geometry_option(setup, tmp_path):
+    """ "affine_geometry" (a labelled option of this build, off by default; the reference always streams the six factor
+    arrays): on a box mesh every element passes the check of the mesh's OWN factors against c_f(e) (w_i w_j) w_k, the
+    outer operator and the inner solves (double and float) run on the kernel that does not read them, and the solve is
+    the streamed one to rounding -- same iteration count against the oracle, solution to 1e-12.  On a deformed mesh no
+    element passes, nothing is switched and the results are the streamed ones bit for bit."""
+    E, N, red = (4, 3, 3), 7, 6
+    p = make_problem(E, N, red, True)
+    W = S.OracleWorld([S.ArrayMesh.from_problem(p)], N)
+    sd = oracle_subdomain(p, N, red)
+    try:
+        assert p.affine_info() == {"fine_domain": False, "sub_lists_affine": 0, "sub_lists": 1, "max_deviation": -1.0}
+        _, f = p.make_rhs_from(S.seeded_uniform(p.n, 1234))
+        u0, its0, h0 = p.solve(f, "fcg")
+        r = S.seeded_uniform(p.n, 5) - 0.5
+        z0, zh0 = p.precond_apply(r, "gmres")
+        q0 = p.stiffness(r, dssum=True)
+        p.set_flag("affine_geometry", 1)
+        info = p.affine_info()
+        assert info["fine_domain"] and info["sub_lists_affine"] == info["sub_lists"] == 1 and 0.0 <= info["max_deviation"] <= 64 * np.finfo(float).eps, info
+        z1, zh1 = p.precond_apply(r, "gmres")
+        assert np.abs(z1 - z0).max() <= 1e-12 * np.abs(z0).max() and np.abs(zh1 - zh0).max() <= 1e-12 * zh0[0]
+        u1, its1, h1 = p.solve(f, "fcg")
+
+        def pre(zz, rr):
+            out, _, _ = sd.solve(rr[0], "gmres")
+            zz[0][:] = out
+
+        ou, oits, ohist = W.solve([f], "fcg", precond=pre)
+        assert its1 == its0 == oits
+        assert np.abs(h1 - ohist).max() <= 1e-8 * ohist[0] and np.abs(u1 - ou[0]).max() <= 1e-9 * np.abs(ou[0]).max()
+        assert np.abs(u1 - u0).max() <= 1e-12 * np.abs(u0).max()
+        # the float inner solve on the same option
+        p.set_flag("preconditioner_precision", 32)
+        u32, its32, h32 = p.solve(f, "fcg")
+        p.set_flag("affine_geometry", 0)
+        assert not p.affine_info()["fine_domain"] and p.affine_info()["sub_lists_affine"] == 0
+        v32, jts32, g32 = p.solve(f, "fcg")
+        assert its32 == jts32 and np.abs(u32 - v32).max() <= 1e-5 * np.abs(v32).max() and h32[-1] <= 1e-7 * h32[0] * 1.0001
+        p.set_flag("preconditioner_precision", 64)
+        assert np.array_equal(p.stiffness(r, dssum=True), q0)  # the point-space reference sequence never uses the option
+    finally:
+        W.close()
+        sd.close()
+        p.close()
+
+    d = str(tmp_path / "curved")
+    E, N, red = (3, 2, 2), 5, 4
+    for deg in S.level_degrees(N, red):
+        S.write_mesh_files(d, S.DeformedMesh(E, deg, 0.05))
+    p = H.Problem.from_directory(d, N, red)
+    p.set_flag("sub_use_preconditioner", 0)
+    try:
+        _, f = p.make_rhs_from(S.seeded_uniform(p.n, 99))
+        u0, its0, h0 = p.solve(f, "fcg")
+        p.set_flag("affine_geometry", 1)
+        info = p.affine_info()
+        assert not info["fine_domain"] and info["sub_lists_affine"] == 0 and info["max_deviation"] > 1e-6, info
+        u1, its1, h1 = p.solve(f, "fcg")
+        assert its1 == its0 and np.array_equal(u1, u0) and np.array_equal(h1, h0)
+    finally:
+        p.close()

@@ -1487,3 +1487,59 @@ def test_runtime_memory_roundtrip(gpu):
     name = ctypes.create_string_buffer(128)
     L.call("fdd_device_name", name, 128)
     assert b"gfx950" in name.value
+
+
+# ------------------------------------- affine elements (an option of the build)
+def affine_factor_arrays(c, w, E, N, dtype=np.float64):
+    """G_f(e; i, j, k) = c[e, f] * ((w_i * w_j) * w_k), associated as the kernel forms it"""
+    n = N + 1
+    w = w.astype(dtype)
+    W = ((w[None, None, :] * w[None, :, None]) * w[:, None, None]).astype(dtype)  # [k, j, i], x fastest
+    return [np.ascontiguousarray((c[:, f, None].astype(dtype) * W.reshape(1, -1)).astype(dtype).ravel()) for f in range(6)]
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 5, 7, 8, 10, 15])
+def test_stiffness_affine_equals_the_streamed_kernel(gpu, N):
+    """fdd_stiffness_matrix_affine forms the six factors of a point from six numbers per element and the GLL weights
+    instead of reading them: on factor arrays that ARE c_f(e) (w_i w_j) w_k it is the oracle's arithmetic bit for bit
+    (plain and gathered with a scale, contiguous and offset-list order), and fdd_stiffness_affine_detect recognises
+    such arrays and points at the one element that is not of that form."""
+    n3 = (N + 1) ** 3
+    w = S.gll(N)[1]
+    for E in (1, 6, 41):
+        rng = np.random.default_rng(900 + 7 * N + E)
+        c = np.concatenate([rng.uniform(0.5, 1.5, (E, 3)), rng.uniform(-0.2, 0.2, (E, 3))], axis=1)
+        G = affine_factor_arrays(c, w, E, N)
+        u, _, D = stiffness_inputs(E, N, 901 + N)
+        Au, _ = oracle_stiffness(u, G, D, N, 3)
+        dc, dw, dD = dev(c.ravel(), gpu), dev(w, gpu), dev(D, gpu)
+        out = torch.full((E * n3,), 3.0, dtype=torch.float64, device=gpu)
+        k("fdd_stiffness_matrix_affine", out, dev(u, gpu), None, None, dD, dc, dw, None, E, N)
+        assert np.array_equal(host(out), Au), (N, E)
+        # gathered through an index array with holes, scaled, elements through an offset list in reverse order
+        ndof = max(1, (E * n3) // 3)
+        pd = rng.integers(-1, ndof, E * n3).astype(np.int32)
+        v = rng.uniform(-1, 1, ndof)
+        scale = 0.37251
+        ug = np.where(pd >= 0, (scale * v)[np.maximum(pd, 0)], 0.0)
+        Aug, _ = oracle_stiffness(ug, G, D, N, 3)
+        eo = (np.arange(E)[::-1] * n3).astype(np.int32)
+        # the list's k-th element sits at eo[k]: its six numbers are those of element E-1-k of the arrays
+        dcr = dev(c[::-1].ravel(), gpu)
+        out2 = torch.full((E * n3,), 5.0, dtype=torch.float64, device=gpu)
+        k("fdd_stiffness_matrix_affine", out2, dev(v, gpu), dev(np.array([scale]), gpu), dev(pd, gpu), dD, dcr, dw, dev(eo, gpu), E, N)
+        assert np.array_equal(host(out2), Aug), (N, E, "gather")
+        # detection: the arrays built above pass; one factor of one point of the last element nudged by 1e-9 does not
+        dG = [dev(g, gpu) for g in G]
+        cd = torch.zeros(E * 6, dtype=torch.float64, device=gpu)
+        dv = torch.full((E,), -1.0, dtype=torch.float64, device=gpu)
+        k("fdd_stiffness_affine_detect", cd, dv, dG, None, dw, E, N)
+        assert host(dv).max() <= 8 * np.finfo(float).eps and np.abs(host(cd).reshape(E, 6) - c).max() <= 4 * np.finfo(float).eps * np.abs(c).max()
+        G2 = [g.copy() for g in G]
+        G2[0][(E - 1) * n3 + n3 - 1] *= 1.0 + 1e-9  # a diagonal factor: between a third of and the whole of the largest one
+        k("fdd_stiffness_affine_detect", cd, dv, [dev(g, gpu) for g in G2], None, dw, E, N)
+        d = host(dv)
+        assert d[: E - 1].max(initial=0.0) <= 8 * np.finfo(float).eps and 1e-10 < d[E - 1] < 1e-8, (N, E, d)
+    if N == 7:
+        with pytest.raises(lib.FddError):
+            k("fdd_stiffness_matrix_affine", out, dev(u, gpu), None, None, dD, dc, dw, None, E, 16)

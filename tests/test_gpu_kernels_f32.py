@@ -226,3 +226,30 @@ def test_diagonal_scaling(gpu, n):
     assert np.array_equal(host(z32), ref32)
     k("fdd_vector_diagonal_scaling_dev_f32", z32, dev(d32, gpu), None, dev(u32, gpu), n)
     assert np.array_equal(host(z32), (d32 * u32).astype(f32))
+
+
+@pytest.mark.parametrize("N", [1, 3, 7, 9])
+def test_stiffness_affine_f32_equals_the_streamed_kernel(gpu, N):
+    """fdd_stiffness_matrix_affine_f32 (the factors of a point formed from six floats per element and the float GLL
+    weights) on factor arrays of exactly that form == the float oracle twin of the streamed kernel, bit for bit."""
+    L = S.oracle()
+    n = N + 1
+    n3 = n**3
+    D = S.gll(N)[2].astype(f32)
+    w = S.gll(N)[1].astype(f32)
+    W = ((w[None, None, :] * w[None, :, None]).astype(f32) * w[:, None, None]).astype(f32).reshape(1, -1)
+    for E in (1, 6, 41):
+        rng = np.random.default_rng(950 + 13 * N + E)
+        c = np.concatenate([rng.uniform(0.5, 1.5, (E, 3)), rng.uniform(-0.2, 0.2, (E, 3))], axis=1).astype(f32)
+        G = [np.ascontiguousarray((c[:, g, None] * W).astype(f32).ravel()) for g in range(6)]
+        ndof = max(1, (E * n3) // 3)
+        pd = rng.integers(-1, ndof, E * n3).astype(np.int32)
+        v = rng.uniform(-1, 1, ndof).astype(f32)
+        for scale in (None, 0.37251):
+            ref = np.zeros(E * n3, f32)
+            sc32 = None if scale is None else np.array([scale], np.float64).astype(f32)
+            L.orc_f32_sub_stiffness(P(ref), P(v), P(pd), None if sc32 is None else P(sc32), P(D), ptrs(G), E, N)
+            dsc = None if scale is None else dev(np.array([scale]), gpu)
+            out = torch.full((E * n3,), 3.0, dtype=torch.float32, device=gpu)
+            k("fdd_stiffness_matrix_affine_f32", out, dev(v, gpu), dsc, dev(pd, gpu), dev(D, gpu), dev(c.ravel(), gpu), dev(w, gpu), None, E, N)
+            assert np.array_equal(host(out), ref), (N, E, scale)

@@ -168,6 +168,14 @@ def main():
         del qc0
         if N >= 8:
             report(f"stiffness.mfma_f64 N={N}", 64 * P, timeit(lambda: k("fdd_stiffness_matrix_mfma", Au, u, Dh, G, None, E**3, N)), results)
+        # affine elements: six numbers per element + the GLL weights instead of six streamed arrays (16 B/pt; with the gather 12 B/pt + the dofs)
+        Gc = torch.rand(E**3 * 6, dtype=torch.float64, device=dev)
+        wg = torch.tensor(w, dtype=torch.float64, device=dev)
+        report(f"stiffness.affine N={N}", 16 * P, timeit(lambda: k("fdd_stiffness_matrix_affine", Au, u, None, None, Dh, Gc, wg, None, E**3, N)), results)
+        (_, qc1, _), _, _, nodes1 = box_Q(E, N, dev)
+        v1 = torch.rand(nodes1, dtype=torch.float64, device=dev)
+        report(f"stiffness.affine+gather N={N}", 12 * P + 8 * nodes1, timeit(lambda: k("fdd_stiffness_matrix_affine", Au, v1, None, qc1, Dh, Gc, wg, None, E**3, N)), results)
+        del qc1, v1
         GDu = [c, d, e_]
 
         def two():
