@@ -297,6 +297,8 @@ int fdd_sqrt_sum_dev(double *out, const double *parts_dev, int nparts, void *str
  * where the mesh's own factor arrays have that form to rounding (Stiffness_Operator::affine); results agree with the
  * streamed form to a few ulp of the factors, not bit for bit. */
 int fdd_stiffness_matrix_affine(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *elem_factors, const double *gll_weights, const int *elem_offset, int num_elements, int poly_degree, void *stream);
+/* the same on the matrix-core kernel (poly_degree 8..15; Au != v) */
+int fdd_stiffness_matrix_mfma_affine(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *elem_factors, const double *gll_weights, const int *elem_offset, int num_elements, int poly_degree, void *stream);
 /* Do the factor arrays have that form?  Per element e of the list: elem_factors[6 e + f] = G_f / W at the element's middle
  * point, deviation[e] = max over points and factors of |G_f(p) - elem_factors[6 e + f] W(p)| / (max_f |elem_factors| W(p)),
  * W(p) = (w_i w_j) w_k.  3-D elements. */

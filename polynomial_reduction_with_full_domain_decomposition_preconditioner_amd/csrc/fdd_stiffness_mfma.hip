@@ -137,7 +137,10 @@ __device__ __forceinline__ void tile_add(double *dst, int base, int rs, int cs, 
 }
 
 // kGather: u[p] = (*u_scale) * v[point_dof[p]] (0 where the point has no dof), as in fused_stiffness_kernel
-template <int n, bool kGather>
+// kAffine: the factors of a point are c_f(e) (w_i w_j) w_k, formed in P2 from six numbers per element (G.g[0], element-
+// major) and the GLL weights (G.g[1]) instead of prefetched from the six arrays -- 48 of the 64 bytes per point are not
+// read (fdd_stiffness.hip, fused_stiffness_kernel_t; an option of this build for affine elements).
+template <int n, bool kGather, bool kAffine = false>
 __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ u_scale, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -221,10 +224,21 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
             for (int m = 0; m < kPts; m++) rd[m] = load_idx(base_n, goff(m), valid(m));
             asm volatile("" ::: "memory");
         }
+        if (!kAffine)
+        {
 #pragma unroll
-        for (int m = 0; m < kPts; m++)
+            for (int m = 0; m < kPts; m++)
 #pragma unroll
-            for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? (G.g[g] + base)[goff(m)] : 0.0;
+                for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = valid(m) ? (G.g[g] + base)[goff(m)] : 0.0;
+        }
+    }
+    // kAffine: (w_i w_j) of the lane's four points and w_k of its slab; zero on the padding
+    double wij[kAffine ? kPts : 1], wk = 0.0;
+    if (kAffine)
+    {
+#pragma unroll
+        for (int m = 0; m < kPts; m++) wij[m] = valid(m) ? G.g[1][pi] * G.g[1][pj0 + 4 * m] : 0.0;
+        wk = (wave < n) ? G.g[1][wave] : 0.0;
     }
 
 #if FDD_MFMA_TRACE
@@ -280,6 +294,19 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
         FDD_TR(4);
 
         // P2: geometric factors, point-wise, in place (domain.okl:47-49)
+        if (kAffine)
+        {
+            double cf[FDD_NUM_GEOM_FACTS];
+#pragma unroll
+            for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) cf[g] = G.g[0][(size_t)e * FDD_NUM_GEOM_FACTS + g]; // wave-uniform address
+#pragma unroll
+            for (int m = 0; m < kPts; m++)
+            {
+                const double w3 = wij[kAffine ? m : 0] * wk;
+#pragma unroll
+                for (int g = 0; g < FDD_NUM_GEOM_FACTS; g++) rg[g][m] = cf[g] * w3;
+            }
+        }
 #pragma unroll
         for (int m = 0; m < kPts; m++)
         {
@@ -288,7 +315,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
             sA2[lidx(m)] = rg[3][m] * Du_1 + rg[1][m] * Du_2 + rg[5][m] * Du_3;
             sA3[lidx(m)] = rg[4][m] * Du_1 + rg[5][m] * Du_2 + rg[2][m] * Du_3;
         }
-        if (FDD_MFMA_UNCOND_PREFETCH || more)
+        if (!kAffine && (FDD_MFMA_UNCOND_PREFETCH || more))
         {
 #pragma unroll
             for (int m = 0; m < kPts; m++)
@@ -335,7 +362,7 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
 #undef valid
 }
 
-template <int n>
+template <int n, bool kAffine = false>
 int launch_mfma(double *Au, const double *u, const int *point_dof, const double *u_scale, const double *D_hat, const GPtrs &G, const int *elem_offset, int num_elements, void *stream)
 {
     const size_t lds = (4 * (size_t)ARR + 4 * 64) * sizeof(double);
@@ -343,18 +370,43 @@ int launch_mfma(double *Au, const double *u, const int *point_dof, const double 
     static std::once_flag configured;
     hipError_t attr_a = hipSuccess, attr_b = hipSuccess;
     std::call_once(configured, [&] {
-        attr_a = hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_stiffness_kernel<n, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_b = hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_stiffness_kernel<n, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_a = hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_stiffness_kernel<n, false, kAffine>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_b = hipFuncSetAttribute(reinterpret_cast<const void *>(mfma_stiffness_kernel<n, true, kAffine>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     FDD_HIP_CHECK(attr_a);
     FDD_HIP_CHECK(attr_b);
     const int grid = num_elements < FDD_CU_COUNT ? num_elements : FDD_CU_COUNT;
     if (point_dof)
-        hipLaunchKernelGGL((mfma_stiffness_kernel<n, true>), dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((mfma_stiffness_kernel<n, true, kAffine>), dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
     else
-        hipLaunchKernelGGL((mfma_stiffness_kernel<n, false>), dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((mfma_stiffness_kernel<n, false, kAffine>), dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
     FDD_LAUNCH_CHECK();
     return 0;
+}
+
+int mfma_dispatch_affine(double *Au, const double *u, const int *point_dof, const double *u_scale, const double *D_hat, const double *elem_factors, const double *gll_weights, const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    FDD_REQUIRE(num_elements >= 0);
+    if (num_elements == 0) return 0;
+    FDD_REQUIRE(Au != nullptr && u != nullptr && D_hat != nullptr && elem_factors != nullptr && gll_weights != nullptr && Au != u);
+    GPtrs g;
+    for (int k = 0; k < FDD_NUM_GEOM_FACTS; k++) g.g[k] = nullptr;
+    g.g[0] = elem_factors;
+    g.g[1] = gll_weights;
+    switch (poly_degree + 1)
+    {
+    case 9: return launch_mfma<9, true>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 10: return launch_mfma<10, true>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 11: return launch_mfma<11, true>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 12: return launch_mfma<12, true>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 13: return launch_mfma<13, true>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 14: return launch_mfma<14, true>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 15: return launch_mfma<15, true>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    case 16: return launch_mfma<16, true>(Au, u, point_dof, u_scale, D_hat, g, elem_offset, num_elements, stream);
+    default:
+        fdd_set_error("fp64-MFMA stiffness kernel supports poly_degree 8..15, got %d", poly_degree);
+        return FDD_ERR_UNSUPPORTED;
+    }
 }
 
 int mfma_dispatch(double *Au, const double *u, const int *point_dof, const double *u_scale, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
@@ -391,6 +443,11 @@ extern "C" {
 int fdd_stiffness_matrix_mfma(double *Au, const double *u, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)
 {
     return mfma_dispatch(Au, u, nullptr, nullptr, D_hat, G, elem_offset, num_elements, poly_degree, stream);
+}
+
+int fdd_stiffness_matrix_mfma_affine(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *elem_factors, const double *gll_weights, const int *elem_offset, int num_elements, int poly_degree, void *stream)
+{
+    return mfma_dispatch_affine(Au, v, point_dof, v_scale_dev, D_hat, elem_factors, gll_weights, elem_offset, num_elements, poly_degree, stream);
 }
 
 int fdd_stiffness_matrix_mfma_gather(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream)

@@ -790,7 +790,7 @@ class Domain
     {
         affine_geometry = false;
         if (not on) return true;
-        if (mesh.dim != 3 or poly_degree > 10 or num_local_elements == 0) return false; // degrees >= 11 run on the matrix cores, which stream
+        if (mesh.dim != 3 or poly_degree > 15 or num_local_elements == 0) return false;
         if (not affine_checked)
         {
             const int n = poly_degree + 1;
@@ -816,6 +816,12 @@ class Domain
     {
         if (affine_geometry)
         {
+            if (poly_degree >= 11 and mfma_stiffness)
+            {
+                fdd::ProfileScope prof("mfma_stiffness_kernel<gather,affine>", 12.0 * num_local_points + 8.0 * num_local_nodes);
+                FDD_CALL(fdd_stiffness_matrix_mfma_affine(q.as<double>(), pn.as<double>(), nullptr, point_node_dev.as<int>(), D_hat.as<double>(), affine_c.as<double>(), affine_w.as<double>(), nullptr, num_local_elements, poly_degree, fdd::dev().stream));
+                return;
+            }
             fdd::ProfileScope prof("fused_stiffness_kernel<gather,affine>", 12.0 * num_local_points + 8.0 * num_local_nodes);
             FDD_CALL(fdd_stiffness_matrix_affine(q.as<double>(), pn.as<double>(), nullptr, point_node_dev.as<int>(), D_hat.as<double>(), affine_c.as<double>(), affine_w.as<double>(), nullptr, num_local_elements, poly_degree, fdd::dev().stream));
             return;

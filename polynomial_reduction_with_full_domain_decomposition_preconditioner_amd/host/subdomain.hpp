@@ -2221,7 +2221,7 @@ class Subdomain
         affine_geometry = false;
         for (auto &ll : subdomain_operator.level_lists)
         {
-            if (not on or dim != 3 or ll.poly_degree > 10 or ll.num_elements == 0)
+            if (not on or dim != 3 or ll.poly_degree > 15 or ll.num_elements == 0)
             {
                 ll.affine = false;
                 continue;
@@ -2267,6 +2267,15 @@ class Subdomain
         for (auto &ll : subdomain_operator.level_lists)
         {
             const double n3 = (double)(ll.poly_degree + 1) * (ll.poly_degree + 1) * (ll.poly_degree + 1);
+            if (ll.affine and ll.poly_degree >= 11 and mfma_stiffness)
+            {
+                fdd::ProfileScope prof("mfma_stiffness_kernel<gather,affine>", (12.0 * n3) * ll.num_elements + 8.0 * subdomain_operator.num_extended_dofs);
+                if (ll.contiguous)
+                    FDD_CALL(fdd_stiffness_matrix_mfma_affine(q.as<double>() + ll.first_offset, za.as<double>(), scale_dev, point_dof_dev.template as<int>() + ll.first_offset, subdomain_operator.D_hat[ll.level].template as<double>(), ll.affine_c.template as<double>(), ll.affine_w.template as<double>(), nullptr, ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                else
+                    FDD_CALL(fdd_stiffness_matrix_mfma_affine(q.as<double>(), za.as<double>(), scale_dev, point_dof_dev.template as<int>(), subdomain_operator.D_hat[ll.level].template as<double>(), ll.affine_c.template as<double>(), ll.affine_w.template as<double>(), ll.elem_offset.template as<int>(), ll.num_elements, ll.poly_degree, fdd::dev().stream));
+                continue;
+            }
             if (ll.affine)
             {
                 fdd::ProfileScope prof("fused_stiffness_kernel<gather,affine>", (12.0 * n3) * ll.num_elements + 8.0 * subdomain_operator.num_extended_dofs);

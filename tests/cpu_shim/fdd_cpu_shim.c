@@ -945,3 +945,8 @@ int fdd_stiffness_affine_detect(double *c, double *deviation, const double *cons
     }
     return 0;
 }
+
+int fdd_stiffness_matrix_mfma_affine(double *Au, const double *v, const double *vscale, const int *pd, const double *D, const double *c, const double *w, const int *eo, int ne, int N, void *s)
+{
+    return fdd_stiffness_matrix_affine(Au, v, vscale, pd, D, c, w, eo, ne, N, s);
+}

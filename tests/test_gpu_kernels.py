@@ -1543,3 +1543,36 @@ def test_stiffness_affine_equals_the_streamed_kernel(gpu, N):
     if N == 7:
         with pytest.raises(lib.FddError):
             k("fdd_stiffness_matrix_affine", out, dev(u, gpu), None, None, dD, dc, dw, None, E, 16)
+
+
+@pytest.mark.parametrize("N", [8, 11, 14, 15])
+def test_stiffness_mfma_affine(gpu, N):
+    """The matrix-core kernel with the factors formed from six numbers per element (fdd_stiffness_matrix_mfma_affine):
+    on factor arrays of exactly that form it is the streamed matrix-core kernel bit for bit (the same products feed
+    the same matrix instructions) and the oracle to the matrix-core tolerance; plain, and gathered with a scale
+    through an offset list (more elements than workgroups, so the persistent loop runs)."""
+    n3 = (N + 1) ** 3
+    w = S.gll(N)[1]
+    for E in (1, 5, 300):
+        rng = np.random.default_rng(970 + 7 * N + E)
+        c = np.concatenate([rng.uniform(0.5, 1.5, (E, 3)), rng.uniform(-0.2, 0.2, (E, 3))], axis=1)
+        G = affine_factor_arrays(c, w, E, N)
+        u, _, D = stiffness_inputs(E, N, 971 + N)
+        Au, _ = oracle_stiffness(u, G, D, N, 3)
+        dc, dw, dD, dG = dev(c.ravel(), gpu), dev(w, gpu), dev(D, gpu), [dev(g, gpu) for g in G]
+        ref = torch.full((E * n3,), 3.0, dtype=torch.float64, device=gpu)
+        out = torch.full((E * n3,), 5.0, dtype=torch.float64, device=gpu)
+        k("fdd_stiffness_matrix_mfma", ref, dev(u, gpu), dD, dG, None, E, N)
+        k("fdd_stiffness_matrix_mfma_affine", out, dev(u, gpu), None, None, dD, dc, dw, None, E, N)
+        assert np.array_equal(host(out), host(ref)), (N, E)
+        assert np.abs(host(out) - Au).max() <= 1e-12 * np.abs(Au).max()
+        ndof = max(1, (E * n3) // 3)
+        pd = rng.integers(-1, ndof, E * n3).astype(np.int32)
+        v = rng.uniform(-1, 1, ndof)
+        sc = dev(np.array([0.37251]), gpu)
+        eo = (np.arange(E)[::-1] * n3).astype(np.int32)
+        ref2 = torch.full((E * n3,), 3.0, dtype=torch.float64, device=gpu)
+        out2 = torch.full((E * n3,), 5.0, dtype=torch.float64, device=gpu)
+        k("fdd_stiffness_matrix_mfma_gather", ref2, dev(v, gpu), sc, dev(pd, gpu), dD, dG, dev(eo, gpu), E, N)
+        k("fdd_stiffness_matrix_mfma_affine", out2, dev(v, gpu), sc, dev(pd, gpu), dD, dev(c[::-1].ravel(), gpu), dw, dev(eo, gpu), E, N)
+        assert np.array_equal(host(out2), host(ref2)), (N, E, "gather")

@@ -175,6 +175,9 @@ def main():
         (_, qc1, _), _, _, nodes1 = box_Q(E, N, dev)
         v1 = torch.rand(nodes1, dtype=torch.float64, device=dev)
         report(f"stiffness.affine+gather N={N}", 12 * P + 8 * nodes1, timeit(lambda: k("fdd_stiffness_matrix_affine", Au, v1, None, qc1, Dh, Gc, wg, None, E**3, N)), results)
+        if N >= 8:
+            report(f"stiffness.mfma_affine N={N}", 16 * P, timeit(lambda: k("fdd_stiffness_matrix_mfma_affine", Au, u, None, None, Dh, Gc, wg, None, E**3, N)), results)
+            report(f"stiffness.mfma_affine+gather N={N}", 12 * P + 8 * nodes1, timeit(lambda: k("fdd_stiffness_matrix_mfma_affine", Au, v1, None, qc1, Dh, Gc, wg, None, E**3, N)), results)
         del qc1, v1
         GDu = [c, d, e_]
 
