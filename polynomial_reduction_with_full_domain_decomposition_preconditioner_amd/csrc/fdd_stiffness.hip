@@ -262,7 +262,7 @@ __device__ __forceinline__ void element_sync()
 // list), G.g[1] to the n weights.  An option of this build (the reference always streams G): the host layer offers it
 // only where the mesh's own factor arrays satisfy the product form to rounding (host/element.hpp: affine_factors).
 template <typename T, int n, bool kGather, bool kNTStore, bool kAffine = false>
-__global__ __launch_bounds__(kBlock) void fused_stiffness_kernel_t(T *__restrict__ Au, const T *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ u_scale, const T *__restrict__ D_hat, GPtrsT<T> G, const int *__restrict__ elem_offset, int num_elements)
+__global__ __launch_bounds__(kBlock, (kAffine && n == 8 && sizeof(T) == 8) ? 4 : 1) void fused_stiffness_kernel_t(T *__restrict__ Au, const T *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ u_scale, const T *__restrict__ D_hat, GPtrsT<T> G, const int *__restrict__ elem_offset, int num_elements)
 {
     using C = FusedCfg<n>;
     constexpr int nn = C::nn;
