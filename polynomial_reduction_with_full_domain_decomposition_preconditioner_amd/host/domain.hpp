@@ -119,6 +119,8 @@ class Domain
     fdd::memory point_node_dev;           // int[num_local_points]: Q as an index array
     fdd::memory node_mask;                // Dirichlet mask per node
     fdd::memory node_stitch;              // local multiplicity * assembled weight * mask
+    std::vector<DType> node_stitch_hst;
+    bool stitch_is_one = false;           // every weight of the dof slice is exactly 1.0 (setup_dof_maps)
     fdd::memory node_of_dof, dof_of_node; // renumbering to / from the subdomain's dofs
     int nodes_sub_dofs = -1;
     int dof_shift = -1; // >= 0: subdomain dof d is node d + dof_shift (the numbering makes it so), no renumbering pass
@@ -283,6 +285,7 @@ class Domain
     bool assembled_outer = true; // flexible CG on node vectors (one value per assembled node) when the configuration allows it
     bool device_scalars = true;  // node-space flexible CG: alpha / beta read by the update kernels from device memory, residual norm fetched late
     bool lazy_steps = true;      // fcg_steps: K iterations with one host synchronisation at the end
+    bool unit_stitch_in_place = true; // stitching weights of the dof slice all exactly 1 (one rank): the inner solve writes z~ in place (0: the multiplication by the ones, the reference's sequence)
     bool mfma_stiffness = true; // N >= 11: stiffness on the fp64 matrix cores (not bit-identical; 1e-12 tolerance)
     DType tolerance = 1.0e-07;
     std::vector<DType> residual_history; // what the reference prints per iteration
@@ -734,6 +737,7 @@ class Domain
         node_mask.copyFrom(mask.data(), (size_t)nn * sizeof(DType));
         node_stitch = fdd::dev().malloc<DType>(std::max(nn, 1));
         node_stitch.copyFrom(stitch.data(), (size_t)nn * sizeof(DType));
+        node_stitch_hst = stitch;
 
         for (fdd::memory *v : {&nu, &nr, &nr1, &nq, &nz, &np, &nt}) *v = fdd::dev().malloc<DType>(std::max(nn, 1));
         nodes_ready = true;
@@ -768,6 +772,9 @@ class Domain
         sub_u = subdomain.new_dof_vector(); // a composite keeps copies / hanging values behind its dofs
         if (composite_precond and not rp.ptr()) rp = subdomain.tree_points(); // lives in the Subdomain's tree vector: level 0 is read in place
         nodes_sub_dofs = nd;
+        stitch_is_one = dof_shift >= 0 and not composite_precond and (int)node_stitch_hst.size() >= dof_shift + nd;
+        for (int d = 0; d < nd and stitch_is_one; d++)
+            if (node_stitch_hst[(size_t)dof_shift + d] != (DType)1.0) stitch_is_one = false;
     }
 
     // t = Qt v: this rank's sums over the copies of every node (no exchange)
@@ -919,9 +926,17 @@ class Domain
             }
             else if (dof_shift >= 0)
             {
-                // the dofs are the node slice [dof_shift, dof_shift + dofs): the inner solve reads r^ in place
+                // the dofs are the node slice [dof_shift, dof_shift + dofs): the inner solve reads r^ in place -- and, where
+                // every stitching weight of the slice is exactly 1 (one rank: multiplicity * 1/multiplicity), writes z~ in
+                // place as well: the multiplication below would be x * 1.0
                 fdd::memory f_slice = rn.slice(dof_shift, nodes_sub_dofs);
-                subdomain.gmres_dofs(sub_u, f_slice);
+                if (stitch_is_one and unit_stitch_in_place)
+                {
+                    fdd::memory z_slice = zn.slice(dof_shift, nodes_sub_dofs);
+                    subdomain.gmres_dofs(z_slice, f_slice);
+                }
+                else
+                    subdomain.gmres_dofs(sub_u, f_slice);
             }
             else
             {
@@ -931,7 +946,11 @@ class Domain
             timer.stop("subdomain.solver");
 
             timer.start("subdomain.stitching");
-            if (dof_shift >= 0)
+            if (dof_shift >= 0 and not composite_precond and stitch_is_one and unit_stitch_in_place)
+            {
+                // z~ is already in place
+            }
+            else if (dof_shift >= 0)
             {
                 // the Dirichlet ends of z~ were cleared once (fcg_nodes_begin) and nothing writes them: the shared ones
                 // see only zeros in the exchange (every rank masks them)

@@ -597,3 +597,30 @@ def test_affine_geometry_option(setup, tmp_path):
         assert its1 == its0 and np.array_equal(u1, u0) and np.array_equal(h1, h0)
     finally:
         p.close()
+
+
+def test_unit_stitch_in_place_is_bit_identical(setup):
+    """One rank: every stitching weight of the dof slice is multiplicity * (1 / multiplicity) = 1.0 exactly, so the
+    inner solve writes its correction straight into the outer iteration's z~ instead of a vector that is then
+    multiplied by ones ("unit_stitch_in_place", on by default).  Same bits as the reference's sequence, double and
+    float inner solve, with and without the V-cycle."""
+    p = make_problem((4, 3, 3), 5, 4, True)
+    try:
+        _, f = p.make_rhs_from(S.seeded_uniform(p.n, 4321))
+        for precision in (64, 32):
+            p.set_flag("preconditioner_precision", precision)
+            p.set_flag("unit_stitch_in_place", 1)
+            u1, its1, h1 = p.solve(f, "fcg")
+            p.set_flag("unit_stitch_in_place", 0)
+            u0, its0, h0 = p.solve(f, "fcg")
+            assert its1 == its0 and np.array_equal(u1, u0) and np.array_equal(h1, h0), precision
+        p.set_flag("preconditioner_precision", 64)
+        p.set_flag("sub_use_preconditioner", 1)
+        assert p.amg_build(coarsest_size=40) >= 2
+        p.set_flag("unit_stitch_in_place", 1)
+        u1, its1, h1 = p.solve(f, "fcg")
+        p.set_flag("unit_stitch_in_place", 0)
+        u0, its0, h0 = p.solve(f, "fcg")
+        assert its1 == its0 and np.array_equal(u1, u0) and np.array_equal(h1, h0)
+    finally:
+        p.close()
