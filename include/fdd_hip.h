@@ -147,6 +147,10 @@ size_t fdd_reduce_workspace_doubles(void);
 int fdd_dom_residual_norm(double *out, double *ws, const double *r_k, const double *QQt_r_k, const double *dirichlet_mask, int num_points, void *stream);                  /* domain.okl:109-138; out[0] = sum r*QQt_r*mask (no sqrt) */
 int fdd_dom_projection_inner_products(double *out2, double *ws, const double *z_k, const double *r_k, const double *p_k, const double *q_k, int num_points, void *stream); /* domain.okl:140-184; out2 = {gamma, theta} */
 int fdd_dom_inner_product_flexible(double *out, double *ws, const double *r_k, const double *r_kp1, const double *z_k, int num_points, void *stream);                      /* domain.okl:195-224 */
+/* The same sum and, from the same three vectors, the NEXT iteration's gamma = <z_k, r_kp1> (the first sum of
+ * domain.okl:140-184 one iteration early; fdd_sub_inner_product(p, q) is what is left of that kernel):
+ * out2 = {gamma_next, theta}.  Same bits as the two separate entries. */
+int fdd_dom_inner_product_flexible_gamma(double *out2, double *ws, const double *r_k, const double *r_kp1, const double *z_k, int num_points, void *stream);
 int fdd_dom_inner_product(double *out, double *ws, const double *u_k, const double *v_k, const double *dirichlet_mask, int num_points, void *stream);                      /* domain.okl:235-264 */
 
 int fdd_dom_solution_and_residual_update(double *u_k, double *r_kp1, const double *r_k, const double *p_k, const double *q_k, double alpha_k, int num_points, void *stream); /* domain.okl:186-193, domain.tpp:978 */

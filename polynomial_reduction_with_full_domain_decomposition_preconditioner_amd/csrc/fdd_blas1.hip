@@ -32,6 +32,11 @@ __global__ __launch_bounds__(kBlock) void ew_scalar_kernel(Op op, long long n)
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) op.one(i);
 }
 
+// Element-wise kernels have no per-workgroup epilogue: at C2 sizes a grid of one pair of doubles per lane (21 k workgroups)
+// streams 5 % faster than 2048 workgroups walking the vector (6.7 against 6.3 TB/s on the axpy forms); the reductions,
+// whose workgroups end in a fold, are best at the 2048 of FDD_REDUCE_MAX_BLOCKS (16384: 4.0-5.1 instead of 5.9 TB/s).
+constexpr int kEwMaxBlocks = 32768;
+
 template <typename Op>
 int launch_ew(const Op &op, long long n, bool aligned, void *stream)
 {
@@ -39,12 +44,12 @@ int launch_ew(const Op &op, long long n, bool aligned, void *stream)
     if (aligned && n >= 2)
     {
         long long n2 = n / 2;
-        int grid = fdd_stream_grid(n2, kBlock);
+        int grid = fdd_stream_grid(n2, kBlock, kEwMaxBlocks);
         hipLaunchKernelGGL(ew_vec2_kernel<Op>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), op, n2, n);
     }
     else
     {
-        int grid = fdd_stream_grid(n, kBlock);
+        int grid = fdd_stream_grid(n, kBlock, kEwMaxBlocks);
         hipLaunchKernelGGL(ew_scalar_kernel<Op>, dim3(grid), dim3(kBlock), 0, fdd_stream(stream), op, n);
     }
     FDD_LAUNCH_CHECK();

@@ -229,6 +229,27 @@ struct FlexOp // domain.okl:195-224
     __device__ void one(long long i, Acc<1> &a) const { a.v[0] += (r1[i] - r[i]) * z[i]; }
 };
 
+// the flexible dot and, from the same three streams, the NEXT iteration's gamma = <z, r+> (domain.okl:140-184's first sum one
+// iteration early: the projection kernel of that iteration is then left with <p, q> alone).  out = {gamma_next, theta}.
+struct FlexGammaOp
+{
+    static constexpr int NV = 2;
+    const double *r, *r1, *z;
+    __device__ void vec2(long long i, Acc<2> &a) const
+    {
+        double2 a0 = ld2(r, i), a1 = ld2(r1, i), zz = ld2(z, i);
+        a.v[0] += zz.x * a1.x;
+        a.v[0] += zz.y * a1.y;
+        a.v[1] += (a1.x - a0.x) * zz.x;
+        a.v[1] += (a1.y - a0.y) * zz.y;
+    }
+    __device__ void one(long long i, Acc<2> &a) const
+    {
+        a.v[0] += z[i] * r1[i];
+        a.v[1] += (r1[i] - r[i]) * z[i];
+    }
+};
+
 struct FlexWOp // subdomain.okl:229-258
 {
     static constexpr int NV = 1;
@@ -527,6 +548,13 @@ int fdd_dom_inner_product_flexible(double *out, double *ws, const double *r_k, c
     FDD_REQUIRE(out != nullptr && ws != nullptr && num_points >= 0);
     FDD_REQUIRE(num_points == 0 || (r_k != nullptr && r_kp1 != nullptr && z_k != nullptr));
     return launch_reduce(FlexOp{r_k, r_kp1, z_k}, out, ws, num_points, al2(r_k, r_kp1) && fdd_aligned16(z_k), stream);
+}
+
+int fdd_dom_inner_product_flexible_gamma(double *out2, double *ws, const double *r_k, const double *r_kp1, const double *z_k, int num_points, void *stream)
+{
+    FDD_REQUIRE(out2 != nullptr && ws != nullptr && num_points >= 0);
+    FDD_REQUIRE(num_points == 0 || (r_k != nullptr && r_kp1 != nullptr && z_k != nullptr));
+    return launch_reduce(FlexGammaOp{r_k, r_kp1, z_k}, out2, ws, num_points, al2(r_k, r_kp1) && fdd_aligned16(z_k), stream);
 }
 
 int fdd_sub_inner_product(double *out, double *ws, const double *u, const double *v, int num_values, void *stream)

@@ -285,6 +285,8 @@ class Domain
     bool assembled_outer = true; // flexible CG on node vectors (one value per assembled node) when the configuration allows it
     bool device_scalars = true;  // node-space flexible CG: alpha / beta read by the update kernels from device memory, residual norm fetched late
     bool lazy_steps = true;      // fcg_steps: K iterations with one host synchronisation at the end
+    bool early_gamma = true;      // device scalars: the flexible dot also forms the next iteration's gamma = <z, r+> (same bits; the projection kernel is left with <p, q>)
+    bool gamma_on_device = false;
     bool unit_stitch_in_place = true; // stitching weights of the dof slice all exactly 1 (one rank): the inner solve writes z~ in place (0: the multiplication by the ones, the reference's sequence)
     bool mfma_stiffness = true; // N >= 11: stiffness on the fp64 matrix cores (not bit-identical; 1e-12 tolerance)
     DType tolerance = 1.0e-07;
@@ -1000,6 +1002,7 @@ class Domain
 
         precondition_nodes(nz, nr, subdomain);
         np.copyFrom(nz, (size_t)num_local_nodes * sizeof(DType));
+        gamma_on_device = false; // the first iteration's projection kernel forms gamma itself
     }
 
     DType fcg_nodes_step_residual()
@@ -1013,11 +1016,21 @@ class Domain
         gather_nodes(nq, q_k);
         timer.stop("domain.operator_application");
 
-        FDD_CALL(fdd_dom_projection_inner_products(scalars.as<double>(), reduce_ws.as<double>(), nz.as<double>(), nr.as<double>(), np.as<double>(), nq.as<double>(), nn, stream));
+        if (device_scalars and gamma_on_device and early_gamma)
+        {
+            // gamma = <z, r> already sits in scalars[0]: the flexible dot of the previous iteration formed it from the
+            // vectors it was reading anyway (fcg_nodes_step_direction); <p, q> is what is left of domain.okl:140-184
+            FDD_CALL(fdd_sub_inner_product(scalars.as<double>() + 1, reduce_ws.as<double>(), np.as<double>(), nq.as<double>(), nn, stream));
+            if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>() + 1, 1);
+        }
+        else
+        {
+            FDD_CALL(fdd_dom_projection_inner_products(scalars.as<double>(), reduce_ws.as<double>(), nz.as<double>(), nr.as<double>(), np.as<double>(), nq.as<double>(), nn, stream));
+            if (device_scalars and fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>(), 2);
+        }
         if (device_scalars)
         {
             // gamma = scalars[0] (kept for beta), theta = scalars[1]: alpha never visits the host
-            if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>(), 2);
             FDD_CALL(fdd_dom_solution_and_residual_update_dev(nu.as<double>(), nr1.as<double>(), nr.as<double>(), np.as<double>(), nq.as<double>(), scalars.as<double>(), scalars.as<double>() + 1, nn, stream));
             if (use_preconditioner and composite_precond) // r+ = r - alpha q on the points too (domain.okl:191), alpha from device memory
                 FDD_CALL(fdd_xmay_ratio_dev(rp.as<double>(), rp.as<double>(), scalars.as<double>(), scalars.as<double>() + 1, q_k.as<double>(), num_local_points, stream));
@@ -1058,15 +1071,27 @@ class Domain
         {
             // beta = scalars[3] / scalars[0] (theta / gamma), read by the update kernel; the residual norm's two
             // parts sit right behind it (scalars[4..5]) and are summed over the ranks in the same collective
-            FDD_CALL(fdd_dom_inner_product_flexible(scalars.as<double>() + 3, reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
-            if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>() + 3, norm_reduce_pending ? 3 : 1);
+            if (early_gamma)
+            {
+                // scalars[2..3] = {<z, r+> (the next iteration's gamma), theta}: one pass over r, r+, z
+                FDD_CALL(fdd_dom_inner_product_flexible_gamma(scalars.as<double>() + 2, reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
+                if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>() + 2, norm_reduce_pending ? 4 : 2);
+            }
+            else
+            {
+                FDD_CALL(fdd_dom_inner_product_flexible(scalars.as<double>() + 3, reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
+                if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>() + 3, norm_reduce_pending ? 3 : 1);
+            }
             norm_reduce_pending = false;
             // p = z + beta p; "r = r+" (domain.okl:226-233) is a swap of the two node vectors, not a copy
             FDD_CALL(fdd_xpby_ratio_dev(np.as<double>(), nz.as<double>(), scalars.as<double>() + 3, scalars.as<double>(), np.as<double>(), nn, fdd::dev().stream));
+            if (early_gamma) FDD_CALL(fdd_memcpy_d2d(scalars.as<double>(), scalars.as<double>() + 2, sizeof(double), fdd::dev().stream)); // gamma <- gamma_next (after beta has read the old one)
+            gamma_on_device = early_gamma;
             std::swap(nr, nr1);
         }
         else
         {
+            gamma_on_device = false;
             FDD_CALL(fdd_dom_inner_product_flexible(scalars.as<double>(), reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
             fetch_scalars(&theta_k, 1);
             const DType beta_k = theta_k / fcg_gamma_k;

@@ -858,6 +858,10 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
         {
             for (auto &kv : p->domains) kv.second.assembled_outer = value != 0;
         }
+        else if (s == "early_gamma")
+        {
+            for (auto &kv : p->domains) kv.second.early_gamma = value != 0;
+        }
         else if (s == "unit_stitch_in_place")
         {
             for (auto &kv : p->domains) kv.second.unit_stitch_in_place = value != 0;

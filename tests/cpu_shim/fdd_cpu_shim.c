@@ -950,3 +950,13 @@ int fdd_stiffness_matrix_mfma_affine(double *Au, const double *v, const double *
 {
     return fdd_stiffness_matrix_affine(Au, v, vscale, pd, D, c, w, eo, ne, N, s);
 }
+
+int fdd_dom_inner_product_flexible_gamma(double *out2, double *ws, const double *r, const double *r1, const double *z, int n, void *s)
+{
+    /* {gamma_next, theta}: the flexible sum as above; gamma_next = <z, r+> is the first sum of the projection kernel */
+    double two[2];
+    int rc = fdd_dom_projection_inner_products(two, ws, z, r1, z, r1, n, s);
+    if (rc) return rc;
+    out2[0] = two[0];
+    return fdd_dom_inner_product_flexible(out2 + 1, ws, r, r1, z, n, s);
+}

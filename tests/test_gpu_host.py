@@ -599,7 +599,7 @@ def test_affine_geometry_option(setup, tmp_path):
         p.close()
 
 
-def test_unit_stitch_in_place_is_bit_identical(setup):
+def test_unit_stitch_in_place_and_early_gamma_are_bit_identical(setup):
     """One rank: every stitching weight of the dof slice is multiplicity * (1 / multiplicity) = 1.0 exactly, so the
     inner solve writes its correction straight into the outer iteration's z~ instead of a vector that is then
     multiplied by ones ("unit_stitch_in_place", on by default).  Same bits as the reference's sequence, double and
@@ -615,6 +615,18 @@ def test_unit_stitch_in_place_is_bit_identical(setup):
             u0, its0, h0 = p.solve(f, "fcg")
             assert its1 == its0 and np.array_equal(u1, u0) and np.array_equal(h1, h0), precision
         p.set_flag("preconditioner_precision", 64)
+        # the same for "early_gamma": the flexible dot also forms the next iteration's <z, r+> from the vectors it reads anyway
+        # (the projection kernel is left with <p, q>): same sums in the same order
+        p.set_flag("unit_stitch_in_place", 1)
+        for lazy in (1, 0):
+            p.set_flag("lazy_steps", lazy)
+            p.set_flag("early_gamma", 1)
+            u1, its1, h1 = p.solve(f, "fcg")
+            p.set_flag("early_gamma", 0)
+            u0, its0, h0 = p.solve(f, "fcg")
+            assert its1 == its0 and np.array_equal(u1, u0) and np.array_equal(h1, h0), lazy
+        p.set_flag("lazy_steps", 1)
+        p.set_flag("early_gamma", 1)
         p.set_flag("sub_use_preconditioner", 1)
         assert p.amg_build(coarsest_size=40) >= 2
         p.set_flag("unit_stitch_in_place", 1)

@@ -1576,3 +1576,18 @@ def test_stiffness_mfma_affine(gpu, N):
         k("fdd_stiffness_matrix_mfma_gather", ref2, dev(v, gpu), sc, dev(pd, gpu), dD, dG, dev(eo, gpu), E, N)
         k("fdd_stiffness_matrix_mfma_affine", out2, dev(v, gpu), sc, dev(pd, gpu), dD, dev(c[::-1].ravel(), gpu), dw, dev(eo, gpu), E, N)
         assert np.array_equal(host(out2), host(ref2)), (N, E, "gather")
+
+
+@pytest.mark.parametrize("n", [1, 7, 4097, 1_000_001])
+def test_flexible_dot_with_the_next_gamma(gpu, n):
+    """fdd_dom_inner_product_flexible_gamma = {<z, r+>, <r+ - r, z>} from one pass over the three vectors: the same bits
+    as the flexible dot and as the first sum of the projection kernel on (z, r+)."""
+    ws = reduce_workspace(gpu)
+    r, r1, z = dev(rnd(n, 1), gpu), dev(rnd(n, 2), gpu), dev(rnd(n, 3), gpu)
+    out2 = torch.zeros(2, dtype=torch.float64, device=gpu)
+    flex = torch.zeros(1, dtype=torch.float64, device=gpu)
+    proj = torch.zeros(2, dtype=torch.float64, device=gpu)
+    k("fdd_dom_inner_product_flexible_gamma", out2, ws, r, r1, z, n)
+    k("fdd_dom_inner_product_flexible", flex, ws, r, r1, z, n)
+    k("fdd_dom_projection_inner_products", proj, ws, z, r1, z, r1, n)
+    assert host(out2)[1] == host(flex)[0] and host(out2)[0] == host(proj)[0]
