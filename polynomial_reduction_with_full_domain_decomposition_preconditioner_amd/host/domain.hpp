@@ -287,6 +287,7 @@ class Domain
     bool lazy_steps = true;      // fcg_steps: K iterations with one host synchronisation at the end
     bool early_gamma = true;      // device scalars: the flexible dot also forms the next iteration's gamma = <z, r+> (same bits; the projection kernel is left with <p, q>)
     bool gamma_on_device = false;
+    int gamma_slot = 0; // where the current gamma sits in `scalars`
     bool unit_stitch_in_place = true; // stitching weights of the dof slice all exactly 1 (one rank): the inner solve writes z~ in place (0: the multiplication by the ones, the reference's sequence)
     bool mfma_stiffness = true; // N >= 11: stiffness on the fp64 matrix cores (not bit-identical; 1e-12 tolerance)
     DType tolerance = 1.0e-07;
@@ -1030,10 +1031,11 @@ class Domain
         }
         if (device_scalars)
         {
-            // gamma = scalars[0] (kept for beta), theta = scalars[1]: alpha never visits the host
-            FDD_CALL(fdd_dom_solution_and_residual_update_dev(nu.as<double>(), nr1.as<double>(), nr.as<double>(), np.as<double>(), nq.as<double>(), scalars.as<double>(), scalars.as<double>() + 1, nn, stream));
+            // gamma = scalars[gamma_slot] (kept for beta), theta = scalars[1]: alpha never visits the host
+            if (not(gamma_on_device and early_gamma)) gamma_slot = 0; // the projection kernel has just written it
+            FDD_CALL(fdd_dom_solution_and_residual_update_dev(nu.as<double>(), nr1.as<double>(), nr.as<double>(), np.as<double>(), nq.as<double>(), scalars.as<double>() + gamma_slot, scalars.as<double>() + 1, nn, stream));
             if (use_preconditioner and composite_precond) // r+ = r - alpha q on the points too (domain.okl:191), alpha from device memory
-                FDD_CALL(fdd_xmay_ratio_dev(rp.as<double>(), rp.as<double>(), scalars.as<double>(), scalars.as<double>() + 1, q_k.as<double>(), num_local_points, stream));
+                FDD_CALL(fdd_xmay_ratio_dev(rp.as<double>(), rp.as<double>(), scalars.as<double>() + gamma_slot, scalars.as<double>() + 1, q_k.as<double>(), num_local_points, stream));
             node_norm_enqueue(nr1, /*defer_exchange=*/true); // finished inside the preconditioner's exchange
             fcg_norm_pending = true;
             return std::numeric_limits<DType>::quiet_NaN(); // fcg_nodes_norm() has the value
@@ -1071,21 +1073,34 @@ class Domain
         {
             // beta = scalars[3] / scalars[0] (theta / gamma), read by the update kernel; the residual norm's two
             // parts sit right behind it (scalars[4..5]) and are summed over the ranks in the same collective
+            int theta_at = 3;
             if (early_gamma)
             {
-                // scalars[2..3] = {<z, r+> (the next iteration's gamma), theta}: one pass over r, r+, z
-                FDD_CALL(fdd_dom_inner_product_flexible_gamma(scalars.as<double>() + 2, reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
-                if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>() + 2, norm_reduce_pending ? 4 : 2);
+                // {<z, r+> (the next iteration's gamma), theta} from one pass over r, r+, z.  The pair alternates between
+                // scalars[2..3] and scalars[6..7] (the current gamma must outlive it: beta reads it below), either side of
+                // the norm's two parts in scalars[4..5], so that one all-reduce still carries all four
+                const int next = (gamma_slot == 2) ? 6 : 2;
+                theta_at = next + 1;
+                FDD_CALL(fdd_dom_inner_product_flexible_gamma(scalars.as<double>() + next, reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
+                if (fdd::comm().size > 1)
+                {
+                    if (norm_reduce_pending)
+                        fdd::comm().allreduce_sum(scalars.as<double>() + (next == 2 ? 2 : 4), 4);
+                    else
+                        fdd::comm().allreduce_sum(scalars.as<double>() + next, 2);
+                }
+                norm_reduce_pending = false;
+                // p = z + beta p; "r = r+" (domain.okl:226-233) is a swap of the two node vectors, not a copy
+                FDD_CALL(fdd_xpby_ratio_dev(np.as<double>(), nz.as<double>(), scalars.as<double>() + theta_at, scalars.as<double>() + gamma_slot, np.as<double>(), nn, fdd::dev().stream));
+                gamma_slot = next;
             }
             else
             {
                 FDD_CALL(fdd_dom_inner_product_flexible(scalars.as<double>() + 3, reduce_ws.as<double>(), nr.as<double>(), nr1.as<double>(), nz.as<double>(), nn, fdd::dev().stream));
                 if (fdd::comm().size > 1) fdd::comm().allreduce_sum(scalars.as<double>() + 3, norm_reduce_pending ? 3 : 1);
+                norm_reduce_pending = false;
+                FDD_CALL(fdd_xpby_ratio_dev(np.as<double>(), nz.as<double>(), scalars.as<double>() + 3, scalars.as<double>() + gamma_slot, np.as<double>(), nn, fdd::dev().stream));
             }
-            norm_reduce_pending = false;
-            // p = z + beta p; "r = r+" (domain.okl:226-233) is a swap of the two node vectors, not a copy
-            FDD_CALL(fdd_xpby_ratio_dev(np.as<double>(), nz.as<double>(), scalars.as<double>() + 3, scalars.as<double>(), np.as<double>(), nn, fdd::dev().stream));
-            if (early_gamma) FDD_CALL(fdd_memcpy_d2d(scalars.as<double>(), scalars.as<double>() + 2, sizeof(double), fdd::dev().stream)); // gamma <- gamma_next (after beta has read the old one)
             gamma_on_device = early_gamma;
             std::swap(nr, nr1);
         }
