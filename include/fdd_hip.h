@@ -285,7 +285,7 @@ int fdd_gmres_last_column(void *state, const double **j_last_dev); /* device add
 int fdd_sub_stiffness_matrix_gather_scaled(double *Au, const double *v, const double *v_scale_dev, const int *point_dof, const double *D_hat, const double *const G[FDD_NUM_GEOM_FACTS], const int *elem_offset, int num_elements, int poly_degree, void *stream);
 /* in the multi-vector reductions below w == NULL means unit weights: nothing is read, and x * 1.0 is x bit for bit */
 int fdd_multi_weighted_inner_product_scaled(double *out, double *ws, const double *a, const double *const *b, const double *b_scale_dev, int m, const double *w, int n, void *stream);
-int fdd_multi_axpy_norm2_scaled_dev(double *out, double *ws, double *dst, const double *y, const double *coeffs_dev, double sign, const double *const *x, const double *x_scale_dev, int m, const double *w, int n, void *stream);
+int fdd_multi_axpy_norm2_scaled_dev(double *out, double *ws, double *dst, const double *y, const double *coeffs_dev, double sign, const double *const *x, const double *x_scale_dev, int m, const double *w, int n, void *stream); /* dst == NULL (also in the _f32 form): the updated vector is not stored, only its norm is formed -- the last Arnoldi step of a cycle, whose basis vector nobody reads */
 int fdd_multi_axpy_scaled_dev(double *q, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream);
 int fdd_vector_scaling_dev(double *au, const double *scale_dev, const double *u, int n, void *stream); /* au = (*scale_dev) * u */
 int fdd_multi_lincomb_scaled_dev(double *q, int q_is_zero, const double *coeffs_dev, const double *const *v, const double *v_scale_dev, int m, int n, void *stream); /* fdd_multi_axpy_scaled_dev; q_is_zero: q is taken to be 0 and is not read (it need not have been cleared) */

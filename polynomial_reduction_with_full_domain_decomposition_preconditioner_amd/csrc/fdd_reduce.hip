@@ -345,7 +345,7 @@ struct MultiAxpyNormOp
             yy.x = 1.0 * yy.x + ck * b.x;
             yy.y = 1.0 * yy.y + ck * b.y;
         }
-        reinterpret_cast<double2 *>(dst)[i] = yy;
+        if (dst) reinterpret_cast<double2 *>(dst)[i] = yy; // dst == NULL: only the norm is wanted (the last Arnoldi step of a cycle)
         acc.v[0] += yy.x * yy.x * ww.x;
         acc.v[0] += yy.y * yy.y * ww.y;
     }
@@ -354,7 +354,7 @@ struct MultiAxpyNormOp
         double v = y[i];
 #pragma unroll
         for (int k = 0; k < M; k++) v = 1.0 * v + (sign * c[k]) * (xs ? xs[k] * x[k][i] : x[k][i]);
-        dst[i] = v;
+        if (dst) dst[i] = v;
         acc.v[0] += v * v * (w ? w[i] : 1.0);
     }
 };
@@ -483,7 +483,7 @@ struct MultiAxpyNormOpF
             v1 += ck * (double)b.y;
         }
         const float2 r = make_float2((float)v0, (float)v1);
-        reinterpret_cast<float2 *>(dst)[i] = r;
+        if (dst) reinterpret_cast<float2 *>(dst)[i] = r;
         acc.v[0] += (double)r.x * (double)r.x;
         acc.v[0] += (double)r.y * (double)r.y;
     }
@@ -493,7 +493,7 @@ struct MultiAxpyNormOpF
 #pragma unroll
         for (int k = 0; k < M; k++) v += sign * c[k] * (xs ? xs[k] : 1.0) * (double)x[k][i];
         const float r = (float)v;
-        dst[i] = r;
+        if (dst) dst[i] = r;
         acc.v[0] += (double)r * (double)r;
     }
 };
@@ -622,9 +622,8 @@ int fdd_multi_axpy_norm2_dev(double *out, double *ws, double *y, const double *c
 
 int fdd_multi_axpy_norm2_scaled_dev(double *out, double *ws, double *dst, const double *y, const double *coeffs_dev, double sign, const double *const *x, const double *x_scale_dev, int m, const double *w, int n, void *stream)
 {
-    FDD_REQUIRE(n == 0 || dst != nullptr);
     FDD_REQUIRE(out != nullptr && ws != nullptr && n >= 0 && m >= 1 && m <= FDD_MULTI_MAX && x != nullptr && coeffs_dev != nullptr);
-    FDD_REQUIRE(n == 0 || y != nullptr); // w == NULL: unit weights
+    FDD_REQUIRE(n == 0 || y != nullptr); // w == NULL: unit weights; dst == NULL: the updated vector is not stored, only its norm formed
     for (int k = 0; k < m; k++) FDD_REQUIRE(n == 0 || x[k] != nullptr);
     switch (m)
     {
@@ -679,7 +678,7 @@ int fdd_multi_inner_product_scaled_f32(double *out, double *ws, const float *a, 
 int fdd_multi_axpy_norm2_scaled_dev_f32(double *out, double *ws, float *dst, const float *y, const double *coeffs_dev, double sign, const float *const *x, const double *x_scale_dev, int m, int n, void *stream)
 {
     FDD_REQUIRE(out != nullptr && ws != nullptr && m >= 1 && n >= 0);
-    FDD_REQUIRE(n == 0 || (dst != nullptr && y != nullptr && x != nullptr && coeffs_dev != nullptr));
+    FDD_REQUIRE(n == 0 || (y != nullptr && x != nullptr && coeffs_dev != nullptr)); // dst == NULL: norm only
 #define FDD_CALL_AN(M_) launch_multi_axpy_norm_f32<M_>(out, ws, dst, y, coeffs_dev, sign, x, x_scale_dev, n, stream)
     FDD_M_SWITCH(FDD_CALL_AN)
 #undef FDD_CALL_AN

@@ -1097,7 +1097,7 @@ class Subdomain
                 dot(slot, sp.qa, W.data(), inv_dev, j + 1);
                 {
                     fdd::ProfileScope prof("reduce_vec2_kernel<MultiAxpyNormF32>", 4.0 * nd * (j + 3));
-                    FDD_CALL(fdd_multi_axpy_norm2_scaled_dev_f32(slot + (j + 1), ws, sp.VA[j + 1].template as<float>(), sp.qa.template as<float>(), slot, -1.0, W.data(), inv_dev, j + 1, nd, stream));
+                    FDD_CALL(fdd_multi_axpy_norm2_scaled_dev_f32(slot + (j + 1), ws, (j + 1 < m or not skip_last_basis_store) ? sp.VA[j + 1].template as<float>() : nullptr, sp.qa.template as<float>(), slot, -1.0, W.data(), inv_dev, j + 1, nd, stream)); // the cycle's last basis vector is never read: only its norm is formed
                 }
                 Wm[j + 1] = &sp.VA[j + 1];
                 W[j + 1] = sp.VA[j + 1].template as<float>();
@@ -1370,6 +1370,7 @@ class Subdomain
     bool restructured = true;             // inner GMRES with cached assembled basis, multi-dot / multi-axpy
     bool assembled_inner = true;          // inner GMRES on vectors over the dofs: Q fused into the stiffness load, no point-space Krylov basis
     bool device_bookkeeping = true;       // assembled inner GMRES: Givens / stopping tests in one-thread kernels, one host sync per cycle
+    bool skip_last_basis_store = true;    // device GMRES: the last Arnoldi step of a cycle forms the norm of its vector without storing it (nobody reads it)
     bool lazy_history = false;            // single-cycle inner solves do not synchronise at all; finish_history() fetches on demand
     bool history_pending = false;
 
@@ -2444,7 +2445,7 @@ class Subdomain
                 dot_dofs(slot, qa, W.data(), inv_dev, j + 1);
                 {
                     fdd::ProfileScope prof("reduce_vec2_kernel<MultiAxpyNorm>", 8.0 * nd * (j + 3 + (nw ? 1 : 0)));
-                    FDD_CALL(fdd_multi_axpy_norm2_scaled_dev(slot + (j + 1), ws, VA[j + 1].template as<double>(), qa.as<double>(), slot, -1.0, W.data(), inv_dev, j + 1, nw, nd, stream));
+                    FDD_CALL(fdd_multi_axpy_norm2_scaled_dev(slot + (j + 1), ws, (j + 1 < m or not skip_last_basis_store) ? VA[j + 1].template as<double>() : nullptr, qa.as<double>(), slot, -1.0, W.data(), inv_dev, j + 1, nw, nd, stream)); // the cycle's last basis vector is never read: only its norm is formed
                 }
                 Wm[j + 1] = &VA[j + 1];
                 W[j + 1] = VA[j + 1].template as<double>();

@@ -521,6 +521,13 @@ int fdd_multi_weighted_inner_product_scaled(double *out, double *ws, const doubl
 
 int fdd_multi_axpy_norm2_scaled_dev(double *out, double *ws, double *dst, const double *y, const double *c, double sign, const double *const *x, const double *xs, int m, const double *w, int n, void *s)
 {
+    if (!dst) /* norm only: the updated vector goes nowhere */
+    {
+        double *t = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+        int rc = fdd_multi_axpy_norm2_scaled_dev(out, ws, t, y, c, sign, x, xs, m, w, n, s);
+        free(t);
+        return rc;
+    }
     if (dst != y) memmove(dst, y, sizeof(double) * (size_t)n);
     if (!xs) return fdd_multi_axpy_norm2_dev(out, ws, dst, c, sign, x, m, w, n, s);
     double **t = shim_scaled(x, xs, m, n);
@@ -814,8 +821,9 @@ int fdd_multi_axpy_norm2_scaled_dev_f32(double *out, double *ws, float *dst, con
     {
         double v = y[i];
         for (int k = 0; k < m; k++) v += sign * c[k] * (xs ? xs[k] : 1.0) * (double)x[k][i];
-        dst[i] = (float)v;
-        acc += (double)dst[i] * (double)dst[i];
+        const float r = (float)v;
+        if (dst) dst[i] = r; /* NULL: norm only */
+        acc += (double)r * (double)r;
     }
     out[0] = acc;
     return 0;

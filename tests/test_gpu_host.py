@@ -627,6 +627,18 @@ def test_unit_stitch_in_place_and_early_gamma_are_bit_identical(setup):
             assert its1 == its0 and np.array_equal(u1, u0) and np.array_equal(h1, h0), lazy
         p.set_flag("lazy_steps", 1)
         p.set_flag("early_gamma", 1)
+        # and for "skip_last_basis_store": the last Arnoldi step of an inner cycle forms its vector's norm without storing it
+        for precision in (64, 32):
+            p.set_flag("preconditioner_precision", precision)
+            p.set_flag("skip_last_basis_store", 1)
+            u1, its1, h1 = p.solve(f, "fcg")
+            z1, zh1 = p.precond_apply(f, "gmres")
+            p.set_flag("skip_last_basis_store", 0)
+            u0, its0, h0 = p.solve(f, "fcg")
+            z0, zh0 = p.precond_apply(f, "gmres")
+            assert its1 == its0 and np.array_equal(u1, u0) and np.array_equal(h1, h0) and np.array_equal(z1, z0) and np.array_equal(zh1, zh0), precision
+        p.set_flag("preconditioner_precision", 64)
+        p.set_flag("skip_last_basis_store", 1)
         p.set_flag("sub_use_preconditioner", 1)
         assert p.amg_build(coarsest_size=40) >= 2
         p.set_flag("unit_stitch_in_place", 1)
