@@ -473,6 +473,19 @@ for key, method, inner in (("fcg+gmres", "fcg", 1), ("gmres+fcg", "gmres", 0)):
     g = gold["solves"][key]
     assert its == g["iterations"], (key, its, g["iterations"])
     assert np.abs(hist - np.array(g["history"])).max() <= 1e-9 * g["history"][0], key
+# launch-sequence switches that leave every bit alone (DESIGN 4.3), one at a time against all on; and the affine option
+p.set_options(preconditioner_type=1)
+base = p.solve(f, "fcg")
+for flag in ("unit_stitch_in_place", "early_gamma", "skip_last_basis_store"):
+    p.set_flag(flag, 0)
+    u, its, hist = p.solve(f, "fcg")
+    assert its == base[1] and np.array_equal(u, base[0]) and np.array_equal(hist, base[2]), flag
+    p.set_flag(flag, 1)
+p.set_flag("affine_geometry", 1)
+info = p.affine_info()
+assert info["fine_domain"] and info["sub_lists_affine"] == info["sub_lists"] == 1, info
+u, its, hist = p.solve(f, "fcg")
+assert its == base[1] and np.abs(u - base[0]).max() <= 1e-12 * np.abs(base[0]).max()
 print("ok")
 """ % (S.ROOT, S.HERE, HOST_CPU_SO)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
