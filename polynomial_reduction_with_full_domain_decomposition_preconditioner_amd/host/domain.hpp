@@ -59,6 +59,8 @@ struct NoPreconditioner
     double comm_coarse_bytes() const { return 0.0; }
     double comm_ring_bytes() const { return 0.0; }
     void gmres_composite_dofs(fdd::memory &, fdd::memory &, bool = true, bool = false, const double * = nullptr) {}
+    const double *known_rhs_norm2_dev = nullptr;
+    bool unit_norm_weight() const { return false; }
 };
 
 template <typename DType>
@@ -119,7 +121,9 @@ class Domain
     fdd::memory point_node_dev;           // int[num_local_points]: Q as an index array
     fdd::memory node_mask;                // Dirichlet mask per node
     fdd::memory node_stitch;              // local multiplicity * assembled weight * mask
-    std::vector<DType> node_stitch_hst;
+    std::vector<DType> node_stitch_hst, node_mask_hst;
+    bool norm_on_dof_slice = false;       // one rank, mask = indicator of the dof slice: the masked node norm is the slice's plain norm
+    const void *norm_shared_from = nullptr;
     bool stitch_is_one = false;           // every weight of the dof slice is exactly 1.0 (setup_dof_maps)
     fdd::memory node_of_dof, dof_of_node; // renumbering to / from the subdomain's dofs
     int nodes_sub_dofs = -1;
@@ -285,6 +289,7 @@ class Domain
     bool assembled_outer = true; // flexible CG on node vectors (one value per assembled node) when the configuration allows it
     bool device_scalars = true;  // node-space flexible CG: alpha / beta read by the update kernels from device memory, residual norm fetched late
     bool lazy_steps = true;      // fcg_steps: K iterations with one host synchronisation at the end
+    bool shared_residual_norm = true; // one rank: the outer residual norm and the inner solve's first norm are the same sum over the dof slice, formed once (the iterates keep their bits; the recorded norm groups its terms differently)
     bool early_gamma = true;      // device scalars: the flexible dot also forms the next iteration's gamma = <z, r+> (same bits; the projection kernel is left with <p, q>)
     bool gamma_on_device = false;
     int gamma_slot = 0; // where the current gamma sits in `scalars`
@@ -741,6 +746,7 @@ class Domain
         node_stitch = fdd::dev().malloc<DType>(std::max(nn, 1));
         node_stitch.copyFrom(stitch.data(), (size_t)nn * sizeof(DType));
         node_stitch_hst = stitch;
+        node_mask_hst = mask;
 
         for (fdd::memory *v : {&nu, &nr, &nr1, &nq, &nz, &np, &nt}) *v = fdd::dev().malloc<DType>(std::max(nn, 1));
         nodes_ready = true;
@@ -775,6 +781,9 @@ class Domain
         sub_u = subdomain.new_dof_vector(); // a composite keeps copies / hanging values behind its dofs
         if (composite_precond and not rp.ptr()) rp = subdomain.tree_points(); // lives in the Subdomain's tree vector: level 0 is read in place
         nodes_sub_dofs = nd;
+        norm_on_dof_slice = fdd::comm().size == 1 and dof_shift >= 0 and not composite_precond and subdomain.unit_norm_weight() and (int)node_mask_hst.size() == num_local_nodes;
+        for (int n = 0; n < num_local_nodes and norm_on_dof_slice; n++)
+            if (node_mask_hst[n] != ((n >= dof_shift and n < dof_shift + nd) ? (DType)1.0 : (DType)0.0)) norm_on_dof_slice = false;
         stitch_is_one = dof_shift >= 0 and not composite_precond and (int)node_stitch_hst.size() >= dof_shift + nd;
         for (int d = 0; d < nd and stitch_is_one; d++)
             if (node_stitch_hst[(size_t)dof_shift + d] != (DType)1.0) stitch_is_one = false;
@@ -875,9 +884,20 @@ class Domain
             node_norm_finish();
             return;
         }
+        else if (norm_on_dof_slice and shared_residual_norm)
+        {
+            // One rank, mask = 1 on the dof slice and 0 elsewhere: the masked sum over the nodes IS the plain sum over the
+            // slice -- the sum the inner solve forms first (its right-hand side is this slice, read in place).  Formed once,
+            // by the inner solve's own call, and handed to it (precondition_nodes): the iterates keep their bits, the
+            // recorded norm differs from the masked form in how its terms are grouped.
+            const double *self[1] = {rn.as<double>() + dof_shift};
+            FDD_CALL(fdd_multi_weighted_inner_product_scaled(out, reduce_ws.as<double>(), self[0], self, nullptr, 1, nullptr, nodes_sub_dofs, fdd::dev().stream));
+            norm_shared_from = rn.ptr();
+        }
         else
         {
             // sum r*r*mask with r read once (the arithmetic and the reduction tree of residual_norm_kernel, domain.okl:109-138)
+            norm_shared_from = nullptr;
             const double *self[1] = {rn.as<double>()};
             FDD_CALL(fdd_multi_weighted_inner_product(out, reduce_ws.as<double>(), rn.as<double>(), self, 1, node_mask.as<double>(), nn, fdd::dev().stream));
         }
@@ -933,6 +953,8 @@ class Domain
                 // every stitching weight of the slice is exactly 1 (one rank: multiplicity * 1/multiplicity), writes z~ in
                 // place as well: the multiplication below would be x * 1.0
                 fdd::memory f_slice = rn.slice(dof_shift, nodes_sub_dofs);
+                // the norm of this very slice was formed a moment ago (node_norm_enqueue): the inner solve starts from it
+                subdomain.known_rhs_norm2_dev = (norm_on_dof_slice and shared_residual_norm and norm_shared_from == rn.ptr()) ? scalars.as<double>() + 4 : nullptr;
                 if (stitch_is_one and unit_stitch_in_place)
                 {
                     fdd::memory z_slice = zn.slice(dof_shift, nodes_sub_dofs);
@@ -940,6 +962,8 @@ class Domain
                 }
                 else
                     subdomain.gmres_dofs(sub_u, f_slice);
+                subdomain.known_rhs_norm2_dev = nullptr;
+                norm_shared_from = nullptr;
             }
             else
             {

@@ -858,6 +858,10 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
         {
             for (auto &kv : p->domains) kv.second.assembled_outer = value != 0;
         }
+        else if (s == "shared_residual_norm")
+        {
+            for (auto &kv : p->domains) kv.second.shared_residual_norm = value != 0;
+        }
         else if (s == "skip_last_basis_store")
         {
             if (p->subdomain) p->subdomain->skip_last_basis_store = value != 0;

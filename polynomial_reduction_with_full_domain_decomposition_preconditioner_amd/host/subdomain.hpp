@@ -1370,6 +1370,8 @@ class Subdomain
     bool restructured = true;             // inner GMRES with cached assembled basis, multi-dot / multi-axpy
     bool assembled_inner = true;          // inner GMRES on vectors over the dofs: Q fused into the stiffness load, no point-space Krylov basis
     bool device_bookkeeping = true;       // assembled inner GMRES: Givens / stopping tests in one-thread kernels, one host sync per cycle
+    bool unit_norm_weight() const { return norm_weight_is_one; }
+    const double *known_rhs_norm2_dev = nullptr; // set by the caller around one solve: |f~|^2 over the dofs, already on the device (double-precision device GMRES only)
     bool skip_last_basis_store = true;    // device GMRES: the last Arnoldi step of a cycle forms the norm of its vector without storing it (nobody reads it)
     bool lazy_history = false;            // single-cycle inner solves do not synchronise at all; finish_history() fetches on demand
     bool history_pending = false;
@@ -2416,11 +2418,14 @@ class Subdomain
                 Wm[0] = &VA[0];
             }
             W[0] = Wm[0]->template as<double>();
+            if (first_cycle and known_rhs_norm2_dev and nw == nullptr)
+                FDD_CALL(fdd_gmres_begin_dev(st, known_rhs_norm2_dev, 1, stream)); // the caller has just formed |f~|^2 with this very call (Domain::node_norm_enqueue)
+            else
             {
                 const double *self[1] = {W[0]};
                 dot_dofs(sc, *Wm[0], self, nullptr, 1);
+                FDD_CALL(fdd_gmres_begin_dev(st, sc, first_cycle ? 1 : 0, stream));
             }
-            FDD_CALL(fdd_gmres_begin_dev(st, sc, first_cycle ? 1 : 0, stream));
 
             for (int j = 0; j < m; j++)
             {

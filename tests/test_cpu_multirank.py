@@ -481,6 +481,10 @@ for flag in ("unit_stitch_in_place", "early_gamma", "skip_last_basis_store"):
     u, its, hist = p.solve(f, "fcg")
     assert its == base[1] and np.array_equal(u, base[0]) and np.array_equal(hist, base[2]), flag
     p.set_flag(flag, 1)
+p.set_flag("shared_residual_norm", 0)  # the iterates keep their bits, the recorded norms group their terms differently
+u, its, hist = p.solve(f, "fcg")
+assert its == base[1] and np.array_equal(u, base[0]) and np.abs(hist - base[2]).max() <= 1e-13 * base[2][0]
+p.set_flag("shared_residual_norm", 1)
 p.set_flag("affine_geometry", 1)
 info = p.affine_info()
 assert info["fine_domain"] and info["sub_lists_affine"] == info["sub_lists"] == 1, info

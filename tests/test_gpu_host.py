@@ -639,6 +639,14 @@ def test_unit_stitch_in_place_and_early_gamma_are_bit_identical(setup):
             assert its1 == its0 and np.array_equal(u1, u0) and np.array_equal(h1, h0) and np.array_equal(z1, z0) and np.array_equal(zh1, zh0), precision
         p.set_flag("preconditioner_precision", 64)
         p.set_flag("skip_last_basis_store", 1)
+        # "shared_residual_norm": the outer residual norm and the inner solve's first norm are one sum over the dof slice,
+        # formed once.  The iterates keep their bits; the recorded norms group their terms differently (a few ulp).
+        p.set_flag("shared_residual_norm", 1)
+        u1, its1, h1 = p.solve(f, "fcg")
+        p.set_flag("shared_residual_norm", 0)
+        u0, its0, h0 = p.solve(f, "fcg")
+        assert its1 == its0 and np.array_equal(u1, u0) and np.abs(h1 - h0).max() <= 1e-13 * h0[0]
+        p.set_flag("shared_residual_norm", 1)
         p.set_flag("sub_use_preconditioner", 1)
         assert p.amg_build(coarsest_size=40) >= 2
         p.set_flag("unit_stitch_in_place", 1)
