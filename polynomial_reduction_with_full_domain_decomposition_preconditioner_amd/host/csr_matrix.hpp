@@ -34,6 +34,7 @@ class CSR_Matrix
     std::vector<std::tuple<int, int, DType>> entries;
     fdd_csr_plan *plan = nullptr;
     int plan_kind = 0;
+    bool lazy_identity = false; // initialize_identity(): the arrays do not exist yet
 
     void initialization_check()
     {
@@ -74,6 +75,37 @@ class CSR_Matrix
     }
 
     void reserve(size_t n) { entries.reserve(n); }
+
+    // The n x n identity (what add_entry(i, i, 1.0) for every i and assemble() give), WITHOUT its arrays: the fused launch
+    // sequences look at `is_identity` and never multiply by it, and at C3's size three such matrices are 5 GB of device
+    // memory and seconds of setup.  The first call that needs the arrays builds them (materialize()).
+    void initialize_identity(int n)
+    {
+        initialize(n, n);
+        num_nnz = n;
+        unit_values = true;
+        is_identity = true;
+        lazy_identity = n > 0;
+    }
+    void materialize()
+    {
+        if (not lazy_identity) return;
+        lazy_identity = false;
+        const int n = num_rows;
+        std::vector<int> p((size_t)n + 1);
+        fdd::low_order::pod_vector<int> c((size_t)n);
+        fdd::low_order::pod_vector<DType> v((size_t)n);
+        fdd::low_order::parallel_ranges(n, fdd::low_order::range_parts(n), [&](long long i0, long long i1, int) {
+            for (long long i = i0; i < i1; i++)
+            {
+                p[i] = (int)i;
+                c[i] = (int)i;
+                v[i] = (DType)1.0;
+            }
+        });
+        p[n] = n;
+        adopt_csr(n, n, std::move(p), std::move(c), std::move(v));
+    }
 
     // val + col per non-zero, ptr + y per row, x once
     double algorithmic_bytes(bool weighted) const { return 12.0 * num_nnz + 12.0 * num_rows + 8.0 * num_cols + (weighted ? 8.0 * num_rows : 0.0); }
@@ -158,6 +190,7 @@ class CSR_Matrix
     // y = alpha*A*x + beta*y (AMG::CSR_Matrix::matvec, AMG/csr_matrix.cpp:129-131); beta == 0 never reads y
     void matvec(fdd::memory &y, fdd::memory &x, double alpha, double beta)
     {
+        materialize();
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
         fdd::ProfileScope prof(sell ? "sell_kernel<EpiAxpby>" : plan_kind == 0 ? "csr_row_kernel<EpiAxpby>" : "csr_block_kernel<EpiAxpby>", algorithmic_bytes(beta != 0.0));
@@ -167,6 +200,7 @@ class CSR_Matrix
     // y = alpha*A*x + beta*y_in: the copy "y = y_in" that precedes the SpMV in the reference (subdomain.tpp:34-36) folded in
     void matvec_to(fdd::memory &y, fdd::memory &y_in, fdd::memory &x, double alpha, double beta)
     {
+        materialize();
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
         fdd::ProfileScope prof(sell ? "sell_kernel<EpiAxpby>" : plan_kind == 0 ? "csr_row_kernel<EpiAxpby>" : "csr_block_kernel<EpiAxpby>", algorithmic_bytes(beta != 0.0));
@@ -257,6 +291,7 @@ class CSR_Matrix
     // ... and fetch them back from the device copies when a later setup step wants to walk the matrix again
     void download_host()
     {
+        materialize();
         if (num_nnz == 0 or not ptr.ptr()) return;
         ptr_hst.resize(num_rows + 1);
         col_hst.resize(num_nnz);
@@ -278,6 +313,7 @@ class CSR_Matrix
 
     void transpose(CSR_Matrix &At)
     {
+        materialize();
         At.initialize(num_cols, num_rows);
         if ((num_rows == 0) or (num_cols == 0)) return;
         // What add_entry + assemble (csr_matrix.tpp:288-300) produces, by a counting transpose instead of a sort of
@@ -317,6 +353,7 @@ class CSR_Matrix
 
     void diagonal(fdd::memory D)
     {
+        materialize();
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
         std::vector<DType> work(num_rows, 0.0);
@@ -362,6 +399,7 @@ class CSR_Matrix
 
     void multiply(fdd::memory &Au, fdd::memory &u)
     {
+        materialize();
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
         if (num_nnz == 0) // never assembled (csr_matrix.tpp:96 leaves no device arrays): A = 0
@@ -375,6 +413,7 @@ class CSR_Matrix
 
     void multiply_range(fdd::memory &Au, fdd::memory &u, int row_start, int row_end)
     {
+        materialize();
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
         if (row_end < row_start)
@@ -388,6 +427,7 @@ class CSR_Matrix
 
     void multiply_weight(fdd::memory &Au, fdd::memory &u, fdd::memory &weight)
     {
+        materialize();
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
         if (num_nnz == 0)

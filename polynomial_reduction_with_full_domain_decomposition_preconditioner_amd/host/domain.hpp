@@ -471,11 +471,7 @@ class Domain
         // the straightforward form were 40 of the 50 s of setup at N = 15).
         std::vector<int> tid(num_local_points);
         int num_tmp = 0;
-        {
-            fdd::KeySlots first((size_t)num_local_points);
-            for (int p = 0; p < num_local_points; p++) tid[p] = first.find_or_insert(mesh.glo_num[p]);
-            num_tmp = first.size();
-        }
+        num_tmp = fdd::first_appearance_ids(mesh.glo_num.data(), (size_t)num_local_points, tid);
         timing.lap("temporary node ids");
         std::vector<int> local_node_degree(num_tmp, 0);
         for (int p = 0; p < num_local_points; p++) local_node_degree[tid[p]]++;

@@ -63,10 +63,30 @@ class KeySlots
             if (table_key[h] == key) return table_slot[h];
             h = (h + 1) & mask;
         }
+        if (3 * (keys.size() + 1) > 2 * table_key.size())
+        {
+            grow();
+            return find_or_insert(key);
+        }
         table_key[h] = key;
         table_slot[h] = (int)keys.size();
         keys.push_back(key);
         return table_slot[h];
+    }
+    // more keys than announced: twice the table, every key back in (their slots stay)
+    void grow()
+    {
+        const size_t cap = 2 * table_key.size();
+        table_key.assign(cap, LLONG_MIN);
+        table_slot.assign(cap, -1);
+        mask = cap - 1;
+        for (size_t s = 0; s < keys.size(); s++)
+        {
+            size_t h = (size_t)(((unsigned long long)keys[s] * 0x9E3779B97F4A7C15ull) >> 17) & mask;
+            while (table_key[h] != LLONG_MIN) h = (h + 1) & mask;
+            table_key[h] = keys[s];
+            table_slot[h] = (int)s;
+        }
     }
     long long key_of_slot(int slot) const { return keys[slot]; }
     int size() const { return (int)keys.size(); }
@@ -156,6 +176,60 @@ inline void concatenate(Out &out, std::vector<Piece> &pieces)
 }
 
 } // namespace low_order
+
+// ids[p] = the rank of keys[p] among the DISTINCT keys in order of first appearance (0, 1, 2, ...); returns their number.
+// What one pass with a KeySlots gives, on the host threads: thread t owns the keys whose hash falls in its share, finds
+// for each the first point that carries it (scanning the points in order), a prefix sum over the points that ARE such
+// first carriers numbers them, and every point takes the number of its key's first carrier.
+inline int first_appearance_ids(const long long *keys, size_t n, std::vector<int> &ids)
+{
+    ids.resize(n);
+    const int T = low_order::range_parts((long long)n);
+    if (T <= 1)
+    {
+        KeySlots first(n);
+        for (size_t p = 0; p < n; p++) ids[p] = first.find_or_insert(keys[p]);
+        return first.size();
+    }
+    std::vector<int> rep(n); // the first point with the same key
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; t++)
+            pool.emplace_back([&, t] {
+                KeySlots mine(n / (size_t)T + n / (size_t)(4 * T) + 16);
+                std::vector<int> first_point;
+                first_point.reserve(n / (size_t)T + 16);
+                for (size_t p = 0; p < n; p++)
+                {
+                    const unsigned long long h = (unsigned long long)keys[p] * 0xD6E8FEB86659FD93ull;
+                    if ((int)((h >> 32) % (unsigned long long)T) != t) continue;
+                    const int s = mine.find_or_insert(keys[p]);
+                    if (s == (int)first_point.size()) first_point.push_back((int)p);
+                    rep[p] = first_point[s];
+                }
+            });
+        for (std::thread &th : pool) th.join();
+    }
+    // number the first carriers in point order: counts per range, offsets, then the numbers
+    std::vector<long long> range_count((size_t)T + 1, 0);
+    low_order::parallel_ranges((long long)n, T, [&](long long p0, long long p1, int part) {
+        long long c = 0;
+        for (long long p = p0; p < p1; p++) c += (rep[p] == (int)p);
+        range_count[(size_t)part + 1] = c;
+    });
+    for (int t = 0; t < T; t++) range_count[(size_t)t + 1] += range_count[t];
+    low_order::parallel_ranges((long long)n, T, [&](long long p0, long long p1, int part) {
+        int next = (int)range_count[part];
+        for (long long p = p0; p < p1; p++)
+            if (rep[p] == (int)p) ids[p] = next++;
+    });
+    low_order::parallel_ranges((long long)n, T, [&](long long p0, long long p1, int) {
+        for (long long p = p0; p < p1; p++)
+            if (rep[p] != (int)p) ids[p] = ids[rep[p]];
+    });
+    return (int)range_count[T];
+}
+
 } // namespace fdd
 
 #endif

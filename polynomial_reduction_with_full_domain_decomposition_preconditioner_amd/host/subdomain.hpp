@@ -203,13 +203,7 @@ class Subdomain
         }
     }
 
-    static void identity_matrix(CSR_Matrix<DType> &A, int n)
-    {
-        A.initialize(n, n);
-        A.reserve(n);
-        for (int i = 0; i < n; i++) A.add_entry(i, i, 1.0);
-        A.assemble();
-    }
+    static void identity_matrix(CSR_Matrix<DType> &A, int n) { A.initialize_identity(n); }
 
     void fetch_scalars(DType *out, int n) { scalars.copyTo(out, n * sizeof(DType)); }
 
@@ -1541,11 +1535,25 @@ class Subdomain
         for (int p = 0; p < P; p++) max_dof = std::max(max_dof, (int)tmp[p]);
 
         // Q (subdomain.tpp:1510-1520, 1584)
-        subdomain_operator.Q.initialize(P, max_dof);
-        subdomain_operator.Q.reserve(P);
-        for (int p = 0; p < P; p++)
-            if (tmp[p] > 0.0) subdomain_operator.Q.add_entry(p, (int)tmp[p] - 1, 1.0);
-        subdomain_operator.Q.assemble();
+        {
+            // at most one unit entry per point, rows in order: what add_entry + assemble produce, written directly
+            std::vector<int> q_ptr((size_t)P + 1, 0);
+            for (int p = 0; p < P; p++) q_ptr[p + 1] = q_ptr[p] + (tmp[p] > 0.0 ? 1 : 0);
+            fdd::low_order::pod_vector<int> q_col((size_t)q_ptr[P]);
+            fdd::low_order::pod_vector<DType> q_val((size_t)q_ptr[P]);
+            fdd::low_order::parallel_ranges(P, fdd::low_order::range_parts(P), [&](long long p0, long long p1, int) {
+                for (long long p = p0; p < p1; p++)
+                    if (tmp[p] > 0.0)
+                    {
+                        q_col[q_ptr[p]] = (int)tmp[p] - 1;
+                        q_val[q_ptr[p]] = (DType)1.0;
+                    }
+            });
+            if (q_ptr[P] > 0)
+                subdomain_operator.Q.adopt_csr(P, max_dof, std::move(q_ptr), std::move(q_col), std::move(q_val));
+            else
+                subdomain_operator.Q.initialize(P, max_dof);
+        }
         subdomain_operator.Q.transpose(subdomain_operator.Qt);
         point_dof.assign(P, -1);
         for (int p = 0; p < P; p++)
