@@ -15,6 +15,7 @@
 
 #include "element.hpp"
 #include "gll.hpp"
+#include "host_parallel.hpp"
 
 namespace fdd
 {
@@ -76,12 +77,14 @@ MeshData<DType> make_box_mesh(const BoxSpec &spec, int N, int rank)
     // after the per-level offset) -- then every other node, lexicographic on the degree-N grid.
     const long long V = (long long)(Ex + 1) * (Ey + 1) * (Ez + 1);
 
-    size_t p = 0;
-    for (int ez = 0; ez < lz; ez++)
-        for (int ey = 0; ey < ly; ey++)
-            for (int ex = 0; ex < lx; ex++)
+    // element ranges on the rank's host threads (every element writes its own n^3 points)
+    const long long n3 = (long long)n * n * n;
+    low_order::parallel_ranges(m.num_local_elements, low_order::range_parts(m.num_local_elements), [&](long long e0, long long e1, int) {
+        for (long long e = e0; e < e1; e++)
             {
+                const int ex = (int)(e % lx), ey = (int)((e / lx) % ly), ez = (int)(e / ((long long)lx * ly));
                 const long long EX = ox + ex, EY = oy + ey, EZ = oz + ez;
+                size_t p = (size_t)(e * n3);
                 for (int k = 0; k < n; k++)
                     for (int j = 0; j < n; j++)
                         for (int i = 0; i < n; i++, p++)
@@ -104,6 +107,7 @@ MeshData<DType> make_box_mesh(const BoxSpec &spec, int N, int rank)
                             m.g[2][p] = www * (hx * hy) / (2.0 * hz);
                         }
             }
+    });
     return m;
 }
 

@@ -117,6 +117,9 @@ def run_local_ranks(size: int, fn, device: int = 0, init_device: bool = True):
     Returns the list of results; the first exception of any rank is re-raised."""
     import threading
 
+    # the ranks share this process's cores: each one's setup threads (host/host_parallel.hpp) take their share
+    if "FDD_HOST_THREADS" not in os.environ and size > 1:
+        os.environ["FDD_HOST_THREADS"] = str(max(1, (os.cpu_count() or size) // size))
     world = local_world(size)
     results, errors = [None] * size, [None] * size
 
