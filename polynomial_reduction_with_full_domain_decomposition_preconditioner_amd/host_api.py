@@ -118,7 +118,8 @@ def run_local_ranks(size: int, fn, device: int = 0, init_device: bool = True):
     import threading
 
     # the ranks share this process's cores: each one's setup threads (host/host_parallel.hpp) take their share
-    if "FDD_HOST_THREADS" not in os.environ and size > 1:
+    shared_cores = "FDD_HOST_THREADS" not in os.environ and size > 1
+    if shared_cores:
         os.environ["FDD_HOST_THREADS"] = str(max(1, (os.cpu_count() or size) // size))
     world = local_world(size)
     results, errors = [None] * size, [None] * size
@@ -139,6 +140,8 @@ def run_local_ranks(size: int, fn, device: int = 0, init_device: bool = True):
     for t in threads:
         t.join()
     local_world_destroy(world)
+    if shared_cores:
+        os.environ.pop("FDD_HOST_THREADS", None)
     for e in errors:
         if e is not None:
             raise e
