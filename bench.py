@@ -90,6 +90,7 @@ def parse():
     ap.add_argument("--rehearse-ranks", type=int, default=0, help="run N ranks as N host threads of THIS process on cuda:0 (no launcher; collectives are device-to-device copies between the ranks' buffers): exercises the N-rank code path, up to 2x2x2 = 8 ranks, on a one-GPU box (not a measurement)")
     ap.add_argument("--kernel-table", action="store_true", help="time every instrumented kernel family in the timed region (fills `kernels`; costs ~8 %% of a step)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events around the kernels of the timed region (no roofline object): how much the instrumentation costs")
+    ap.add_argument("--print-launch", action="store_true", help="print the launcher command `--gpus N` would start (JSON list) and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-elements", type=int, default=20)
     ap.add_argument("--cpu-sample-steps", type=int, default=12)
@@ -225,6 +226,26 @@ def pmc_traffic(kernel_key, elements, degree):
     return (None, None) if best is None else (best["hbm_bytes_per_launch"], source)
 
 
+def launch_command(args, argv):
+    """The launcher line of an N-rank run: one rank per GPU of this node, rendezvous on 127.0.0.1 (the container's hostname
+    may not resolve) at a port the launcher's own agent binds and KEEPS (--standalone: no port number is passed around)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            os.path.abspath(__file__)] + [a for a in argv if a != "--print-launch"]
+
+
+def launch_ranks(args):
+    import subprocess
+
+    cmd = launch_command(args, sys.argv[1:])
+    if args.print_launch:
+        print(json.dumps(cmd))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or args.gpus) // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 class _ThreadRanks:
     """max over the ranks of an in-process rehearsal (ranks are threads of this process)"""
 
@@ -243,6 +264,11 @@ class _ThreadRanks:
 
 def main():
     args = parse()
+    if (args.gpus > 1 or args.print_launch) and "RANK" not in os.environ and args.rehearse_ranks <= 1:
+        # `python bench.py --gpus N` from a bare shell: this process launches its own ranks, as the reference's harness
+        # does (run.py:160, `jsrun -n P -a 1 -g 1`) -- one CHILD process per GPU under torch.distributed.run (never an
+        # exec: nothing here has touched the GPU, and nothing will), its output relayed, its exit code returned.
+        sys.exit(launch_ranks(args))
     import torch
 
     if args.rehearse_ranks > 1:
@@ -263,10 +289,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world  # under a launcher the launcher's world size governs
 
     if args.rehearse_on_one_gpu:
         local_rank = 0
@@ -319,6 +342,7 @@ def run(args, rank, world, max_over_ranks, comm_label):
             print("[bench.py %6.1f s] %s" % (time.perf_counter() - t_start, what), file=sys.stderr, flush=True)
 
     t_start = time.perf_counter()
+    rehearsal = bool(world > 1 and (args.rehearse_ranks > 1 or args.rehearse_on_one_gpu))
     P = H.rank_grid(world)
     e = args.elements
     E = tuple(e * p for p in P)
@@ -506,6 +530,16 @@ def run(args, rank, world, max_over_ranks, comm_label):
             block_local_leg = leg(blk, "BLOCK-LOCAL fdd_gmres4 (own elements only: no neighbour rings / superdomain)")
         else:
             composite_leg = leg(comp, "full-domain-decomposition composite, fdd_gmres4 WITHOUT the V-cycle (not a configuration the reference runs: its use_preconditioner is hard-wired true)")
+    if world == 1 and not args.no_precond and not args.amg:
+        # identical keys at every N: on one rank the region IS the whole domain -- no rings, no
+        # superdomain -- so the composite without the V-cycle is the headline configuration itself
+        composite_leg = {"preconditioner": "one rank: the subdomain is the whole domain, the full-domain-decomposition composite without the V-cycle IS the headline configuration (same figures as `value`)",
+                         "ms_per_step": dt / args.steps * 1e3, "value": value, "last_residual_norm": last_res}
+        if headline_tol is not None:
+            composite_leg["to_1e-7"] = headline_tol
+    for lg in (composite_leg, block_local_leg):
+        if lg is not None:
+            lg["converged"] = lg["to_1e-7"]["converged"] if "to_1e-7" in lg else None
     progress("comparison leg done")
     table = {}
     for name, st in kernels.items():
@@ -590,12 +624,15 @@ def run(args, rank, world, max_over_ranks, comm_label):
         "metric": "PCG DOF-updates/sec + SpMV GB/s (%HBM peak), 3D Poisson N=7",
         "value": value,
         "unit": "DOF-updates/s",
-        "n_gpus": world,
+        # a rehearsal's ranks share ONE device: the structured fields say so, never an N-GPU weak-scaling point
+        "n_gpus": 1 if rehearsal else world,
+        "ranks": world,
+        "rehearsal": rehearsal,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": None if rehearsal else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",

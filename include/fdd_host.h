@@ -84,6 +84,12 @@ int fddh_problem_create_dir_ex(fddh_problem **out, const char *directory, int po
 int fddh_problem_destroy(fddh_problem *p);
 /* write the box mesh of this rank as the reference's file set under `directory` */
 int fddh_write_box_mesh_files(const char *directory, const int E[3], const int P[3], int poly_degree, int rank);
+/* The box mesh under the generalized Kershaw map (eps_y, eps_z in (0, 1]; 1 = the uniform box): the geometry of every
+ * experiment of the reference (run.py:25-47, run.sh:30: Nek5000 "Kershaw" exports with eps = 0.3, which are not in the
+ * repository).  GLL points moved by the map, the six geometric factors isoparametric at each level's own degree, all six
+ * non-zero (host/box_mesh.hpp). */
+int fddh_problem_create_kershaw_ex(fddh_problem **out, const int E[3], const int P[3], int poly_degree, int poly_reduction, int subdomain_overlap, int superdomain_overlap, int flags, double eps_y, double eps_z);
+int fddh_write_kershaw_mesh_files(const char *directory, const int E[3], const int P[3], int poly_degree, int rank, double eps_y, double eps_z);
 
 enum
 {

@@ -11,6 +11,8 @@
 #ifndef FDD_BOX_MESH_HPP
 #define FDD_BOX_MESH_HPP
 
+#include <atomic>
+#include <stdexcept>
 #include <vector>
 
 #include "element.hpp"
@@ -24,7 +26,46 @@ struct BoxSpec
 {
     int E[3] = {4, 4, 4}; // global elements per direction
     int P[3] = {1, 1, 1}; // rank blocks per direction
+    // Kershaw deformation of the cube (the reference's own experiment geometry: every mesh of run.py:25-47 and run.sh:30 is
+    // a Nek5000 "Kershaw" export with eps = 0.3).  1.0 = the uniform box.
+    double kershaw_eps[2] = {1.0, 1.0}; // eps_y, eps_z in (0, 1]
+    bool deformed() const { return kershaw_eps[0] != 1.0 || kershaw_eps[1] != 1.0; }
 };
+
+// The generalized Kershaw map of the unit cube onto itself (D. Kershaw, J. Comput. Phys. 39 (1981) 375-395, in the 3-D
+// form the CEED bake-off problems and Nek5000's kershaw case use): x is kept; the x-range is cut into six layers whose
+// yz-sections go left-to-left, left-to-right, right-to-left (two layers), left-to-right, right-to-right, where "left" /
+// "right" compress the lower / upper half of [0,1] to eps/2.  Piecewise trilinear, continuous, boundary-preserving;
+// eps = 1 is the identity.  The reference reads the deformed GLL coordinates and factors from Nek5000 exports that are not
+// in the repository; here the map is applied to the GLL points of the box mesh and the factors follow isoparametrically.
+namespace kershaw
+{
+inline double right(double eps, double x) { return x <= 0.5 ? (2.0 - eps) * x : 1.0 + eps * (x - 1.0); }
+inline double left(double eps, double x) { return 1.0 - right(eps, 1.0 - x); }
+inline double step(double a, double b, double t) { return t <= 0.0 ? a : (t >= 1.0 ? b : a + (b - a) * t); }
+inline double section(double eps, double s, int layer, double lambda)
+{
+    switch (layer)
+    {
+    case 0: return left(eps, s);
+    case 1:
+    case 4: return step(left(eps, s), right(eps, s), lambda);
+    case 2: return step(right(eps, s), left(eps, s), 0.5 * lambda);
+    case 3: return step(right(eps, s), left(eps, s), 0.5 * (1.0 + lambda));
+    default: return right(eps, s);
+    }
+}
+inline void map(double eps_y, double eps_z, double x, double y, double z, double &X, double &Y, double &Z)
+{
+    X = x;
+    int layer = (int)(x * 6.0);
+    if (layer > 5) layer = 5;
+    if (layer < 0) layer = 0;
+    const double lambda = (x - layer / 6.0) * 6.0;
+    Y = section(eps_y, y, layer, lambda);
+    Z = section(eps_z, z, layer, lambda);
+}
+} // namespace kershaw
 
 // rank blocks for a cube of ranks: 1 -> 1x1x1, 2 -> 2x1x1, 4 -> 2x2x1, 8 -> 2x2x2, ...
 inline void default_rank_grid(int num_ranks, int P[3])
@@ -38,6 +79,76 @@ inline void default_rank_grid(int num_ranks, int P[3])
         d = (d + 1) % 3;
     }
     P[0] *= num_ranks; // any odd remainder goes along x
+}
+
+// Move the GLL points of a 3-D mesh by a global map and recompute the six geometric factors isoparametrically at the mesh's
+// own degree: J = dX/dr through D_hat along r, s, t; G = w_i w_j w_k |J| J^-1 J^-T in the order rr, ss, tt, rs, rt, st
+// (domain.okl:47-49), quadrature weights folded in as the reference's files have them.  The reference-cube factor 1/2 per
+// direction of the affine box is part of J here (r in [-1,1]).
+template <typename DType, typename Map>
+void deform_isoparametric(MeshData<DType> &m, Map map)
+{
+    const int n = m.poly_degree + 1;
+    const long long n3 = (long long)n * n * n;
+    std::vector<double> zg(n), wg(n), D((size_t)n * n);
+    gll::zwgll(zg.data(), wg.data(), n);
+    gll::dgll(D.data(), zg.data(), n);
+    std::atomic<bool> bad(false);
+    low_order::parallel_ranges(m.num_local_elements, low_order::range_parts(m.num_local_elements), [&](long long e0, long long e1, int) {
+        std::vector<double> c[3];
+        for (auto &v : c) v.resize((size_t)n3);
+        for (long long e = e0; e < e1; e++)
+        {
+            const size_t base = (size_t)(e * n3);
+            for (long long q = 0; q < n3; q++) map((double)m.x[base + q], (double)m.y[base + q], (double)m.z[base + q], c[0][q], c[1][q], c[2][q]);
+            for (int k = 0; k < n; k++)
+                for (int j = 0; j < n; j++)
+                    for (int i = 0; i < n; i++)
+                    {
+                        const long long q = i + (long long)n * (j + (long long)n * k);
+                        double J[3][3]; // J[a][b] = d X_a / d r_b
+                        for (int a = 0; a < 3; a++)
+                        {
+                            double dr = 0.0, ds = 0.0, dt = 0.0;
+                            for (int p = 0; p < n; p++)
+                            {
+                                dr += D[(size_t)i * n + p] * c[a][p + (long long)n * (j + (long long)n * k)];
+                                ds += D[(size_t)j * n + p] * c[a][i + (long long)n * (p + (long long)n * k)];
+                                dt += D[(size_t)k * n + p] * c[a][i + (long long)n * (j + (long long)n * p)];
+                            }
+                            J[a][0] = dr;
+                            J[a][1] = ds;
+                            J[a][2] = dt;
+                        }
+                        const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) + J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+                        if (!(det > 0.0)) bad.store(true); // reported after the threads have joined
+                        double I[3][3]; // I = J^-1 = d r / d X
+                        I[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) / det;
+                        I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+                        I[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+                        I[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
+                        I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+                        I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+                        I[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) / det;
+                        I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+                        I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+                        const double sc = wg[i] * wg[j] * wg[k] * det;
+                        static const int pa[6] = {0, 1, 2, 0, 0, 1}, pb[6] = {0, 1, 2, 1, 2, 2};
+                        for (int f = 0; f < 6; f++)
+                        {
+                            const int a = pa[f], b = pb[f];
+                            m.g[f][base + q] = (DType)(sc * (I[a][0] * I[b][0] + I[a][1] * I[b][1] + I[a][2] * I[b][2]));
+                        }
+                    }
+            for (long long q = 0; q < n3; q++)
+            {
+                m.x[base + q] = (DType)c[0][q];
+                m.y[base + q] = (DType)c[1][q];
+                m.z[base + q] = (DType)c[2][q];
+            }
+        }
+    });
+    if (bad.load()) throw std::runtime_error("deformed box mesh: non-positive Jacobian at a GLL point");
 }
 
 template <typename DType>
@@ -108,6 +219,7 @@ MeshData<DType> make_box_mesh(const BoxSpec &spec, int N, int rank)
                         }
             }
     });
+    if (spec.deformed()) deform_isoparametric(m, [&](double x, double y, double z, double &X, double &Y, double &Z) { kershaw::map(spec.kershaw_eps[0], spec.kershaw_eps[1], x, y, z, X, Y, Z); });
     return m;
 }
 

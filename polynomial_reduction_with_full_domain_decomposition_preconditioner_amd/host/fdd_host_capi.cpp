@@ -440,8 +440,14 @@ int fddh_problem_create_box(fddh_problem **out, const int E[3], const int P[3], 
 
 int fddh_problem_create_box_ex(fddh_problem **out, const int E[3], const int P[3], int poly_degree, int poly_reduction, int subdomain_overlap, int superdomain_overlap, int flags)
 {
+    return fddh_problem_create_kershaw_ex(out, E, P, poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, flags, 1.0, 1.0);
+}
+
+int fddh_problem_create_kershaw_ex(fddh_problem **out, const int E[3], const int P[3], int poly_degree, int poly_reduction, int subdomain_overlap, int superdomain_overlap, int flags, double eps_y, double eps_z)
+{
     try
     {
+        if (!(eps_y > 0.0 && eps_y <= 1.0 && eps_z > 0.0 && eps_z <= 1.0)) return fail("Kershaw eps must lie in (0, 1]");
         const int with_subdomain = flags & FDDH_WITH_SUBDOMAIN;
         if (!out || !E || !P || poly_degree < 1 || poly_reduction < 1) return fail("bad argument");
         if (P[0] * P[1] * P[2] != fdd::comm().size) return fail("rank grid %dx%dx%d does not match communicator size %d", P[0], P[1], P[2], fdd::comm().size);
@@ -459,6 +465,8 @@ int fddh_problem_create_box_ex(fddh_problem **out, const int E[3], const int P[3
             spec.E[d] = E[d];
             spec.P[d] = P[d];
         }
+        spec.kershaw_eps[0] = eps_y;
+        spec.kershaw_eps[1] = eps_z;
 
         for (int deg : p->degrees)
         {
@@ -549,15 +557,23 @@ int fddh_problem_destroy(fddh_problem *p)
 
 int fddh_write_box_mesh_files(const char *directory, const int E[3], const int P[3], int poly_degree, int rank)
 {
+    return fddh_write_kershaw_mesh_files(directory, E, P, poly_degree, rank, 1.0, 1.0);
+}
+
+int fddh_write_kershaw_mesh_files(const char *directory, const int E[3], const int P[3], int poly_degree, int rank, double eps_y, double eps_z)
+{
     try
     {
         if (!directory || !E || !P) return fail("null argument");
+        if (!(eps_y > 0.0 && eps_y <= 1.0 && eps_z > 0.0 && eps_z <= 1.0)) return fail("Kershaw eps must lie in (0, 1]");
         fdd::BoxSpec spec;
         for (int d = 0; d < 3; d++)
         {
             spec.E[d] = E[d];
             spec.P[d] = P[d];
         }
+        spec.kershaw_eps[0] = eps_y;
+        spec.kershaw_eps[1] = eps_z;
         MeshData<SType> m = fdd::make_box_mesh<SType>(spec, poly_degree, rank);
         char sub[4096];
         mkdir(directory, 0777);

@@ -292,6 +292,15 @@ class Problem:
         return cls(h)
 
     @classmethod
+    def kershaw(cls, E, P=(1, 1, 1), poly_degree=7, poly_reduction=2, eps=0.3, with_subdomain=True, subdomain_overlap=1, superdomain_overlap=1, block_local=False, force_composite=False, eps_z=None):
+        """The box under the generalized Kershaw map (the reference's experiment geometry, run.py:25-47: eps = 0.3); all
+        six geometric factors are non-zero.  eps = 1 is the uniform box."""
+        h = vp()
+        _H().call("fddh_problem_create_kershaw_ex", ctypes.byref(h), _arr3(E), _arr3(P), poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap,
+                  cls._flags(with_subdomain, block_local, force_composite), ctypes.c_double(eps), ctypes.c_double(eps if eps_z is None else eps_z))
+        return cls(h)
+
+    @classmethod
     def from_directory(cls, directory, poly_degree, poly_reduction, subdomain_overlap=1, superdomain_overlap=1, with_subdomain=True, block_local=False, force_composite=False):
         h = vp()
         _H().call("fddh_problem_create_dir_ex", ctypes.byref(h), os.fsencode(directory), poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, cls._flags(with_subdomain, block_local, force_composite))

@@ -12,7 +12,6 @@ the setup whose cost grows with the rank count.
 import argparse
 import os
 import resource
-import socket
 import sys
 import time
 
@@ -21,9 +20,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def worker(rank, world, port, E, N, red):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+def worker(rank, world, rdzv, E, N, red):
     import torch.distributed as dist
 
     import support as S
@@ -32,7 +29,9 @@ def worker(rank, world, port, E, N, red):
 
     shim = os.path.join(ROOT, "tests", "cpu_shim", "_build", "libfdd_host_cpu.so")
     lib._host = lib._Lib(shim, os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rendezvous
+
+    rendezvous.init_gloo(rank, world, rdzv)
     try:
         H.init(0, use_torch_stream=False)
         H.set_print(False)
@@ -60,10 +59,9 @@ def main():
     a = ap.parse_args()
     import torch.multiprocessing as mp
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    import rendezvous
+
+    port = rendezvous.new()
     mp.spawn(worker, args=(a.ranks, port, a.E, a.N, a.reduction), nprocs=a.ranks, join=True)
 
 

@@ -1,18 +1,19 @@
 #!/usr/bin/env python3
 """Outer PCG iterations to 1e-7 for block-local vs composite preconditioning, with and without the V-cycle inside
 (test infrastructure: gloo ranks on the CPU stand-in of the kernel C-ABI).  python tests/composite_iteration_counts.py [ranks] [E per rank] [N]"""
-import json, os, socket, sys
+import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def worker(rank, world, port, e, N, red):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+def worker(rank, world, rdzv, e, N, red):
     import torch.distributed as dist
     import support as S
     from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H, lib
     lib._host = lib._Lib(os.path.join(ROOT, "tests/cpu_shim/_build/libfdd_host_cpu.so"), os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rendezvous
+
+    rendezvous.init_gloo(rank, world, rdzv)
     H.init(0, use_torch_stream=False); H.set_print(False)
     if world > 1: H.comm_torch_callbacks(on_gpu=False)
     else: H.comm_single()
@@ -39,5 +40,7 @@ if __name__ == "__main__":
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     e = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     N = int(sys.argv[3]) if len(sys.argv) > 3 else 7
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    import rendezvous
+
+    port = rendezvous.new()
     mp.spawn(worker, args=(world, port, e, N, 6 if N == 7 else 2), nprocs=world, join=True)

@@ -14,7 +14,6 @@ python tests/composite_operator_analysis.py [ranks] [E per rank] [N]
 """
 import json
 import os
-import socket
 import sys
 
 import numpy as np
@@ -46,16 +45,16 @@ def gmres(op, f, m):
     return x, f - op(x)
 
 
-def worker(rank, world, port, e, N, red, out_file):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+def worker(rank, world, rdzv, e, N, red, out_file):
     import torch.distributed as dist
 
     import support as S
     from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H, lib
 
     lib._host = lib._Lib(os.path.join(ROOT, "tests/cpu_shim/_build/libfdd_host_cpu.so"), os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rendezvous
+
+    rendezvous.init_gloo(rank, world, rdzv)
     H.init(0, use_torch_stream=False)
     H.set_print(False)
     H.comm_torch_callbacks(on_gpu=False)
@@ -153,8 +152,7 @@ if __name__ == "__main__":
     e = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     N = int(sys.argv[3]) if len(sys.argv) > 3 else 7
     out = sys.argv[4] if len(sys.argv) > 4 else "/tmp/composite_operator_analysis.json"
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    import rendezvous
+
+    port = rendezvous.new()
     mp.spawn(worker, args=(world, port, e, N, 6 if N == 7 else 2, out), nprocs=world, join=True)

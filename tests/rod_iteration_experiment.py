@@ -2,16 +2,17 @@
 """Outer iterations on the rod of DESIGN 5.3 (Dirichlet ends only, strips of 4 elements of degree 2 per rank) for a given superdomain
 overlap and number of inner Krylov steps: what the iteration growth with the rank count is made of.  Test infrastructure (CPU
 stand-in of the kernel C-ABI under a gloo group).  python tests/rod_iteration_experiment.py <ranks> <superdomain overlap> <inner steps>"""
-import os, sys, socket, json, tempfile
+import os, sys, json, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-def worker(rank, world, port, mesh_dir, N, red, w, sup_ov, inner, omega_env):
-    os.environ["MASTER_ADDR"]="127.0.0.1"; os.environ["MASTER_PORT"]=str(port)
+def worker(rank, world, rdzv, mesh_dir, N, red, w, sup_ov, inner, omega_env):
     import torch.distributed as dist
     import support as S
     from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H, lib
     lib._host = lib._Lib(os.path.join(ROOT, "tests/cpu_shim/_build/libfdd_host_cpu.so"), os.path.join(lib.INCLUDE_DIR, "fdd_host.h"), "fddh_last_error")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rendezvous
+
+    rendezvous.init_gloo(rank, world, rdzv)
     H.init(0, use_torch_stream=False); H.set_print(False)
     if world>1: H.comm_torch_callbacks(on_gpu=False)
     else: H.comm_single()
@@ -31,5 +32,7 @@ if __name__=="__main__":
     import torch.multiprocessing as mp
     world=int(sys.argv[1]); sup=int(sys.argv[2]); inner=int(sys.argv[3])
     d=tempfile.mkdtemp()
-    s=socket.socket(); s.bind(("127.0.0.1",0)); port=s.getsockname()[1]; s.close()
+    import rendezvous
+
+    port = rendezvous.new()
     mp.spawn(worker,args=(world,port,d,2,1,4,sup,inner,None),nprocs=world,join=True)

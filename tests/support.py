@@ -842,7 +842,13 @@ class DeformedMesh(BoxMesh):
         _, w, D = gll(N)
         D = np.asarray(D).reshape(n, n)  # D[i, p] = D_hat[p + i*n]
         s = np.sin(np.pi * self.x) * np.sin(np.pi * self.y) * np.sin(np.pi * self.z)
-        X = [self.x + amplitude * s, self.y - 0.7 * amplitude * s, self.z + 0.5 * amplitude * s]
+        self._isoparametric([self.x + amplitude * s, self.y - 0.7 * amplitude * s, self.z + 0.5 * amplitude * s])
+
+    def _isoparametric(self, X):
+        """move the GLL points to X = [x, y, z] and recompute the six factors at the mesh's own degree"""
+        n = self.N + 1
+        _, w, D = gll(self.N)
+        D = np.asarray(D).reshape(n, n)  # D[i, p] = D_hat[p + i*n]
         self.x, self.y, self.z = [np.ascontiguousarray(c) for c in X]
         ne = self.num_local_elements
         J = np.zeros((ne, n, n, n, 3, 3))
@@ -859,6 +865,32 @@ class DeformedMesh(BoxMesh):
         sc = www * det
         pairs = [(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]
         self.g = [np.ascontiguousarray((sc * M[..., a, b]).reshape(-1)) for a, b in pairs]
+
+
+def kershaw_map(eps_y, eps_z, x, y, z):
+    """The generalized Kershaw map of the unit cube (D. Kershaw, JCP 39 (1981); the 3-D form of the CEED bake-off problems
+    and of Nek5000's kershaw case, whose eps = 0.3 exports every experiment of the reference reads, run.py:25-47): x kept,
+    six x-layers whose yz-sections go left-left, left-right, right-left (two layers), left-right, right-right.  An
+    independent numpy statement of host/box_mesh.hpp's."""
+    right = lambda eps, s: np.where(s <= 0.5, (2.0 - eps) * s, 1.0 + eps * (s - 1.0))
+    left = lambda eps, s: 1.0 - right(eps, 1.0 - s)
+    step = lambda a, b, t: np.where(t <= 0.0, a, np.where(t >= 1.0, b, a + (b - a) * t))
+    layer = np.clip(np.floor(x * 6.0).astype(np.int64), 0, 5)
+    lam = (x - layer / 6.0) * 6.0
+
+    def section(eps, s):
+        L, R = left(eps, s), right(eps, s)
+        return np.select([layer == 0, (layer == 1) | (layer == 4), layer == 2, layer == 3], [L, step(L, R, lam), step(R, L, 0.5 * lam), step(R, L, 0.5 * (1.0 + lam))], default=R)
+
+    return x, section(eps_y, y), section(eps_z, z)
+
+
+class KershawMesh(DeformedMesh):
+    """BoxMesh under the Kershaw map: the reference's experiment geometry (all six geometric factors non-zero)."""
+
+    def __init__(self, E, N, eps=0.3, P=(1, 1, 1), rank=0, eps_z=None):
+        BoxMesh.__init__(self, E, N, P, rank)
+        self._isoparametric(list(kershaw_map(eps, eps if eps_z is None else eps_z, self.x, self.y, self.z)))
 
 
 class QuadMesh(BoxMesh):
@@ -972,3 +1004,34 @@ def write_mesh_files(directory, mesh, proc_id=0):
     put("p_mask", mesh.p_mask, np.float64)
     for g in range(6):
         put("g_%d" % (g + 1), mesh.g[g], np.float64)
+
+
+def read_mesh_arrays(directory, N, proc_id=0, dim=3):
+    """the arrays of one rank's file set (the reader's format, domain.tpp:45-224) as a dict"""
+    d = os.path.join(directory, "lx1_%d" % (N + 1))
+    get = lambda stem, dtype: np.fromfile(os.path.join(d, "%s_%d.%d.dat" % (stem, proc_id, N)), dtype=dtype)
+    out = {"x": get("x", np.float64), "y": get("y", np.float64), "glo_num": get("glo_num", np.int64), "node_degree": get("node_degree", np.int32), "p_mask": get("p_mask", np.float64)}
+    out["z"] = get("z", np.float64) if dim == 3 else np.zeros_like(out["x"])
+    for g in range(6):
+        out["g_%d" % (g + 1)] = get("g_%d" % (g + 1), np.float64)
+    return out
+
+
+def kershaw_mesh_of_the_host_layer(host_lib, directory, E, N, eps, P=(1, 1, 1), rank=0):
+    """Rank `rank`'s Kershaw mesh as host/box_mesh.hpp generates it (written through fddh_write_kershaw_mesh_files and read
+    back), held against the numpy statement of the same map and returned with the host layer's bits, so that an oracle
+    world built from it sees the geometry of the product's ranks exactly (a long Krylov iteration on a strongly deformed
+    mesh amplifies a last-bit difference of the factors past the comparison tolerances)."""
+    import ctypes as C
+
+    twin = KershawMesh(E, N, eps, P, rank)
+    arr3 = lambda v: (C.c_int * 3)(*v)
+    host_lib.call("fddh_write_kershaw_mesh_files", os.fsencode(directory), arr3(E), arr3(P), N, rank, C.c_double(eps), C.c_double(eps))
+    a = read_mesh_arrays(directory, N, rank)
+    gmax = max(np.abs(g).max() for g in twin.g)
+    for name, ref in [("x", twin.x), ("y", twin.y), ("z", twin.z)] + [("g_%d" % (k + 1), twin.g[k]) for k in range(6)]:
+        assert np.abs(a[name] - ref).max() <= 1e-13 * (gmax if name.startswith("g_") else 1.0), (N, rank, name)
+    assert np.array_equal(a["glo_num"], twin.glo_num) and np.array_equal(a["node_degree"], twin.node_degree) and np.array_equal(a["p_mask"], twin.p_mask)
+    twin.x, twin.y, twin.z = a["x"], a["y"], a["z"]
+    twin.g = [a["g_%d" % (k + 1)] for k in range(6)]
+    return twin

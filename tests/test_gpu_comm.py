@@ -9,6 +9,8 @@ import os
 import numpy as np
 import pytest
 
+import rendezvous
+
 from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
 from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
 
@@ -20,15 +22,15 @@ def group(gpu):
     import torch
     import torch.distributed as dist
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    rdzv = rendezvous.new()  # a file store: no TCP port is reserved, released or guessed (GPUTEST_r03's EADDRINUSE)
+    rendezvous.init("nccl", 0, 1, rdzv, device_id=torch.device("cuda", 0))
     H.init(0, use_torch_stream=True)
     H.set_print(False)
     yield dist
     H.comm_single()
     dist.destroy_process_group()
+    rendezvous.done(rdzv)
 
 
 def test_torch_distributed_callbacks_on_device_buffers(group):
@@ -55,21 +57,19 @@ def test_solve_is_identical_under_every_backend(group):
         assert its == results[0][1] and np.array_equal(hist, results[0][2]) and np.array_equal(u, results[0][0])
 
 
-def _two_rank_worker(rank, world, port, E, N, red, composite=False):
+def _two_rank_worker(rank, world, rdzv, E, N, red, composite=False):
     """One of `world` ranks that all drive cuda:0; collectives go through a gloo
     group with the device buffers staged over the host (the solver's multi-rank
     code path -- interface exchange, device-side scalars, node-space PCG -- is
     exactly the one RCCL serves on a multi-GPU node)."""
     import sys
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
 
     import support as S
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rendezvous.init_gloo(rank, world, rdzv)
     try:
         H.init(0, use_torch_stream=True)
         H.set_print(False)
@@ -144,43 +144,31 @@ def _two_rank_worker(rank, world, port, E, N, red, composite=False):
         dist.destroy_process_group()
 
 
-def _port():
-    import socket
-
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
 def test_two_ranks_on_one_gpu_against_the_oracle_world(gpu):
     import torch.multiprocessing as mp
 
-    mp.spawn(_two_rank_worker, args=(2, _port(), (4, 4, 4), 3, 2), nprocs=2, join=True)  # block-local regions
+    mp.spawn(_two_rank_worker, args=(2, rendezvous.new(), (4, 4, 4), 3, 2), nprocs=2, join=True)  # block-local regions
 
 
 def test_two_ranks_on_one_gpu_full_domain_decomposition_composite(gpu):
     """The composite region (rings at reduced degree + graded superdomain) of two ranks that share cuda:0."""
     import torch.multiprocessing as mp
 
-    mp.spawn(_two_rank_worker, args=(2, _port(), (16, 4, 4), 3, 2, True), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, rendezvous.new(), (16, 4, 4), 3, 2, True), nprocs=2, join=True)
 
 
-def _full_size_worker(rank, world, port):
+def _full_size_worker(rank, world, rdzv):
     """Config C4's per-rank size (32^3 elements of degree 7 per rank) with two ranks sharing cuda:0: the composite with
     the reference's default inner preconditioner (AMG V-cycle on the composite low-order operator).  No oracle run at
     this size: the manufactured solution comes back, in a handful of outer iterations."""
     import sys
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
 
     import support as S
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rendezvous.init_gloo(rank, world, rdzv)
     try:
         H.init(0, use_torch_stream=True)
         H.set_print(False)
@@ -208,22 +196,20 @@ def _full_size_worker(rank, world, port):
 def test_two_ranks_full_size_composite_with_the_reference_default_preconditioner(gpu):
     import torch.multiprocessing as mp
 
-    mp.spawn(_full_size_worker, args=(2, _port()), nprocs=2, join=True)
+    mp.spawn(_full_size_worker, args=(2, rendezvous.new()), nprocs=2, join=True)
 
 
-def _two_rank_worker_2d(rank, world, port, mesh_dir):
+def _two_rank_worker_2d(rank, world, rdzv, mesh_dir):
     """The composite's `dim == 2` branches on the HIP kernels: two rank strips of a deformed quadrilateral mesh read from
     the reference's per-rank files (fused 2-D stiffness on mixed degrees, hanging edges, the exchange), against the oracle."""
     import sys
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
 
     import support as S
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rendezvous.init_gloo(rank, world, rdzv)
     try:
         H.init(0, use_torch_stream=True)
         H.set_print(False)
@@ -276,7 +262,7 @@ def _two_rank_worker_2d(rank, world, port, mesh_dir):
 def test_two_ranks_on_one_gpu_composite_in_two_dimensions(gpu, tmp_path):
     import torch.multiprocessing as mp
 
-    mp.spawn(_two_rank_worker_2d, args=(2, _port(), str(tmp_path / "quad")), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker_2d, args=(2, rendezvous.new(), str(tmp_path / "quad")), nprocs=2, join=True)
 
 
 @pytest.mark.parametrize("world,E", [(4, (8, 8, 4)), (8, (8, 8, 8))])
@@ -311,7 +297,7 @@ def test_bench_line_of_an_n_rank_run(gpu):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 4 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["n_gpus"] == 1 and line["ranks"] == 4 and line["rehearsal"] is True and line["scaling"] is None and line["value"] > 0  # four ranks, ONE device
     assert "BLOCK-LOCAL" in line["config"]["workload"] and line["config"]["rank_grid"] == [2, 2, 1]
     assert line["to_1e-7"]["converged"] is True
     comp = line["composite"]
