@@ -90,6 +90,10 @@ def parse():
     ap.add_argument("--rehearse-ranks", type=int, default=0, help="run N ranks as N host threads of THIS process on cuda:0 (no launcher; collectives are device-to-device copies between the ranks' buffers): exercises the N-rank code path, up to 2x2x2 = 8 ranks, on a one-GPU box (not a measurement)")
     ap.add_argument("--kernel-table", action="store_true", help="time every instrumented kernel family in the timed region (fills `kernels`; costs ~8 %% of a step)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events around the kernels of the timed region (no roofline object): how much the instrumentation costs")
+    ap.add_argument("--outer", choices=["fcg", "gmres"], default="fcg", help="outer Krylov method of the timed steps: the metric's PCG (default) or the reference driver's own choice, flexible GMRES(20) (poisson.cpp:224 hard-codes solver_id = 1); `reference_default_gmres` is in the line either way")
+    ap.add_argument("--mesh", choices=["box", "kershaw"], default="box", help="geometry of the whole run (default: the uniform box SURVEY 8(d) specifies); the Kershaw leg of the default run is in `kershaw` either way")
+    ap.add_argument("--eps", type=float, default=0.3, help="Kershaw map parameter (run.py:25-47: eps_0.3)")
+    ap.add_argument("--no-kershaw", action="store_true", help="skip the `kershaw` leg (a second problem on the deformed mesh)")
     ap.add_argument("--print-launch", action="store_true", help="print the launcher command `--gpus N` would start (JSON list) and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-elements", type=int, default=20)
@@ -352,6 +356,8 @@ def run(args, rank, world, max_over_ranks, comm_label):
         """A failure on one rank leaves the others inside the composite's setup collectives: report it and leave with a
         failure code so that the launcher tears the job down, instead of moving on to a mismatched collective."""
         try:
+            if args.mesh == "kershaw":
+                return H.Problem.kershaw(E, P, N, args.reduction, args.eps, with_subdomain=not args.no_precond, block_local=block_local, force_composite=args.force_composite and world == 1)
             return H.Problem.box(E, P, N, args.reduction, with_subdomain=not args.no_precond, block_local=block_local, force_composite=args.force_composite and world == 1)
         except Exception as exc:
             print("bench.py rank %d: problem setup failed: %s" % (rank, exc), file=sys.stderr, flush=True)
@@ -439,25 +445,53 @@ def run(args, rank, world, max_over_ranks, comm_label):
         lib.host().call("fddh_profile_enable", 0)
         return dt, last, json.loads(buf.value.decode())
 
-    def to_tolerance(problem=None, rhs=None):
+    def timed_gmres_steps(steps, warmup, kernel_timing, problem=None, rhs=None):
+        """`warmup` untimed + exactly `steps` timed Arnoldi steps of the outer flexible GMRES(20) (domain.tpp:727-914): a solve
+        capped at `steps` iterations with the stopping test off, so the time holds the cycle's start (residual norm, first
+        basis vector) and end (back-substitution, solution update) as a real solve pays them, bracketed as timed_steps is"""
+        problem = problem or prob
+        rhs = f if rhs is None else rhs
+        problem.set_options(max_iterations=max(warmup, 1), tolerance=0.0)
+        problem.solve_timed(rhs, "gmres")
+        problem.set_options(max_iterations=steps, tolerance=0.0)
+        lib.host().call("fddh_profile_enable", 1 if kernel_timing else 0)
+        H.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        its, hist, _ = problem.solve_timed(rhs, "gmres")
+        torch.cuda.synchronize()
+        H.barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.host().call("fddh_profile_collect", buf, len(buf))
+        lib.host().call("fddh_profile_enable", 0)
+        problem.set_options(max_iterations=500, tolerance=1e-7)  # the reference's values (domain.hpp:116-118)
+        assert its == steps, (its, steps)
+        return dt, float(hist[-1]), json.loads(buf.value.decode())
+
+    def to_tolerance(problem=None, rhs=None, method="fcg"):
         """the reference's own stopping rule: relative residual 1e-7 within 500 iterations (domain.hpp:116-118), clock
         around the device work; `converged` says which of the two ended the solve"""
-        its, hist, sec = (problem or prob).solve_timed(f if rhs is None else rhs, "fcg")
+        its, hist, sec = (problem or prob).solve_timed(f if rhs is None else rhs, method)
         sec = max_over_ranks(sec)
         rel = float(hist[-1] / hist[0]) if len(hist) else None
         return {"iterations": its, "converged": bool(rel is not None and rel <= 1e-7), "time_ms": sec * 1e3, "relative_residual": rel, "DOF_updates_per_s": nodes * its / sec if sec > 0 else None}
 
     # ---------------- headline configuration ----------------
     configure(args.amg, args.amg_precision)
-    dt, last_res, kernels = timed_steps(args.steps, args.warmup, not args.no_kernel_timing)
+    headline_steps = timed_gmres_steps if args.outer == "gmres" else timed_steps
+    dt, last_res, kernels = headline_steps(args.steps, args.warmup, not args.no_kernel_timing)
     value = nodes * args.steps / dt
     progress("headline steps timed: %.3f ms per step" % (dt / args.steps * 1e3))
 
     # the same K steps with a stopping test (one host synchronisation) per step, as a real solve runs them
-    prob.set_flag("lazy_steps", 0)
-    dt_tests, _, _ = timed_steps(args.steps, min(args.warmup, 1), False)
-    prob.set_flag("lazy_steps", 1)
-    headline_tol = None if args.no_time_to_tolerance else to_tolerance()
+    if args.outer == "fcg":
+        prob.set_flag("lazy_steps", 0)
+        dt_tests, _, _ = timed_steps(args.steps, min(args.warmup, 1), False)
+        prob.set_flag("lazy_steps", 1)
+    else:
+        dt_tests = dt  # a GMRES solve reads its residual estimate every step anyway
+    headline_tol = None if args.no_time_to_tolerance else to_tolerance(method=args.outer)
     progress("headline solve to tolerance: %s" % (headline_tol,))
 
     # the headline configuration with the preconditioner in single precision (the reference's Float = float)
@@ -589,7 +623,7 @@ def run(args, rank, world, max_over_ranks, comm_label):
         }
 
     # ---------------- the reference's default inner preconditioner (V-cycle on): on the composite when there is one ----------------
-    reference_default = None
+    reference_default = reference_default_gmres = None
     ref_prob = comp if comp is not None else prob
     if not args.no_precond and not args.no_reference_default and not args.amg:
         reference_default = {"preconditioner": "fdd_gmres4 + low-order AMG V-cycle in every inner step (Subdomain::use_preconditioner = true, subdomain.hpp:231)"
@@ -603,9 +637,55 @@ def run(args, rank, world, max_over_ranks, comm_label):
                 entry["to_1e-7"] = to_tolerance(ref_prob, f_ref)
             reference_default["f%d" % precision] = entry
             progress("reference-default leg (f%d) done" % precision)
+        # ... and under the outer solver the reference's driver actually runs: flexible GMRES(20) (poisson.cpp:224, solver_id = 1;
+        # domain.tpp:727-914), classical Gram-Schmidt with (j+1) assembled dots and (j+1) updates in Arnoldi step j
+        reference_default_gmres = {"solver": "outer flexible GMRES(20) (poisson.cpp:224: the driver's hard-wired solver_id = 1) + " + reference_default["preconditioner"]}
+        for precision in (64, 32):
+            configure(True, precision, problem=ref_prob)
+            d, lr, _ = timed_gmres_steps(args.steps, min(args.warmup, 2), False, problem=ref_prob, rhs=f_ref)
+            entry = {"ms_per_arnoldi_step": d / args.steps * 1e3, "value": nodes * args.steps / d, "steps": args.steps, "last_residual_estimate": lr}
+            if not args.no_time_to_tolerance:
+                entry["to_1e-7"] = to_tolerance(ref_prob, f_ref, "gmres")
+            reference_default_gmres["f%d" % precision] = entry
+            progress("reference-default GMRES leg (f%d) done" % precision)
         reference_default["amg_levels"] = amg_states[id(ref_prob)]["levels"]
         reference_default["amg_setup_s"] = amg_states[id(ref_prob)]["setup_s"]
         configure(args.amg if ref_prob is prob else False, args.amg_precision, problem=ref_prob)
+
+    # ---------------- the reference's own experiment geometry: the box under the Kershaw map (run.py:25-47, run.sh:30: eps_0.3) ----------------
+    # Every factor array is full there (g4..g6 = 0 on the box), the operator is far worse conditioned, and the preconditioner
+    # shows its real behaviour (the box converges in 3 iterations with the V-cycle inside).  One rank: a second problem of the
+    # same size; N ranks: run the whole line with --mesh kershaw instead.
+    kershaw_leg = None
+    if world == 1 and args.mesh == "box" and not args.no_kershaw and not args.no_precond and not args.no_reference_default and not args.amg:
+        kp = None
+        try:
+            kp = H.Problem.kershaw(E, P, N, args.reduction, args.eps, with_subdomain=True)
+        except Exception as exc:
+            kershaw_leg = {"error": str(exc)[:300]}
+        if kp is not None:
+            _, kf = kp.make_rhs(function_id=4, seed=1234 + rank)
+            kp.set_flag("affine_geometry", 1)
+            kdev = kp.affine_info()["max_deviation"]
+            kp.set_flag("affine_geometry", 0)
+            configure(False, 64, problem=kp)
+            dk, lrk, _ = timed_steps(args.steps, min(args.warmup, 2), False, problem=kp, rhs=kf)
+            kershaw_leg = {"mesh": f"{E[0]}x{E[1]}x{E[2]} elements under the Kershaw map, eps_y = eps_z = {args.eps} (host/box_mesh.hpp; the reference's meshes are Nek5000 exports of this case)",
+                           "max_deviation_of_the_mesh_factors": kdev,
+                           "headline": {"preconditioner": "fdd_gmres4 (no V-cycle)", "ms_per_step": dk / args.steps * 1e3, "value": nodes * args.steps / dk, "last_residual_norm": lrk}}
+            if not args.no_time_to_tolerance:
+                kershaw_leg["headline"]["to_1e-7"] = to_tolerance(kp, kf)
+            progress("Kershaw leg: headline done")
+            configure(True, 64, problem=kp)
+            dk, lrk, _ = timed_steps(args.steps, min(args.warmup, 2), False, problem=kp, rhs=kf)
+            kershaw_leg["reference_default"] = {"ms_per_step": dk / args.steps * 1e3, "value": nodes * args.steps / dk, "last_residual_norm": lrk, "amg_levels": amg_states[id(kp)]["levels"], "amg_setup_s": amg_states[id(kp)]["setup_s"]}
+            if not args.no_time_to_tolerance:
+                kershaw_leg["reference_default"]["to_1e-7"] = to_tolerance(kp, kf)
+                kershaw_leg["reference_default"]["gmres_to_1e-7"] = to_tolerance(kp, kf, "gmres")
+                configure(True, 32, problem=kp)
+                kershaw_leg["reference_default"]["f32_to_1e-7"] = to_tolerance(kp, kf)
+            progress("Kershaw leg: reference default done")
+            kp.close()
 
     info = prob.refresh()
     if args.no_precond:
@@ -637,7 +717,10 @@ def run(args, rank, world, max_over_ranks, comm_label):
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"3D Poisson, {E[0]}x{E[1]}x{E[2]} elements ({e}^3 per GPU), N={N}, flexible PCG + " + pre_text,
+            "workload": f"3D Poisson, {E[0]}x{E[1]}x{E[2]} elements ({e}^3 per GPU), N={N}, " + ("flexible PCG" if args.outer == "fcg" else "flexible GMRES(20)") + " + " + pre_text
+                        + ("" if args.mesh == "box" else f", Kershaw mesh eps = {args.eps}"),
+            "outer": args.outer,
+            "mesh": args.mesh,
             "elements": list(E),
             "rank_grid": list(P),
             "poly_degree": N,
@@ -659,6 +742,8 @@ def run(args, rank, world, max_over_ranks, comm_label):
         "roofline": roofline,
         "spmv": spmv,
         "reference_default": reference_default,
+        "reference_default_gmres": reference_default_gmres,
+        "kershaw": kershaw_leg,
         "kernels": table,
     }
     if world > 1:

@@ -54,6 +54,10 @@ int fddh_comm_callbacks_ex(int rank, int size, void *ctx, fddh_allreduce_fn allr
  * fddh_comm_local with its rank. */
 int fddh_local_world_create(void **world, int size);
 int fddh_local_world_destroy(void *world);
+/* a rank of the world failed outside a collective (its thread raised): wake the peers waiting for it with an error now */
+int fddh_local_world_fail(void *world);
+/* end of a rank thread: release what fddh_init(own_stream) / fddh_comm_* gave the calling thread (stream, communicator) */
+int fddh_rank_finalize(void);
 int fddh_comm_local(void *world, int rank);
 int fddh_comm_info(int *rank, int *size, char *name, size_t name_len);
 /* run every collective of the active communicator once on n doubles and verify the results */

@@ -525,9 +525,17 @@ class LocalComm : public Comm
         dev().finish();
         w_->send[rank] = send_dev;
         w_->meet();
-        for (int r = 0; r < size; r++)
-            if (bytes) FDD_CALL(fdd_memcpy_d2d((char *)recv_dev + (size_t)r * bytes, w_->send[r], bytes, stream));
-        dev().finish();
+        try
+        {
+            for (int r = 0; r < size; r++)
+                if (bytes) FDD_CALL(fdd_memcpy_d2d((char *)recv_dev + (size_t)r * bytes, w_->send[r], bytes, stream));
+            dev().finish();
+        }
+        catch (...)
+        {
+            w_->fail(); // the peers are on their way to the second meeting point: an error there, not a wait
+            throw;
+        }
         w_->meet();
     }
     void exchange(const ExchangeOp *ops, int n) override
@@ -539,23 +547,31 @@ class LocalComm : public Comm
         w_->ops[rank].assign(ops, ops + std::max(n, 0));
         w_->meet();
         std::string error;
-        for (int i = 0; i < n and error.empty(); i++)
+        try
         {
-            if (ops[i].recv_bytes == 0) continue;
-            const ExchangeOp *theirs = nullptr;
-            for (const ExchangeOp &o : w_->ops[ops[i].peer])
-                if (o.peer == rank) theirs = &o;
-            if (theirs == nullptr or theirs->send_bytes != ops[i].recv_bytes)
-                error = "local world: rank " + std::to_string(rank) + " expects " + std::to_string(ops[i].recv_bytes) + " bytes from rank " + std::to_string(ops[i].peer) + ", which sends " + std::to_string(theirs ? theirs->send_bytes : 0);
-            else
-                FDD_CALL(fdd_memcpy_d2d(ops[i].recv, theirs->send, ops[i].recv_bytes, stream));
+            for (int i = 0; i < n and error.empty(); i++)
+            {
+                if (ops[i].recv_bytes == 0) continue;
+                const ExchangeOp *theirs = nullptr;
+                for (const ExchangeOp &o : w_->ops[ops[i].peer])
+                    if (o.peer == rank) theirs = &o;
+                if (theirs == nullptr or theirs->send_bytes != ops[i].recv_bytes)
+                    error = "local world: rank " + std::to_string(rank) + " expects " + std::to_string(ops[i].recv_bytes) + " bytes from rank " + std::to_string(ops[i].peer) + ", which sends " + std::to_string(theirs ? theirs->send_bytes : 0);
+                else
+                    FDD_CALL(fdd_memcpy_d2d(ops[i].recv, theirs->send, ops[i].recv_bytes, stream));
+            }
+            if (error.empty()) dev().finish();
+        }
+        catch (...)
+        {
+            w_->fail();
+            throw;
         }
         if (not error.empty())
         {
             w_->fail();
             throw CommError(error);
         }
-        dev().finish();
         w_->meet();
     }
     void barrier() override

@@ -123,7 +123,7 @@ class Domain
     fdd::memory node_stitch;              // local multiplicity * assembled weight * mask
     std::vector<DType> node_stitch_hst, node_mask_hst;
     bool norm_on_dof_slice = false;       // one rank, mask = indicator of the dof slice: the masked node norm is the slice's plain norm
-    const void *norm_shared_from = nullptr;
+    const double *pending_rhs_norm2 = nullptr; // what node_norm_enqueue returned for the residual the next precondition_nodes call receives
     bool stitch_is_one = false;           // every weight of the dof slice is exactly 1.0 (setup_dof_maps)
     fdd::memory node_of_dof, dof_of_node; // renumbering to / from the subdomain's dofs
     int nodes_sub_dofs = -1;
@@ -856,7 +856,10 @@ class Domain
     // fetched when the host wants it, which may be after more work has been enqueued.
     // defer_exchange: the boundary prefix is only saved; its exchange rides with the stitching exchange of the
     // preconditioner that follows (precondition_nodes), which then finishes the norm (node_norm_finish)
-    void node_norm_enqueue(fdd::memory &rn, bool defer_exchange = false)
+    // Returns the device address of |r^ restricted to the dof slice|^2 when -- and only when -- the sum just enqueued IS that
+    // number (one rank, shared_residual_norm): the caller hands it to the precondition_nodes call that receives the same,
+    // unmodified rn (the inner solve's first norm); every other branch returns nullptr.
+    const double *node_norm_enqueue(fdd::memory &rn, bool defer_exchange = false)
     {
         const int nn = num_local_nodes;
         // every rank of a multi-rank run takes the two-part path (a rank without shared nodes contributes an empty
@@ -874,13 +877,14 @@ class Domain
             if (defer_exchange)
             {
                 norm_deferred = true;
-                return;
+                return nullptr;
             }
             gs_add_boundary(nprefix);
             node_norm_finish();
-            return;
+            return nullptr;
         }
-        else if (norm_on_dof_slice and shared_residual_norm)
+        const double *known = nullptr;
+        if (norm_on_dof_slice and shared_residual_norm)
         {
             // One rank, mask = 1 on the dof slice and 0 elsewhere: the masked sum over the nodes IS the plain sum over the
             // slice -- the sum the inner solve forms first (its right-hand side is this slice, read in place).  Formed once,
@@ -888,17 +892,17 @@ class Domain
             // recorded norm differs from the masked form in how its terms are grouped.
             const double *self[1] = {rn.as<double>() + dof_shift};
             FDD_CALL(fdd_multi_weighted_inner_product_scaled(out, reduce_ws.as<double>(), self[0], self, nullptr, 1, nullptr, nodes_sub_dofs, fdd::dev().stream));
-            norm_shared_from = rn.ptr();
+            known = out;
         }
         else
         {
             // sum r*r*mask with r read once (the arithmetic and the reduction tree of residual_norm_kernel, domain.okl:109-138)
-            norm_shared_from = nullptr;
             const double *self[1] = {rn.as<double>()};
             FDD_CALL(fdd_multi_weighted_inner_product(out, reduce_ws.as<double>(), rn.as<double>(), self, 1, node_mask.as<double>(), nn, fdd::dev().stream));
         }
         norm_parts = 1;
         if (fdd::comm().size > 1) fdd::comm().allreduce_sum(out, norm_parts);
+        return known;
     }
 
     // the boundary part of the norm once the saved prefix has been exchanged, then the all-reduce of both parts
@@ -921,15 +925,18 @@ class Domain
         return std::sqrt(v[0] + v[1]);
     }
 
-    void node_norm(DType &r_norm, fdd::memory &rn)
+    const double *node_norm(DType &r_norm, fdd::memory &rn)
     {
-        node_norm_enqueue(rn);
+        const double *known = node_norm_enqueue(rn);
         r_norm = node_norm_fetch();
+        return known;
     }
 
     // z~ = M^-1 r^ and the stitching (domain.tpp:639-645, 697-706)
+    // rhs_norm2: device address of |rn's dof slice|^2 if the caller has just formed it from this very rn (node_norm_enqueue's
+    // return value), else nullptr
     template <typename PType>
-    void precondition_nodes(fdd::memory &zn, fdd::memory &rn, PType &subdomain)
+    void precondition_nodes(fdd::memory &zn, fdd::memory &rn, PType &subdomain, const double *rhs_norm2 = nullptr)
     {
         void *stream = fdd::dev().stream;
         if (use_preconditioner)
@@ -950,7 +957,7 @@ class Domain
                 // place as well: the multiplication below would be x * 1.0
                 fdd::memory f_slice = rn.slice(dof_shift, nodes_sub_dofs);
                 // the norm of this very slice was formed a moment ago (node_norm_enqueue): the inner solve starts from it
-                subdomain.known_rhs_norm2_dev = (norm_on_dof_slice and shared_residual_norm and norm_shared_from == rn.ptr()) ? scalars.as<double>() + 4 : nullptr;
+                subdomain.known_rhs_norm2_dev = rhs_norm2;
                 if (stitch_is_one and unit_stitch_in_place)
                 {
                     fdd::memory z_slice = zn.slice(dof_shift, nodes_sub_dofs);
@@ -959,7 +966,6 @@ class Domain
                 else
                     subdomain.gmres_dofs(sub_u, f_slice);
                 subdomain.known_rhs_norm2_dev = nullptr;
-                norm_shared_from = nullptr;
             }
             else
             {
@@ -1017,11 +1023,11 @@ class Domain
         FDD_CALL(fdd_set_to_value(nu.as<double>(), 0.0, num_local_nodes, 0, fdd::dev().stream));
         FDD_CALL(fdd_set_to_value(nz.as<double>(), 0.0, num_local_nodes, 0, fdd::dev().stream));
 
-        node_norm(fcg_r_0_norm, nr);
+        const double *r0_norm2 = node_norm(fcg_r_0_norm, nr);
         residual_history.push_back(fcg_r_0_norm);
         rstdout("Iter %2d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", 0, fcg_r_0_norm, 1.0);
 
-        precondition_nodes(nz, nr, subdomain);
+        precondition_nodes(nz, nr, subdomain, r0_norm2);
         np.copyFrom(nz, (size_t)num_local_nodes * sizeof(DType));
         gamma_on_device = false; // the first iteration's projection kernel forms gamma itself
     }
@@ -1056,7 +1062,7 @@ class Domain
             FDD_CALL(fdd_dom_solution_and_residual_update_dev(nu.as<double>(), nr1.as<double>(), nr.as<double>(), np.as<double>(), nq.as<double>(), scalars.as<double>() + gamma_slot, scalars.as<double>() + 1, nn, stream));
             if (use_preconditioner and composite_precond) // r+ = r - alpha q on the points too (domain.okl:191), alpha from device memory
                 FDD_CALL(fdd_xmay_ratio_dev(rp.as<double>(), rp.as<double>(), scalars.as<double>() + gamma_slot, scalars.as<double>() + 1, q_k.as<double>(), num_local_points, stream));
-            node_norm_enqueue(nr1, /*defer_exchange=*/true); // finished inside the preconditioner's exchange
+            pending_rhs_norm2 = node_norm_enqueue(nr1, /*defer_exchange=*/true); // finished inside the preconditioner's exchange
             fcg_norm_pending = true;
             return std::numeric_limits<DType>::quiet_NaN(); // fcg_nodes_norm() has the value
         }
@@ -1067,7 +1073,7 @@ class Domain
         FDD_CALL(fdd_dom_solution_and_residual_update(nu.as<double>(), nr1.as<double>(), nr.as<double>(), np.as<double>(), nq.as<double>(), alpha_k, nn, stream));
         if (use_preconditioner and composite_precond) FDD_CALL(fdd_vector_vector_addition(rp.as<double>(), 1.0, rp.as<double>(), -alpha_k, q_k.as<double>(), num_local_points, stream));
 
-        node_norm(r_norm, nr1);
+        pending_rhs_norm2 = node_norm(r_norm, nr1);
         residual_history.push_back(r_norm);
         rstdout("Iter %2d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", fcg_iter + 1, r_norm, r_norm / fcg_r_0_norm);
         return r_norm;
@@ -1088,7 +1094,8 @@ class Domain
     {
         const int nn = num_local_nodes;
         DType theta_k;
-        precondition_nodes(nz, nr1, subdomain);
+        precondition_nodes(nz, nr1, subdomain, pending_rhs_norm2); // nr1 is untouched since its norm was enqueued (fcg_nodes_step_residual)
+        pending_rhs_norm2 = nullptr;
         if (device_scalars)
         {
             // beta = scalars[3] / scalars[0] (theta / gamma), read by the update kernel; the residual norm's two

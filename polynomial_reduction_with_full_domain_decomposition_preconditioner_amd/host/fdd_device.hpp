@@ -37,6 +37,8 @@ inline void check(int rc, const char *what)
 struct device_t
 {
     void *stream = nullptr; // hipStream_t all kernels of this rank run on
+    bool owns_stream = false; // created by fddh_init(own_stream): released by fddh_rank_finalize
+    bool initialised = false; // fddh_init ran on this thread (a null stream alone cannot tell: it is also the legacy default stream)
 
     template <typename T>
     class memory malloc(size_t n);

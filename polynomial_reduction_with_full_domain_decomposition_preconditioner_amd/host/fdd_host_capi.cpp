@@ -44,6 +44,11 @@ struct fddh_problem
     std::unique_ptr<Subdomain<PType>> subdomain;
     NoPreconditioner none;
 
+    // The rank (= host thread) that built the problem: its device stream, communicator and globals are thread_local, so a
+    // call from any other thread would silently run on the legacy default stream with a one-rank communicator (every
+    // collective skipped: wrong sums, or peers hanging in RCCL).  Every fddh_problem_* entry checks it (rank_check).
+    const void *owner = nullptr;
+
     // device staging vectors
     fdd::memory a, b, c;
     fdd::memory sa, sb; // subdomain-sized
@@ -51,6 +56,17 @@ struct fddh_problem
     Domain<SType> &fine() { return domains[poly_degree]; }
     const Domain<SType> &fine() const { return domains.at(poly_degree); }
 };
+
+// identity of the calling rank's per-thread state
+static const void *this_rank() { return &fdd::dev(); }
+
+// 0 when the calling thread is an initialised rank (fddh_init) and, for a problem, the one that built it
+static int rank_check(const fddh_problem *p = nullptr)
+{
+    if (!fdd::dev().initialised) return fail("fddh_init has not been called on this thread: the host layer's device stream and communicator are per rank = per host thread");
+    if (p && p->owner != this_rank()) return fail("this problem was built by another rank (host thread); its stream and communicator are not the calling thread's");
+    return 0;
+}
 
 static std::vector<int> level_degrees(int N, int reduction)
 {
@@ -77,6 +93,7 @@ static void setup_lap(const char *what, int degree, double &mark)
 static void finish_problem(fddh_problem *p, int flags, int sub_overlap, int sup_overlap)
 {
     double mark = setup_clock();
+    p->owner = this_rank();
     const int with_subdomain = flags & FDDH_WITH_SUBDOMAIN;
     Domain<SType> &dom = p->fine();
     p->a = fdd::dev().malloc<double>(dom.num_local_points);
@@ -115,7 +132,9 @@ int fddh_init(int device, void *stream, int own_stream)
             if (fdd_stream_create(&s) != 0) return fail("fdd_stream_create: %s", fdd_last_error());
             stream = s;
         }
+        fdd::dev().owns_stream = own_stream != 0;
         fdd::dev().stream = stream;
+        fdd::dev().initialised = true;
         return 0;
     }
     catch (const std::exception &e)
@@ -183,6 +202,7 @@ int fddh_comm_single(void)
 {
     try
     {
+        if (int rc = rank_check()) return rc;
         fdd::set_comm(new fdd::SingleComm());
         fdd::globals().proc_id = 0;
         fdd::globals().num_procs = 1;
@@ -214,10 +234,45 @@ int fddh_local_world_destroy(void *world)
     return 0;
 }
 
+int fddh_local_world_fail(void *world)
+{
+    try
+    {
+        if (!world) return fail("null argument");
+        (*static_cast<std::shared_ptr<fdd::LocalWorld> *>(world))->fail();
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return fail("%s", e.what());
+    }
+}
+
+int fddh_rank_finalize(void)
+{
+    try
+    {
+        fdd::device_t &d = fdd::dev();
+        if (!d.initialised) return 0;
+        if (d.stream) fdd_stream_sync(d.stream);
+        fdd::set_comm(new fdd::SingleComm()); // deletes the thread's communicator (and its device scratch)
+        if (d.owns_stream && d.stream) fdd_stream_destroy(d.stream);
+        d.stream = nullptr;
+        d.owns_stream = false;
+        d.initialised = false;
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return fail("%s", e.what());
+    }
+}
+
 int fddh_comm_local(void *world, int rank)
 {
     try
     {
+        if (int rc = rank_check()) return rc;
         if (!world) return fail("null argument");
         std::shared_ptr<fdd::LocalWorld> w = *static_cast<std::shared_ptr<fdd::LocalWorld> *>(world);
         if (rank < 0 || rank >= w->size) return fail("bad rank");
@@ -251,6 +306,7 @@ int fddh_comm_rccl_init(const char *id128, int rank, int size)
 {
     try
     {
+        if (int rc = rank_check()) return rc;
         if (!id128 || rank < 0 || size < 1 || rank >= size) return fail("bad rank/size");
         fdd::RcclComm *c = new fdd::RcclComm();
         c->init(id128, rank, size);
@@ -269,6 +325,7 @@ int fddh_comm_callbacks(int rank, int size, void *ctx, fddh_allreduce_fn allredu
 {
     try
     {
+        if (int rc = rank_check()) return rc;
         if (rank < 0 || size < 1 || rank >= size || !allreduce_sum_f64 || !allreduce_max_f64 || !allgather_bytes || !barrier) return fail("bad callback set");
         fdd::CommCallbacks cb;
         cb.ctx = ctx;
@@ -292,6 +349,7 @@ int fddh_comm_callbacks_ex(int rank, int size, void *ctx, fddh_allreduce_fn allr
 {
     try
     {
+        if (int rc = rank_check()) return rc;
         if (rank < 0 || size < 1 || rank >= size || !allreduce_sum_f64 || !allreduce_max_f64 || !allgather_bytes || !barrier || !exchange_bytes) return fail("bad callback set");
         fdd::CommCallbacks cb;
         cb.ctx = ctx;
@@ -317,6 +375,7 @@ int fddh_comm_selftest(int n)
 {
     try
     {
+        if (int rc = rank_check()) return rc;
         if (n < 1) return fail("n must be positive");
         fdd::Comm &c = fdd::comm();
         const int R = c.size, me = c.rank;
@@ -415,6 +474,7 @@ int fddh_comm_info(int *rank, int *size, char *name, size_t name_len)
 {
     try
     {
+        if (int rc = rank_check()) return rc;
         if (rank) *rank = fdd::comm().rank;
         if (size) *size = fdd::comm().size;
         if (name && name_len) snprintf(name, name_len, "%s", fdd::comm().name());
@@ -430,6 +490,7 @@ int fddh_problem_create_box(fddh_problem **out, const int E[3], const int P[3], 
 {
     try
     {
+        if (int rc = rank_check()) return rc;
         return fddh_problem_create_box_ex(out, E, P, poly_degree, poly_reduction, 1, 1, with_subdomain ? FDDH_WITH_SUBDOMAIN : 0);
     }
     catch (const std::exception &e)
@@ -447,6 +508,7 @@ int fddh_problem_create_kershaw_ex(fddh_problem **out, const int E[3], const int
 {
     try
     {
+        if (int rc = rank_check()) return rc;
         if (!(eps_y > 0.0 && eps_y <= 1.0 && eps_z > 0.0 && eps_z <= 1.0)) return fail("Kershaw eps must lie in (0, 1]");
         const int with_subdomain = flags & FDDH_WITH_SUBDOMAIN;
         if (!out || !E || !P || poly_degree < 1 || poly_reduction < 1) return fail("bad argument");
@@ -494,6 +556,7 @@ int fddh_problem_create_dir(fddh_problem **out, const char *directory, int poly_
 {
     try
     {
+        if (int rc = rank_check()) return rc;
         return fddh_problem_create_dir_ex(out, directory, poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, with_subdomain ? FDDH_WITH_SUBDOMAIN : 0);
     }
     catch (const std::exception &e)
@@ -506,6 +569,7 @@ int fddh_problem_create_dir_ex(fddh_problem **out, const char *directory, int po
 {
     try
     {
+        if (int rc = rank_check()) return rc;
         const int with_subdomain = flags & FDDH_WITH_SUBDOMAIN;
         if (!out || !directory || poly_degree < 1 || poly_reduction < 1) return fail("bad argument");
         fddh_problem *p = new fddh_problem();
@@ -538,6 +602,7 @@ int fddh_problem_destroy(fddh_problem *p)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         // Like the reference (empty destructors, domain.tpp:24-28), device memory of
         // the host classes is released at process end; the staging vectors are freed.
         if (!p) return 0;
@@ -592,6 +657,7 @@ int fddh_problem_info(const fddh_problem *p, long long *info, int n)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !info) return fail("null argument");
         const Domain<SType> &d = p->fine();
         long long v[FDDH_INFO_COUNT];
@@ -620,6 +686,7 @@ int fddh_problem_sub_info(const fddh_problem *p, long long *info, int n)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !info) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         const Subdomain<PType> &s = *p->subdomain;
@@ -653,6 +720,7 @@ int fddh_problem_sub_region(const fddh_problem *p, int *element, int *level, int
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !element || !level) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         const Subdomain<PType> &s = *p->subdomain;
@@ -676,6 +744,7 @@ int fddh_problem_sub_composite_levels(const fddh_problem *p, int *kept, int n, i
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !num_levels) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         const fdd::composite::Composite &c = p->subdomain->composite_description();
@@ -693,6 +762,7 @@ int fddh_problem_level_degree(const fddh_problem *p, int level, int *poly_degree
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !poly_degree || level < 0 || level >= (int)p->degrees.size()) return fail("bad level");
         *poly_degree = p->degrees[level];
         return 0;
@@ -707,6 +777,7 @@ int fddh_problem_mesh_array(const fddh_problem *p, int level, const char *name, 
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !name || !out || level < 0 || level >= (int)p->degrees.size()) return fail("bad argument");
         const MeshData<SType> &m = p->domains.at(p->degrees[level]).mesh;
         const void *src = nullptr;
@@ -771,6 +842,7 @@ int fddh_problem_set_D_hat(fddh_problem *p, int level, const double *D_hat, int 
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !D_hat || level < 0 || level >= (int)p->degrees.size()) return fail("bad argument");
         if (n != p->degrees[level] + 1) return fail("D_hat of level %d is %d x %d", level, p->degrees[level] + 1, p->degrees[level] + 1);
         p->domains[p->degrees[level]].set_D_hat(D_hat, n);
@@ -786,6 +858,7 @@ int fddh_problem_get_D_hat(const fddh_problem *p, int level, double *D_hat, int 
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !D_hat || level < 0 || level >= (int)p->degrees.size()) return fail("bad argument");
         if (n != p->degrees[level] + 1) return fail("wrong size");
         const std::vector<double> &D = p->domains.at(p->degrees[level]).D_hat_hst;
@@ -802,6 +875,7 @@ int fddh_problem_set_options(fddh_problem *p, int max_iterations, double toleran
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p) return fail("null argument");
         Domain<SType> &d = p->fine();
         if (max_iterations >= 0) d.max_iterations = max_iterations;
@@ -831,6 +905,7 @@ int fddh_problem_affine_info(fddh_problem *p, int *fine_domain_affine, int *sub_
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p) return fail("null argument");
         Domain<SType> &dom = p->fine();
         double worst = dom.affine_deviation;
@@ -858,6 +933,7 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !name) return fail("null argument");
         const std::string s(name);
         if (s == "fused_dssum")
@@ -954,6 +1030,7 @@ int fddh_problem_sub_point_dofs(const fddh_problem *p, int *dof, int n)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !dof) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         if (n != (int)p->subdomain->point_dof.size()) return fail("the subdomain region has %d points", (int)p->subdomain->point_dof.size());
@@ -970,6 +1047,7 @@ int fddh_problem_amg_add_level(fddh_problem *p, int n, const int *A_ptr, const i
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !A_ptr || !A_col || !A_val || !D_val || !coefs) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         Subdomain<SType> &s = *p->subdomain;
@@ -996,6 +1074,7 @@ int fddh_problem_amg_finalize(fddh_problem *p)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         if (p->subdomain->amg_hierarchy.levels.empty()) return fail("no AMG level was added");
@@ -1013,6 +1092,7 @@ int fddh_problem_amg_build(fddh_problem *p, int coarsest_size, double strength, 
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         fdd::low_order::Options o;
@@ -1033,6 +1113,7 @@ int fddh_problem_amg_level_info(const fddh_problem *p, int level, int *n, int *n
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !p->subdomain) return fail("no Subdomain");
         const auto &lv = p->subdomain->amg_hierarchy.levels;
         if (level < 0 || level >= (int)lv.size()) return fail("the hierarchy has %d levels", (int)lv.size());
@@ -1081,6 +1162,7 @@ int fddh_problem_amg_apply(fddh_problem *p, const double *r, double *z)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !r || !z) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         if (!p->subdomain->amg_hierarchy.ready()) return fail("no finalized AMG hierarchy is attached");
@@ -1100,6 +1182,7 @@ int fddh_problem_dssum(fddh_problem *p, double *out, const double *in, int apply
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !out || !in) return fail("null argument");
         Domain<SType> &d = p->fine();
         const size_t bytes = (size_t)d.num_local_points * sizeof(double);
@@ -1118,6 +1201,7 @@ int fddh_problem_stiffness(fddh_problem *p, double *out, const double *in, int a
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !out || !in) return fail("null argument");
         Domain<SType> &d = p->fine();
         const size_t bytes = (size_t)d.num_local_points * sizeof(double);
@@ -1136,6 +1220,7 @@ int fddh_problem_residual_norm(fddh_problem *p, const double *r, double *norm)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !r || !norm) return fail("null argument");
         Domain<SType> &d = p->fine();
         const size_t bytes = (size_t)d.num_local_points * sizeof(double);
@@ -1163,6 +1248,7 @@ int fddh_problem_make_rhs(fddh_problem *p, int function_id, unsigned long long s
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p) return fail("null argument");
         Domain<SType> &d = p->fine();
         const size_t bytes = (size_t)d.num_local_points * sizeof(double);
@@ -1182,6 +1268,7 @@ int fddh_problem_make_rhs_from(fddh_problem *p, double *u_star_inout, double *f)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !u_star_inout) return fail("null argument");
         Domain<SType> &d = p->fine();
         const size_t bytes = (size_t)d.num_local_points * sizeof(double);
@@ -1202,6 +1289,7 @@ int fddh_problem_solve(fddh_problem *p, int solver_id, const double *f, double *
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !f || !u) return fail("null argument");
         Domain<SType> &d = p->fine();
         const size_t bytes = (size_t)d.num_local_points * sizeof(double);
@@ -1240,6 +1328,7 @@ int fddh_problem_solve_timed(fddh_problem *p, int solver_id, const double *f, do
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !f || !seconds) return fail("null argument");
         Domain<SType> &d = p->fine();
         const size_t bytes = (size_t)d.num_local_points * sizeof(double);
@@ -1281,6 +1370,7 @@ int fddh_problem_precond_apply(fddh_problem *p, int type, const double *r, doubl
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !r || !z) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         Domain<SType> &d = p->fine();
@@ -1308,6 +1398,7 @@ int fddh_problem_sub_op(fddh_problem *p, int op, const double *in, double *out)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !in || !out) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         Subdomain<PType> &s = *p->subdomain;
@@ -1341,6 +1432,7 @@ int fddh_problem_sub_dof_op(fddh_problem *p, int op, const double *in, double *o
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !in || !out) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         Subdomain<PType> &s = *p->subdomain;
@@ -1367,6 +1459,7 @@ int fddh_problem_sub_jacobi_diagonal(fddh_problem *p, double *out, int n)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !out) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         const std::vector<double> &d = p->subdomain->jacobi_diagonal();
@@ -1384,6 +1477,7 @@ int fddh_problem_sub_residual_norm(fddh_problem *p, const double *r, double *nor
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !r || !norm) return fail("null argument");
         if (!p->subdomain) return fail("problem was created without a Subdomain");
         p->sa.copyFrom(r, (size_t)p->subdomain->num_values * sizeof(double));
@@ -1400,6 +1494,7 @@ int fddh_problem_pcg_begin(fddh_problem *p, const double *f)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !f) return fail("null argument");
         Domain<SType> &d = p->fine();
         p->a.copyFrom(f, (size_t)d.num_local_points * sizeof(double));
@@ -1419,6 +1514,7 @@ int fddh_problem_pcg_steps(fddh_problem *p, int steps, double *last_residual)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || steps < 0) return fail("bad argument");
         Domain<SType> &d = p->fine();
         double r = std::numeric_limits<double>::quiet_NaN();
@@ -1439,6 +1535,7 @@ int fddh_problem_pcg_solution(fddh_problem *p, double *u)
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !u) return fail("null argument");
         p->fine().fcg_finish();
         p->b.copyTo(u, (size_t)p->fine().num_local_points * sizeof(double));
@@ -1457,6 +1554,7 @@ int fddh_problem_spmv_time(fddh_problem *p, int which, int iterations, double *a
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !avg_us || !algorithmic_bytes || iterations < 1 || which < 0 || which > 1) return fail("bad argument");
         Domain<SType> &d = p->fine();
         CSR_Matrix<SType> &A = (which == 0) ? d.scatter_matrix() : d.gather_matrix();
@@ -1490,6 +1588,7 @@ int fddh_problem_comm_time(fddh_problem *p, int iterations, double *avg_us, doub
 {
     try
     {
+        if (int rc = rank_check(p)) return rc;
         if (!p || !avg_us || !bytes || iterations < 1) return fail("bad argument");
         for (int k = 0; k < 4; k++) avg_us[k] = bytes[k] = 0.0;
         fdd::Comm &c = fdd::comm();

@@ -133,6 +133,15 @@ def run_local_ranks(size: int, fn, device: int = 0, init_device: bool = True):
             results[r] = fn(r, size)
         except BaseException as exc:  # noqa: BLE001 - reported to the caller below
             errors[r] = exc
+            try:
+                _H().call("fddh_local_world_fail", world)  # the peers waiting for this rank get an error now, not after the timeout
+            except Exception:  # noqa: BLE001
+                pass
+        finally:
+            try:
+                _H().call("fddh_rank_finalize")  # the rank's own stream and communicator end with its thread
+            except Exception:  # noqa: BLE001
+                pass
 
     threads = [threading.Thread(target=body, args=(r,), name="fdd-rank-%d" % r) for r in range(size)]
     for t in threads:
@@ -142,9 +151,9 @@ def run_local_ranks(size: int, fn, device: int = 0, init_device: bool = True):
     local_world_destroy(world)
     if shared_cores:
         os.environ.pop("FDD_HOST_THREADS", None)
-    for e in errors:
-        if e is not None:
-            raise e
+    first = [e for e in errors if e is not None and "a peer rank failed" not in str(e)] or [e for e in errors if e is not None]
+    if first:
+        raise first[0]  # the rank that failed first, not a peer's "a peer rank failed"
     return results
 
 

@@ -1035,3 +1035,17 @@ def kershaw_mesh_of_the_host_layer(host_lib, directory, E, N, eps, P=(1, 1, 1), 
     twin.x, twin.y, twin.z = a["x"], a["y"], a["z"]
     twin.g = [a["g_%d" % (k + 1)] for k in range(6)]
     return twin
+
+
+def oracle_stiffness(u, G, D, N, dim=3):
+    """The oracle's two-kernel element stiffness (domain.okl:5-98) on plain arrays: (Au, GDu)."""
+    L = oracle()
+    vp = ctypes.c_void_p
+    npts = len(u)
+    GDu = [np.zeros(npts) for _ in range(3)]
+    Au = np.zeros(npts)
+    gd = (vp * 3)(*[a.ctypes.data for a in GDu])
+    gg = (vp * 6)(*[a.ctypes.data for a in G])
+    L.orc_dom_stiffness_matrix_1(gd, _p(u), _p(D), gg, npts, N, dim)
+    L.orc_dom_stiffness_matrix_2(_p(Au), gd, _p(D), npts, N, dim)
+    return Au, GDu
