@@ -96,8 +96,8 @@ def parse():
     ap.add_argument("--no-kershaw", action="store_true", help="skip the `kershaw` leg (a second problem on the deformed mesh)")
     ap.add_argument("--print-launch", action="store_true", help="print the launcher command `--gpus N` would start (JSON list) and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-elements", type=int, default=20)
-    ap.add_argument("--cpu-sample-steps", type=int, default=12)
+    ap.add_argument("--cpu-sample-elements", type=int, default=32, help="elements per direction and rank of the CPU baseline's sample (32 = the workload itself, config C2)")
+    ap.add_argument("--cpu-sample-steps", type=int, default=3, help="outer PCG iterations of the sample (one rank at C2: about 6 s each on the box's host)")
     return ap.parse_args()
 
 
@@ -121,7 +121,7 @@ def cpu_baseline(args, world, P):
 
     N, red = args.degree, args.reduction
     composite_sample = world > 1 and args.composite_headline and not args.block_local  # the oracle's composites cost a setup of their own: a smaller cube
-    e = args.cpu_sample_elements if world == 1 else max(4, int(round((0.6 if composite_sample else 1.0) * args.cpu_sample_elements / world ** (1.0 / 3.0))))
+    e = args.cpu_sample_elements if world == 1 else max(4, int(round((0.6 if composite_sample else 1.0) * min(args.cpu_sample_elements, 20) / world ** (1.0 / 3.0))))
     E = tuple(e * p for p in P)
     deg = S.level_degrees(N, red)
     t_setup = time.perf_counter()
@@ -174,7 +174,7 @@ def cpu_baseline_ranks(args, world, P):
     import subprocess
 
     composite = args.composite_headline and not args.block_local
-    e = max(4, int(round((0.6 if composite else 1.0) * args.cpu_sample_elements)))  # per rank: about 10 s of work on every core
+    e = max(4, int(round((0.6 if composite else 1.0) * min(args.cpu_sample_elements, 20))))  # per rank: about 10 s of work on every core (N ranks: a 20^3 sample per rank at most, the N cores share the host's memory system)
     steps = args.cpu_sample_steps
     script = os.path.join(ROOT, "tests", "cpu_baseline_ranks.py")
     out = subprocess.run([sys.executable, script, str(world), str(e), str(args.degree), str(args.reduction), str(steps), "0" if composite else "1"], capture_output=True, text=True, timeout=900)

@@ -148,6 +148,23 @@ __device__ __forceinline__ int fdd_xcd_chunked_block(int bid, int nblocks)
     return xcd * per + (xcd < rem ? xcd : rem) + idx;
 }
 
+// XCD-windowed order: the chunked order above sends the eight XCDs to eight far-apart eighths of the index range (eight
+// distant streams: measured slower on the row-block SpMVs although it removes the double fetches).  Here the range is cut
+// into windows of 8*C consecutive blocks and, inside a window, XCD x (= bid % 8 under round-robin dispatch) takes the C
+// consecutive blocks [x*C, (x+1)*C), one after the other as its workgroups are dispatched: neighbours in index space run
+// on ONE XCD close in time (the sectors / lines they share are fetched into one L2, once), while all eight XCDs stay inside
+// the same window of memory.  C = nblocks / 8 is the chunked order.  A ragged last window keeps the plain order.
+// Bijective; speed only, never correctness (HIP promises no block -> XCD placement).
+__device__ __forceinline__ int fdd_xcd_windowed_block(int bid, int nblocks, int C)
+{
+    if (C <= 1) return bid;
+    const int W = FDD_NUM_XCD * C;
+    const int win = bid / W;
+    if (win >= nblocks / W) return bid;
+    const int in = bid - win * W;
+    return win * W + (in % FDD_NUM_XCD) * C + in / FDD_NUM_XCD;
+}
+
 // integer tuning knob from the environment (read once by the caller: `static const`)
 static inline int fdd_env_int(const char *name, int fallback)
 {

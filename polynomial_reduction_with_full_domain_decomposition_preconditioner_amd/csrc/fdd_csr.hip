@@ -370,12 +370,15 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(T *__restrict__ Au, c
 // The gather half (MODE 1, no weight) on float vectors: the single-precision preconditioner's Qt (subdomain.okl's kernels
 // instantiated with DType = float).  Same staging, the row sums in column order in IEEE single.
 template <int kBlockNnz>
-__global__ __launch_bounds__(kBlock) void gather_block_f32_kernel(float *__restrict__ t, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const float *__restrict__ u, const int *__restrict__ row_blocks, int block_first, int row_lo, int row_hi)
+__global__ __launch_bounds__(kBlock) void gather_block_f32_kernel(float *__restrict__ t, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const float *__restrict__ u, const int *__restrict__ row_blocks, int block_first, int row_lo, int row_hi, int xcd_window)
 {
     __shared__ float x[kBlockNnz];
     __shared__ int sp[kBlockNnz + 1];
     constexpr int kIts = kBlockNnz / kBlock;
-    const int b = block_first + blockIdx.x;
+    // Row blocks follow the node order, which follows the element order: a block gathers the low-face points of the NEXT
+    // element(s), whose 64-byte sectors hold seven more points that the next block gathers.  In XCD-windowed order that
+    // next block runs on the same XCD (fdd_common.h).
+    const int b = block_first + fdd_xcd_windowed_block(blockIdx.x, gridDim.x, xcd_window);
     const int r0 = row_blocks[b] > row_lo ? row_blocks[b] : row_lo;
     const int r1 = row_blocks[b + 1] < row_hi ? row_blocks[b + 1] : row_hi;
     if (r1 <= r0) return;
@@ -506,7 +509,7 @@ int launch_one_per_row(double *Au, const int *A_col, const double *A_val, const 
 // MODE 0: gather + scatter, 1: gather only, 2: scatter only (s read from t).
 // ---------------------------------------------------------------------------
 template <int MODE, bool WEIGHT, bool MASK, int kBlockNnz>
-__global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double *__restrict__ t, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const double *u, const double *__restrict__ node_weight, const double *__restrict__ point_mask, const int *__restrict__ row_blocks, int block_first, int row_lo, int row_hi)
+__global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double *__restrict__ t, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const double *u, const double *__restrict__ node_weight, const double *__restrict__ point_mask, const int *__restrict__ row_blocks, int block_first, int row_lo, int row_hi, int xcd_window)
 {
     __shared__ double x[kBlockNnz];
     constexpr int kBlockRowsMax = kBlockNnz;
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double
     constexpr int kIts = kBlockNnz / kBlock;
     constexpr int kRowIts = kBlockRowsMax / kBlock;
 
-    const int b = block_first + blockIdx.x;
+    const int b = block_first + fdd_xcd_windowed_block(blockIdx.x, gridDim.x, xcd_window); // as in gather_block_f32_kernel
     const int r0 = row_blocks[b] > row_lo ? row_blocks[b] : row_lo;
     const int r1 = row_blocks[b + 1] < row_hi ? row_blocks[b + 1] : row_hi;
     if (r1 <= r0) return;
@@ -1071,10 +1074,11 @@ int fdd_csr_plan_gather_f32(const fdd_csr_plan *plan, float *t, const int *Qt_pt
     if (last > plan->num_blocks) last = plan->num_blocks;
     if (last <= first) return 0;
     const dim3 grid(last - first), block(kBlock);
+    static const int xcd_window = fdd_env_int("FDD_TUNE_DSSUM_XCD_WINDOW", 0);
     if (plan->block_nnz == kBlockNnzSmall)
-        hipLaunchKernelGGL((gather_block_f32_kernel<kBlockNnzSmall>), grid, block, 0, fdd_stream(stream), t, Qt_ptr, Qt_col, u, plan->row_blocks_dev, first, row_lo, row_hi);
+        hipLaunchKernelGGL((gather_block_f32_kernel<kBlockNnzSmall>), grid, block, 0, fdd_stream(stream), t, Qt_ptr, Qt_col, u, plan->row_blocks_dev, first, row_lo, row_hi, xcd_window);
     else
-        hipLaunchKernelGGL((gather_block_f32_kernel<kBlockNnzMax>), grid, block, 0, fdd_stream(stream), t, Qt_ptr, Qt_col, u, plan->row_blocks_dev, first, row_lo, row_hi);
+        hipLaunchKernelGGL((gather_block_f32_kernel<kBlockNnzMax>), grid, block, 0, fdd_stream(stream), t, Qt_ptr, Qt_col, u, plan->row_blocks_dev, first, row_lo, row_hi, xcd_window);
     FDD_LAUNCH_CHECK();
     return 0;
 }
@@ -1111,13 +1115,14 @@ int fdd_csr_plan_dssum(const fdd_csr_plan *plan, double *QQtu, double *t, const 
     const dim3 grid(last - first), block(kBlock);
     hipStream_t s = fdd_stream(stream);
     const bool W = node_weight != nullptr && mode != 2, M = point_mask != nullptr && mode != 1;
+    static const int xcd_window = fdd_env_int("FDD_TUNE_DSSUM_XCD_WINDOW", 0); // consecutive row blocks per XCD inside a window of 8x as many (0: dispatch order)
 #define FDD_DSB(MODE, WW, MM)                                                                                                                                                                    \
     do                                                                                                                                                                                          \
     {                                                                                                                                                                                           \
         if (plan->block_nnz == kBlockNnzSmall)                                                                                                                                                  \
-            hipLaunchKernelGGL((dssum_block_kernel<MODE, WW, MM, kBlockNnzSmall>), grid, block, 0, s, QQtu, t, Qt_ptr, Qt_col, u, node_weight, point_mask, plan->row_blocks_dev, first, row_lo, row_hi); \
+            hipLaunchKernelGGL((dssum_block_kernel<MODE, WW, MM, kBlockNnzSmall>), grid, block, 0, s, QQtu, t, Qt_ptr, Qt_col, u, node_weight, point_mask, plan->row_blocks_dev, first, row_lo, row_hi, xcd_window); \
         else                                                                                                                                                                                    \
-            hipLaunchKernelGGL((dssum_block_kernel<MODE, WW, MM, kBlockNnzMax>), grid, block, 0, s, QQtu, t, Qt_ptr, Qt_col, u, node_weight, point_mask, plan->row_blocks_dev, first, row_lo, row_hi);   \
+            hipLaunchKernelGGL((dssum_block_kernel<MODE, WW, MM, kBlockNnzMax>), grid, block, 0, s, QQtu, t, Qt_ptr, Qt_col, u, node_weight, point_mask, plan->row_blocks_dev, first, row_lo, row_hi, xcd_window);   \
     } while (0)
     if (mode == 0)
     {

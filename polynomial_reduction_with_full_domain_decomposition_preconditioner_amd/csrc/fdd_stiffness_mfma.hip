@@ -141,7 +141,7 @@ __device__ __forceinline__ void tile_add(double *dst, int base, int rs, int cs, 
 // major) and the GLL weights (G.g[1]) instead of prefetched from the six arrays -- 48 of the 64 bytes per point are not
 // read (fdd_stiffness.hip, fused_stiffness_kernel_t; an option of this build for affine elements).
 template <int n, bool kGather, bool kAffine = false>
-__global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ u_scale, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements)
+__global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__restrict__ Au, const double *__restrict__ u, const int *__restrict__ point_dof, const double *__restrict__ u_scale, const double *__restrict__ D_hat, GPtrs G, const int *__restrict__ elem_offset, int num_elements, int xcd_window)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *sU = smem;
@@ -200,7 +200,11 @@ __global__ __launch_bounds__(kThreads) void mfma_stiffness_kernel(double *__rest
 #endif
     double ru[kPts], rg[FDD_NUM_GEOM_FACTS][kPts];
     int rd[kGather ? kPts : 1];
-    int e = blockIdx.x;
+    // Which elements the persistent workgroups visit together.  Under round-robin dispatch workgroup b sits on XCD b % 8, so
+    // in plain order the x-neighbours e and e + 1 -- which share a face whose 256 dofs are the LAST dof of 256 different
+    // 120-byte runs of the left neighbour's numbering -- are always on different XCDs and both L2s fetch those lines.  In
+    // XCD-windowed order (one window = the grid) the workgroups of an XCD take grid / 8 CONSECUTIVE elements of every sweep.
+    int e = fdd_xcd_windowed_block(blockIdx.x, gridDim.x, xcd_window);
     if (e < num_elements)
     {
         const size_t base = elem_base(e);
@@ -376,10 +380,14 @@ int launch_mfma(double *Au, const double *u, const int *point_dof, const double 
     FDD_HIP_CHECK(attr_a);
     FDD_HIP_CHECK(attr_b);
     const int grid = num_elements < FDD_CU_COUNT ? num_elements : FDD_CU_COUNT;
+    // consecutive elements per XCD and sweep (fdd_xcd_windowed_block; 0 = dispatch order, -1 = grid / 8: every XCD's
+    // workgroups take one run of consecutive elements per sweep)
+    static const int xcd_env = fdd_env_int("FDD_TUNE_MFMA_XCD_WINDOW", 0);
+    const int xcd_window = xcd_env < 0 ? grid / FDD_NUM_XCD : xcd_env;
     if (point_dof)
-        hipLaunchKernelGGL((mfma_stiffness_kernel<n, true, kAffine>), dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((mfma_stiffness_kernel<n, true, kAffine>), dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements, xcd_window);
     else
-        hipLaunchKernelGGL((mfma_stiffness_kernel<n, false, kAffine>), dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements);
+        hipLaunchKernelGGL((mfma_stiffness_kernel<n, false, kAffine>), dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements, xcd_window);
     FDD_LAUNCH_CHECK();
     return 0;
 }

@@ -213,16 +213,16 @@ class Domain
     {
         if (use_preconditioner)
         {
-            timer.start("subdomain.solver");
+            fdd_timer().start("subdomain.solver");
             if (preconditioner_type == 0)
                 subdomain.flexible_conjugate_gradient(z, r);
             else
                 subdomain.generalized_minimum_residual(z, r);
-            timer.stop("subdomain.solver");
+            fdd_timer().stop("subdomain.solver");
 
-            timer.start("subdomain.stitching");
+            fdd_timer().start("subdomain.stitching");
             direct_stiffness_summation(z, z, true, true);
-            timer.stop("subdomain.stitching");
+            fdd_timer().stop("subdomain.stitching");
         }
         else
         {
@@ -941,7 +941,7 @@ class Domain
         void *stream = fdd::dev().stream;
         if (use_preconditioner)
         {
-            timer.start("subdomain.solver");
+            fdd_timer().start("subdomain.solver");
             if (composite_precond)
             {
                 // full domain decomposition: the inner solve starts from the residual on the points (degree tree,
@@ -972,9 +972,9 @@ class Domain
                 FDD_CALL(fdd_gather_indexed(sub_f.as<double>(), rn.as<double>(), node_of_dof.as<int>(), nullptr, nodes_sub_dofs, stream));
                 subdomain.gmres_dofs(sub_u, sub_f);
             }
-            timer.stop("subdomain.solver");
+            fdd_timer().stop("subdomain.solver");
 
-            timer.start("subdomain.stitching");
+            fdd_timer().start("subdomain.stitching");
             if (dof_shift >= 0 and not composite_precond and stitch_is_one and unit_stitch_in_place)
             {
                 // z~ is already in place
@@ -994,7 +994,7 @@ class Domain
             }
             else
                 gs_add_boundary(zn);
-            timer.stop("subdomain.stitching");
+            fdd_timer().stop("subdomain.stitching");
         }
         else
         {
@@ -1038,10 +1038,10 @@ class Domain
         void *stream = fdd::dev().stream;
         DType values[2], r_norm;
 
-        timer.start("domain.operator_application");
+        fdd_timer().start("domain.operator_application");
         stiffness_from_nodes(q_k, np);
         gather_nodes(nq, q_k);
-        timer.stop("domain.operator_application");
+        fdd_timer().stop("domain.operator_application");
 
         if (device_scalars and gamma_on_device and early_gamma)
         {
@@ -1167,22 +1167,22 @@ class Domain
         }
         fcg_u = u;
 
-        timer.start("domain.vector_operations");
+        fdd_timer().start("domain.vector_operations");
         FDD_CALL(fdd_dom_initialize_arrays(fcg_u.as<double>(), r_k.as<double>(), f.as<double>(), num_local_points, fdd::dev().stream));
-        timer.stop("domain.vector_operations");
+        fdd_timer().stop("domain.vector_operations");
 
-        timer.start("domain.residual_norm");
+        fdd_timer().start("domain.residual_norm");
         residual_norm(fcg_r_0_norm, r_k);
-        timer.stop("domain.residual_norm");
+        fdd_timer().stop("domain.residual_norm");
 
         residual_history.push_back(fcg_r_0_norm);
         rstdout("Iter %2d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", 0, fcg_r_0_norm, 1.0);
 
         apply_preconditioner(z_k, r_k, subdomain);
 
-        timer.start("domain.vector_operations");
+        fdd_timer().start("domain.vector_operations");
         p_k.copyFrom(z_k, (size_t)num_local_points * sizeof(DType));
-        timer.stop("domain.vector_operations");
+        fdd_timer().stop("domain.vector_operations");
 
         num_iterations = 0;
         fcg_iter = 0;
@@ -1194,23 +1194,23 @@ class Domain
         if (fcg_nodes_active) return fcg_nodes_step_residual();
         DType theta_k, r_norm;
 
-        timer.start("domain.operator_application");
+        fdd_timer().start("domain.operator_application");
         stiffness_matrix(q_k, p_k);
-        timer.stop("domain.operator_application");
+        fdd_timer().stop("domain.operator_application");
 
-        timer.start("domain.inner_products");
+        fdd_timer().start("domain.inner_products");
         projection_inner_products(fcg_gamma_k, theta_k, z_k, r_k, p_k, q_k);
-        timer.stop("domain.inner_products");
+        fdd_timer().stop("domain.inner_products");
 
         const DType alpha_k = fcg_gamma_k / theta_k;
 
-        timer.start("domain.vector_operations");
+        fdd_timer().start("domain.vector_operations");
         solution_and_residual_update(fcg_u, r_kp1, r_k, p_k, q_k, alpha_k);
-        timer.stop("domain.vector_operations");
+        fdd_timer().stop("domain.vector_operations");
 
-        timer.start("domain.residual_norm");
+        fdd_timer().start("domain.residual_norm");
         residual_norm(r_norm, r_kp1);
-        timer.stop("domain.residual_norm");
+        fdd_timer().stop("domain.residual_norm");
 
         residual_history.push_back(r_norm);
         rstdout("Iter %2d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", fcg_iter + 1, r_norm, r_norm / fcg_r_0_norm);
@@ -1230,15 +1230,15 @@ class Domain
 
         apply_preconditioner(z_k, r_kp1, subdomain);
 
-        timer.start("domain.inner_products");
+        fdd_timer().start("domain.inner_products");
         inner_product_flexible(theta_k, r_k, r_kp1, z_k);
-        timer.stop("domain.inner_products");
+        fdd_timer().stop("domain.inner_products");
 
         const DType beta_k = theta_k / fcg_gamma_k;
 
-        timer.start("domain.vector_operations");
+        fdd_timer().start("domain.vector_operations");
         residual_and_search_update(p_k, r_k, z_k, r_kp1, beta_k);
-        timer.stop("domain.vector_operations");
+        fdd_timer().stop("domain.vector_operations");
 
         num_iterations++;
         fcg_iter++;
@@ -1347,17 +1347,17 @@ class Domain
         allocate_gmres();
         residual_history.clear();
 
-        timer.start("domain.vector_operations");
+        fdd_timer().start("domain.vector_operations");
         fdd::memory &u_k = u;
         FDD_CALL(fdd_dom_initialize_arrays(u_k.as<double>(), r_k.as<double>(), f.as<double>(), num_local_points, fdd::dev().stream));
-        timer.stop("domain.vector_operations");
+        fdd_timer().stop("domain.vector_operations");
 
         DType r_norm;
         DType r_0_norm;
 
-        timer.start("domain.residual_norm");
+        fdd_timer().start("domain.residual_norm");
         residual_norm(r_0_norm, r_k);
-        timer.stop("domain.residual_norm");
+        fdd_timer().stop("domain.residual_norm");
 
         residual_history.push_back(r_0_norm);
         rstdout("Iter %2d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", 0, r_0_norm, 1.0);
@@ -1372,17 +1372,17 @@ class Domain
         {
             if (iter > 0)
             {
-                timer.start("domain.operator_application");
+                fdd_timer().start("domain.operator_application");
                 stiffness_matrix(r_k, u_k);
-                timer.stop("domain.operator_application");
+                fdd_timer().stop("domain.operator_application");
 
-                timer.start("domain.vector_operations");
+                fdd_timer().start("domain.vector_operations");
                 math.vector_vector_addition(r_k, 1.0, f, -1.0, r_k, num_local_points);
-                timer.stop("domain.vector_operations");
+                fdd_timer().stop("domain.vector_operations");
 
-                timer.start("domain.residual_norm");
+                fdd_timer().start("domain.residual_norm");
                 residual_norm(r_norm, r_k);
-                timer.stop("domain.residual_norm");
+                fdd_timer().stop("domain.residual_norm");
 
                 gamma[0] = r_norm;
             }
@@ -1391,18 +1391,18 @@ class Domain
                 gamma[0] = r_0_norm;
             }
 
-            timer.start("domain.vector_operations");
+            fdd_timer().start("domain.vector_operations");
             math.vector_scaling(V[0], 1.0 / gamma[0], r_k, num_local_points);
-            timer.stop("domain.vector_operations");
+            fdd_timer().stop("domain.vector_operations");
             va_valid = 0; // a new basis
 
             for (j = 0; j < num_vectors; j++)
             {
                 apply_preconditioner(Z[j], V[j], subdomain);
 
-                timer.start("domain.operator_application");
+                fdd_timer().start("domain.operator_application");
                 stiffness_matrix(q_k, Z[j]);
-                timer.stop("domain.operator_application");
+                fdd_timer().stop("domain.operator_application");
 
                 // classical Gram-Schmidt: every H[i][j] from the same q_k (domain.tpp:810-815)
                 if (restructured_outer)
@@ -1410,7 +1410,7 @@ class Domain
                     // <q, V_i> = sum q * (QQt V_i) * mask with the assembled copy VA[i] = mask * QQt V_i cached when
                     // V_i was made (the reference redoes the dssum inside each of the (j+1)(j+2)/2 products);
                     // the (j+1) dots read q once per group of FDD_MULTI_MAX, the (j+1) updates are one pass per group
-                    timer.start("domain.inner_products");
+                    fdd_timer().start("domain.inner_products");
                     gmres_cache_assembled(j);
                     std::vector<double> h(j + 1);
                     for (int g0 = 0; g0 < j + 1; g0 += FDD_MULTI_MAX)
@@ -1422,9 +1422,9 @@ class Domain
                         fetch_scalars(h.data() + g0, cnt);
                     }
                     for (int i = 0; i < j + 1; i++) H[i][j] = h[i];
-                    timer.stop("domain.inner_products");
+                    fdd_timer().stop("domain.inner_products");
 
-                    timer.start("domain.vector_operations");
+                    fdd_timer().start("domain.vector_operations");
                     for (int g0 = 0; g0 < j + 1; g0 += FDD_MULTI_MAX)
                     {
                         const int cnt = std::min(FDD_MULTI_MAX, j + 1 - g0);
@@ -1437,22 +1437,22 @@ class Domain
                         }
                         FDD_CALL(fdd_multi_axpy(q_k.as<double>(), coeffs, ptrs, cnt, num_local_points, fdd::dev().stream));
                     }
-                    timer.stop("domain.vector_operations");
+                    fdd_timer().stop("domain.vector_operations");
                 }
                 else
                 {
                     for (int i = 0; i < j + 1; i++)
                     {
-                        timer.start("domain.inner_products");
+                        fdd_timer().start("domain.inner_products");
                         assembled_inner_product(H[i][j], q_k, V[i]);
-                        timer.stop("domain.inner_products");
+                        fdd_timer().stop("domain.inner_products");
                     }
 
                     for (int i = 0; i < j + 1; i++)
                     {
-                        timer.start("domain.vector_operations");
+                        fdd_timer().start("domain.vector_operations");
                         math.vector_vector_addition(q_k, 1.0, q_k, -H[i][j], V[i], num_local_points);
-                        timer.stop("domain.vector_operations");
+                        fdd_timer().stop("domain.vector_operations");
                     }
                 }
 
@@ -1463,9 +1463,9 @@ class Domain
                     H[i + 1][j] = -s_gmres[i] * h_ij + c_gmres[i] * H[i + 1][j];
                 }
 
-                timer.start("domain.residual_norm");
+                fdd_timer().start("domain.residual_norm");
                 residual_norm(alpha_j, q_k);
-                timer.stop("domain.residual_norm");
+                fdd_timer().stop("domain.residual_norm");
 
                 if (std::abs(alpha_j) == 0.0)
                 {
@@ -1514,9 +1514,9 @@ class Domain
                     break;
                 }
 
-                timer.start("domain.vector_operations");
+                fdd_timer().start("domain.vector_operations");
                 math.vector_scaling(V[j + 1], 1.0 / alpha_j, q_k, num_local_points);
-                timer.stop("domain.vector_operations");
+                fdd_timer().stop("domain.vector_operations");
 
                 iter++;
             }
@@ -1533,7 +1533,7 @@ class Domain
 
             if (restructured_outer)
             {
-                timer.start("domain.vector_operations");
+                fdd_timer().start("domain.vector_operations");
                 for (int g0 = 0; g0 < j + 1; g0 += FDD_MULTI_MAX)
                 {
                     const int cnt = std::min(FDD_MULTI_MAX, j + 1 - g0);
@@ -1541,15 +1541,15 @@ class Domain
                     for (int i = 0; i < cnt; i++) ptrs[i] = Z[g0 + i].template as<double>();
                     FDD_CALL(fdd_multi_axpy(u_k.as<double>(), c_gmres.data() + g0, ptrs, cnt, num_local_points, fdd::dev().stream));
                 }
-                timer.stop("domain.vector_operations");
+                fdd_timer().stop("domain.vector_operations");
             }
             else
             {
                 for (int i = 0; i < j + 1; i++)
                 {
-                    timer.start("domain.vector_operations");
+                    fdd_timer().start("domain.vector_operations");
                     math.vector_vector_addition(u_k, 1.0, u_k, c_gmres[i], Z[i], num_local_points);
-                    timer.stop("domain.vector_operations");
+                    fdd_timer().stop("domain.vector_operations");
                 }
             }
 

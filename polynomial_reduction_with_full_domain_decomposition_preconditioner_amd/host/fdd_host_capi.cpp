@@ -160,8 +160,8 @@ int fddh_set_timer(int on)
 {
     try
     {
-        timer.enabled = on != 0;
-        if (on) timer.initialize();
+        fdd_timer().enabled = on != 0;
+        if (on) fdd_timer().initialize();
         return 0;
     }
     catch (const std::exception &e)
@@ -175,7 +175,7 @@ int fddh_timer_total(const char *key, double *seconds)
     try
     {
         if (!key || !seconds) return fail("null argument");
-        *seconds = timer.total(key);
+        *seconds = fdd_timer().total(key);
         return 0;
     }
     catch (const std::exception &e)
@@ -189,7 +189,7 @@ int fddh_timer_total_over_ranks(const char *key, const char *aggregation, double
     try
     {
         if (!key || !aggregation || !seconds) return fail("null argument");
-        *seconds = timer.total(key, aggregation); // collective: all-reduce (max or sum) over the ranks, timer.tpp:67
+        *seconds = fdd_timer().total(key, aggregation); // collective: all-reduce (max or sum) over the ranks, timer.tpp:67
         return 0;
     }
     catch (const std::exception &e)

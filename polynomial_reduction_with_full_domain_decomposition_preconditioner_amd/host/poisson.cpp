@@ -10,6 +10,10 @@
  * the five positional arguments):
  *     --box Ex Ey Ez     generate the synthetic unit-cube mesh instead of
  *                        reading <directory> (which is then ignored)
+ *     --kershaw EPS      with --box: the box under the Kershaw map with
+ *                        eps_y = eps_z = EPS (the geometry of the reference's
+ *                        experiments: run.py:25-47 and run.sh:30 read Nek5000
+ *                        exports of it with EPS = 0.3)
  *     --solver fcg|gmres outer solver (the reference hard-codes solver_id = 1,
  *                        GMRES, poisson.cpp:224; PCG is solver_id = 0)
  *     --function ID      manufactured solution id (poisson.cpp:211: 4)
@@ -140,6 +144,7 @@ int main(int argc, char *argv[])
     int use_amg = 1;     // Subdomain::use_preconditioner, subdomain.hpp:231
     int block_local = 0;
     const char *write_dir = nullptr;
+    double kershaw_eps = 1.0;
     for (int a = 6; a < argc; a++)
     {
         if (!strcmp(argv[a], "--box") && a + 3 < argc)
@@ -149,6 +154,8 @@ int main(int argc, char *argv[])
             box[2] = atoi(argv[a + 3]);
             a += 3;
         }
+        else if (!strcmp(argv[a], "--kershaw") && a + 1 < argc)
+            kershaw_eps = atof(argv[++a]);
         else if (!strcmp(argv[a], "--solver") && a + 1 < argc)
             solver_id = !strcmp(argv[++a], "fcg") ? 0 : 1;
         else if (!strcmp(argv[a], "--function") && a + 1 < argc)
@@ -189,12 +196,12 @@ int main(int argc, char *argv[])
             int deg = poly_degree;
             for (;;)
             {
-                if (fddh_write_box_mesh_files(write_dir, box, P, deg, rank)) die("fddh_write_box_mesh_files");
+                if (fddh_write_kershaw_mesh_files(write_dir, box, P, deg, rank, kershaw_eps, kershaw_eps)) die("fddh_write_kershaw_mesh_files");
                 if (deg == 1 || !with_subdomain) break;
                 deg = (deg - poly_reduction >= 1) ? deg - poly_reduction : 1;
             }
         }
-        if (fddh_problem_create_box_ex(&problem, box, P, poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, flags)) die("fddh_problem_create_box_ex");
+        if (fddh_problem_create_kershaw_ex(&problem, box, P, poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, flags, kershaw_eps, kershaw_eps)) die("fddh_problem_create_kershaw_ex");
     }
     else
     {

@@ -217,11 +217,11 @@ class Subdomain
     {
         // Level 0 of the tree is the caller's vector (copy_from_domain_data, subdomain.tpp:4571).  The composite reads it
         // where it lies (first restriction, ring packing, own part of the result); the other paths keep the copy.
-        timer.start("subdomain.tree_construction.gpu_to_gpu");
+        fdd_timer().start("subdomain.tree_construction.gpu_to_gpu");
         if (not is_composite) FDD_CALL(fdd_sub_copy_f64_f64(work_dev[0].as<double>(), u.as<double>(), levels[0].num_points, fdd::dev().stream));
-        timer.stop("subdomain.tree_construction.gpu_to_gpu");
+        fdd_timer().stop("subdomain.tree_construction.gpu_to_gpu");
 
-        timer.start("subdomain.tree_construction.subdomain");
+        fdd_timer().start("subdomain.tree_construction.subdomain");
         if (build_tree or is_composite) // the composite's rings and superdomain are fed by the tree
         {
             for (int l = 0; l < num_levels - 1; l++)
@@ -245,7 +245,7 @@ class Subdomain
                 }
             }
         }
-        timer.stop("subdomain.tree_construction.subdomain");
+        fdd_timer().stop("subdomain.tree_construction.subdomain");
 
         if (is_composite)
         {
@@ -256,16 +256,16 @@ class Subdomain
         // Tree exchange.  With only own elements in the region the gs pull of
         // subdomain.tpp:4626-4630 is a device copy of the level-0 slice; the
         // coarse level has no superdomain consumer, so no all-gather is issued.
-        timer.start("subdomain.tree_exchange.subdomain");
+        fdd_timer().start("subdomain.tree_exchange.subdomain");
         Tu.copyFrom(work_dev[0], (size_t)subdomain_operator.num_points * sizeof(DType));
-        timer.stop("subdomain.tree_exchange.subdomain");
+        fdd_timer().stop("subdomain.tree_exchange.subdomain");
 
         if (build_tree and Qt_coarse.num_rows > 0)
         {
-            timer.start("subdomain.tree_construction.assemble_coarse");
+            fdd_timer().start("subdomain.tree_construction.assemble_coarse");
             fdd::memory coarse = work_dev[0].slice(levels[num_levels - 1].offset, levels[num_levels - 1].num_points);
             Qt_coarse.multiply(work_dev[1], coarse); // subdomain.tpp:4639
-            timer.stop("subdomain.tree_construction.assemble_coarse");
+            fdd_timer().stop("subdomain.tree_construction.assemble_coarse");
         }
         // superdomain_operator.Pt.multiply: empty matrix (subdomain.tpp:4643-4644)
     }
@@ -279,33 +279,33 @@ class Subdomain
     void tree_exchange(fdd::memory &Tu, fdd::memory &u)
     {
         void *stream = fdd::dev().stream;
-        timer.start("subdomain.tree_exchange.subdomain");
+        fdd_timer().start("subdomain.tree_exchange.subdomain");
         // level 0 of the tree is `u` itself, the restricted levels are in work_dev[0] at their tree offsets
         if (num_send_points > 0) FDD_CALL(fdd_gather_indexed_split(send_all.as<double>(), u.as<double>(), work_dev[0].as<double>(), levels[0].num_points, send_index.template as<int>(), num_send_points, stream));
         fdd::comm().exchange(exchange_ops.data(), (int)exchange_ops.size()); // every rank calls it (a rank without peers passes none): one back-end meets world-wide
         // the rank's own elements: the level-0 slice (:4630); nothing to do when the caller keeps its vector in place (tree_points())
         if (Tu.ptr() != u.ptr()) Tu.copyFrom(u, (size_t)own_points * sizeof(DType));
         if (num_ring_points > 0) FDD_CALL(fdd_gather_indexed(Tu.as<double>() + own_points, recv_all.as<double>(), unpack_index.template as<int>(), nullptr, num_ring_points, stream));
-        timer.stop("subdomain.tree_exchange.subdomain");
+        fdd_timer().stop("subdomain.tree_exchange.subdomain");
 
         // The all-gather is issued by EVERY rank, as the reference's MPI_Allgatherv is (subdomain.tpp:4620): whether a
         // rank has a superdomain of its own is a per-rank fact (a rank whose rings already cover the whole domain has
         // none while its peers do), and a collective gated on it would leave the peers waiting.  Only the local
         // products below are skipped by such a rank.
-        timer.start("subdomain.tree_exchange.superdomain");
+        fdd_timer().start("subdomain.tree_exchange.superdomain");
         fdd::memory coarse = work_dev[0].slice(levels[num_levels - 1].offset, coarse_pad);
         if (fdd::comm().size > 1 or superdomain_operator.num_extended_dofs > 0) fdd::comm().allgather(coarse.ptr(), coarse_all.ptr(), (size_t)coarse_pad * sizeof(DType));
-        timer.stop("subdomain.tree_exchange.superdomain");
+        fdd_timer().stop("subdomain.tree_exchange.superdomain");
         if (superdomain_operator.num_extended_dofs == 0) return;
 
-        timer.start("subdomain.tree_construction.assemble_coarse");
+        fdd_timer().start("subdomain.tree_construction.assemble_coarse");
         Qt_coarse.multiply(work_dev[1], coarse_all); // :4639
-        timer.stop("subdomain.tree_construction.assemble_coarse");
+        fdd_timer().stop("subdomain.tree_construction.assemble_coarse");
 
-        timer.start("subdomain.tree_construction.superdomain");
+        fdd_timer().start("subdomain.tree_construction.superdomain");
         fdd::memory Tu_sup = Tu.slice(subdomain_operator.num_points, superdomain_operator.num_extended_dofs);
         superdomain_operator.Pt.multiply(Tu_sup, work_dev[1]); // :4643-4644
-        timer.stop("subdomain.tree_construction.superdomain");
+        fdd_timer().stop("subdomain.tree_construction.superdomain");
     }
 
     // subdomain.tpp:4491-4515
@@ -1933,55 +1933,55 @@ class Subdomain
         residual_history.clear();
         tree_operator(r_k, f_l);
 
-        timer.start("subdomain.vector_operations");
+        fdd_timer().start("subdomain.vector_operations");
         math.set_to_value(u_k, 0.0, num_values);
-        timer.stop("subdomain.vector_operations");
+        fdd_timer().stop("subdomain.vector_operations");
 
         DType r_norm;
         DType r_0_norm;
 
-        timer.start("subdomain.residual_norm");
+        fdd_timer().start("subdomain.residual_norm");
         residual_norm(r_0_norm, r_k);
-        timer.stop("subdomain.residual_norm");
+        fdd_timer().stop("subdomain.residual_norm");
         residual_history.push_back(r_0_norm);
         if (print_history) pstdout("- Iter %3d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", 0, r_0_norm, 1.0);
 
         DType alpha_k, beta_k, gamma_k, theta_k;
 
-        timer.start("subdomain.preconditioner");
+        fdd_timer().start("subdomain.preconditioner");
         if (use_preconditioner)
             low_order_preconditioner(z_k, r_k);
         else if (use_jacobi)
             jacobi_preconditioner(z_k, r_k);
         else
             direct_stiffness_summation(z_k, r_k);
-        timer.stop("subdomain.preconditioner");
+        fdd_timer().stop("subdomain.preconditioner");
 
-        timer.start("subdomain.vector_operations");
+        fdd_timer().start("subdomain.vector_operations");
         p_k.copyFrom(z_k, (size_t)num_values * sizeof(DType));
-        timer.stop("subdomain.vector_operations");
+        fdd_timer().stop("subdomain.vector_operations");
 
         int iter = 0;
 
         while (iter < max_iterations)
         {
-            timer.start("subdomain.operator_application");
+            fdd_timer().start("subdomain.operator_application");
             stiffness_matrix(q_k, p_k);
-            timer.stop("subdomain.operator_application");
+            fdd_timer().stop("subdomain.operator_application");
 
-            timer.start("subdomain.inner_products");
+            fdd_timer().start("subdomain.inner_products");
             projection_inner_products(gamma_k, theta_k, z_k, r_k, p_k, q_k);
-            timer.stop("subdomain.inner_products");
+            fdd_timer().stop("subdomain.inner_products");
 
             alpha_k = gamma_k / theta_k;
 
-            timer.start("subdomain.vector_operations");
+            fdd_timer().start("subdomain.vector_operations");
             solution_and_residual_update(u_k, r_kp1, r_k, p_k, q_k, alpha_k);
-            timer.stop("subdomain.vector_operations");
+            fdd_timer().stop("subdomain.vector_operations");
 
-            timer.start("subdomain.residual_norm");
+            fdd_timer().start("subdomain.residual_norm");
             residual_norm(r_norm, r_kp1);
-            timer.stop("subdomain.residual_norm");
+            fdd_timer().stop("subdomain.residual_norm");
 
             iter++;
             residual_history.push_back(r_norm);
@@ -1998,31 +1998,31 @@ class Subdomain
 
             if (iter == max_iterations) break;
 
-            timer.start("subdomain.preconditioner");
+            fdd_timer().start("subdomain.preconditioner");
             if (use_preconditioner)
                 low_order_preconditioner(z_k, r_kp1);
             else if (use_jacobi)
                 jacobi_preconditioner(z_k, r_kp1);
             else
                 direct_stiffness_summation(z_k, r_kp1);
-            timer.stop("subdomain.preconditioner");
+            fdd_timer().stop("subdomain.preconditioner");
 
-            timer.start("subdomain.inner_products");
+            fdd_timer().start("subdomain.inner_products");
             search_update_inner_product(theta_k, r_k, r_kp1, z_k);
-            timer.stop("subdomain.inner_products");
+            fdd_timer().stop("subdomain.inner_products");
 
             beta_k = theta_k / gamma_k;
 
-            timer.start("subdomain.vector_operations");
+            fdd_timer().start("subdomain.vector_operations");
             residual_and_search_update(p_k, r_k, z_k, r_kp1, beta_k);
-            timer.stop("subdomain.vector_operations");
+            fdd_timer().stop("subdomain.vector_operations");
         }
 
         num_iterations += iter;
 
-        timer.start("subdomain.vector_operations");
+        fdd_timer().start("subdomain.vector_operations");
         FDD_CALL(fdd_sub_copy_f64_f64(u_l.as<double>(), u_k.as<double>(), levels[0].num_points, fdd::dev().stream));
-        timer.stop("subdomain.vector_operations");
+        fdd_timer().stop("subdomain.vector_operations");
     }
 
     // The same flexible GMRES(m) as below (subdomain.tpp:4309-4489), same
@@ -2719,16 +2719,16 @@ class Subdomain
 
         tree_operator(f, f_l);
 
-        timer.start("subdomain.vector_operations");
+        fdd_timer().start("subdomain.vector_operations");
         initialize_arrays(u_k, r_k, f);
-        timer.stop("subdomain.vector_operations");
+        fdd_timer().stop("subdomain.vector_operations");
 
         DType r_norm;
         DType r_0_norm;
 
-        timer.start("subdomain.residual_norm");
+        fdd_timer().start("subdomain.residual_norm");
         residual_norm(r_0_norm, r_k);
-        timer.stop("subdomain.residual_norm");
+        fdd_timer().stop("subdomain.residual_norm");
         residual_history.push_back(r_0_norm);
         if (print_history) pstdout("- Iter %3d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", 0, r_0_norm, 1.0);
 
@@ -2742,17 +2742,17 @@ class Subdomain
         {
             if (iter > 0)
             {
-                timer.start("subdomain.operator_application");
+                fdd_timer().start("subdomain.operator_application");
                 stiffness_matrix(r_k, u_k);
-                timer.stop("subdomain.operator_application");
+                fdd_timer().stop("subdomain.operator_application");
 
-                timer.start("subdomain.vector_operations");
+                fdd_timer().start("subdomain.vector_operations");
                 math.vector_vector_addition(r_k, 1.0, f, -1.0, r_k, num_values);
-                timer.stop("subdomain.vector_operations");
+                fdd_timer().stop("subdomain.vector_operations");
 
-                timer.start("subdomain.residual_norm");
+                fdd_timer().start("subdomain.residual_norm");
                 residual_norm(r_norm, r_k);
-                timer.stop("subdomain.residual_norm");
+                fdd_timer().stop("subdomain.residual_norm");
 
                 gamma[0] = r_norm;
             }
@@ -2761,9 +2761,9 @@ class Subdomain
                 gamma[0] = r_0_norm;
             }
 
-            timer.start("subdomain.vector_operations");
+            fdd_timer().start("subdomain.vector_operations");
             math.vector_scaling(V[0], 1.0 / gamma[0], r_k, num_values);
-            timer.stop("subdomain.vector_operations");
+            fdd_timer().stop("subdomain.vector_operations");
 
             for (j = 0; j < num_vectors; j++)
             {
@@ -2779,27 +2779,27 @@ class Subdomain
                 }
                 else
                 {
-                    timer.start("subdomain.preconditioner.identity");
+                    fdd_timer().start("subdomain.preconditioner.identity");
                     direct_stiffness_summation(Z[j], V[j]);
-                    timer.stop("subdomain.preconditioner.identity");
+                    fdd_timer().stop("subdomain.preconditioner.identity");
                 }
 
-                timer.start("subdomain.operator_application");
+                fdd_timer().start("subdomain.operator_application");
                 stiffness_matrix(q_k, Z[j]);
-                timer.stop("subdomain.operator_application");
+                fdd_timer().stop("subdomain.operator_application");
 
                 for (int i = 0; i < j + 1; i++)
                 {
-                    timer.start("subdomain.inner_products");
+                    fdd_timer().start("subdomain.inner_products");
                     assembled_inner_product(H[i][j], q_k, V[i]);
-                    timer.stop("subdomain.inner_products");
+                    fdd_timer().stop("subdomain.inner_products");
                 }
 
                 for (int i = 0; i < j + 1; i++)
                 {
-                    timer.start("subdomain.vector_operations");
+                    fdd_timer().start("subdomain.vector_operations");
                     math.vector_vector_addition(q_k, 1.0, q_k, -H[i][j], V[i], num_values);
-                    timer.stop("subdomain.vector_operations");
+                    fdd_timer().stop("subdomain.vector_operations");
                 }
 
                 for (int i = 0; i < j; i++)
@@ -2809,9 +2809,9 @@ class Subdomain
                     H[i + 1][j] = -s_gmres[i] * h_ij + c_gmres[i] * H[i + 1][j];
                 }
 
-                timer.start("subdomain.residual_norm");
+                fdd_timer().start("subdomain.residual_norm");
                 residual_norm(alpha_j, q_k);
-                timer.stop("subdomain.residual_norm");
+                fdd_timer().stop("subdomain.residual_norm");
 
                 if (std::abs(alpha_j) == 0.0)
                 {
@@ -2855,9 +2855,9 @@ class Subdomain
                     break;
                 }
 
-                timer.start("subdomain.vector_operations");
+                fdd_timer().start("subdomain.vector_operations");
                 math.vector_scaling(V[j + 1], 1.0 / alpha_j, q_k, num_values);
-                timer.stop("subdomain.vector_operations");
+                fdd_timer().stop("subdomain.vector_operations");
             }
 
             if (j == num_vectors) j--;
@@ -2871,17 +2871,17 @@ class Subdomain
 
             for (int i = 0; i < j + 1; i++)
             {
-                timer.start("subdomain.vector_operations");
+                fdd_timer().start("subdomain.vector_operations");
                 math.vector_vector_addition(u_k, 1.0, u_k, c_gmres[i], Z[i], num_values);
-                timer.stop("subdomain.vector_operations");
+                fdd_timer().stop("subdomain.vector_operations");
             }
 
             if (converged) break;
         }
 
-        timer.start("subdomain.vector_operations");
+        fdd_timer().start("subdomain.vector_operations");
         FDD_CALL(fdd_sub_copy_f64_f64(u_l.as<double>(), u_k.as<double>(), levels[0].num_points, fdd::dev().stream));
-        timer.stop("subdomain.vector_operations");
+        fdd_timer().stop("subdomain.vector_operations");
 
         num_iterations += iter;
     }

@@ -78,6 +78,7 @@ inline Timer<double> &fdd_timer()
     return t;
 }
 
-#define timer (fdd_timer())
+// (no `timer` macro: a header a maintainer drops into the reference's include path must not redefine a common identifier;
+// the host classes call fdd_timer() where the reference has its global `timer`, config.hpp:50)
 
 #endif
