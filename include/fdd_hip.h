@@ -365,6 +365,11 @@ int fdd_csr_plan_gather_weighted_norm2(const fdd_csr_plan *plan, double *out, do
 /* ------------------------------------------------------------------ */
 int fdd_interface_pack(double *slots, const int *slot_of, const double *prefix, int n, void *stream);   /* slots[slot_of[i]] = prefix[i]; slot_of is injective */
 int fdd_interface_unpack(double *prefix, const double *slots, const int *slot_of, int n, void *stream); /* prefix[i] = slots[slot_of[i]] */
+/* neighbour form of gs(gs_add) (domain.tpp:590-594) for point-to-point links: buf[i*nc + c] = {a, b}[c][index[i]] (nc = b ? 2 : 1) fills the
+ * own copies and the parts sent to the peers; after the grouped send / receive, {a, b}[c][r] = sum_k buf[col[k]*nc + c] over ptr[r] <= k < ptr[r+1],
+ * in the order of col (ascending rank of the contributor) */
+int fdd_interface_gather(double *buf, const int *index, int n, const double *a, const double *b, void *stream);
+int fdd_interface_sum(double *a, double *b, const int *ptr, const int *col, int rows, const double *buf, void *stream);
 
 #ifdef __cplusplus
 }

@@ -243,10 +243,13 @@ int fddh_problem_sub_jacobi_diagonal(fddh_problem *p, double *out, int n);
  * 12 B per row, 8 B per column) of the assembly SpMVs of csr_matrix.okl on the problem's matrices:
  * which = 0: Q x (scatter), 1: Qt x (gather). */
 int fddh_problem_spmv_time(fddh_problem *p, int which, int iterations, double *avg_us, double *algorithmic_bytes);
-/* The solve path's collectives alone, with the sizes and buffers the solve uses: avg_us[4], bytes[4] =
- * { all-reduce of 3 scalars, interface exchange of two prefixes (dense all-reduce), coarse-level all-gather (total bytes
- * gathered), ring pull (bytes this rank sends) }; host wall clock around device synchronisation, after a barrier.
- * Collective: every rank calls it.  Zeros on one rank / without a composite. */
+/* The solve path's exchanges alone, with the sizes and buffers the solve uses: avg_us[FDDH_COMM_TIME_COUNT],
+ * bytes[FDDH_COMM_TIME_COUNT] = { all-reduce of 3 scalars, interface exchange of two prefixes as a dense all-reduce, coarse-level
+ * all-gather (total bytes gathered), ring pull (bytes this rank sends), the same interface exchange as grouped sends / receives
+ * between the ranks that share nodes (bytes this rank sends: the default path, flag "neighbour_interface_exchange"), ring pull
+ * and coarse blocks in one group (bytes this rank sends: the default path, flag "fold_coarse_exchange") }; host wall clock around
+ * device synchronisation, after a barrier.  Collective: every rank calls it.  Zeros on one rank / without a composite. */
+#define FDDH_COMM_TIME_COUNT 6
 int fddh_problem_comm_time(fddh_problem *p, int iterations, double *avg_us, double *bytes);
 /* The general CSR case of the same metric: the 27-point trilinear stencil on an m^3 node grid
  * ((3m - 2)^3 non-zeros; m = 225 is the C2 node grid), values and x seeded, y = A x through CSR_Matrix::multiply. */

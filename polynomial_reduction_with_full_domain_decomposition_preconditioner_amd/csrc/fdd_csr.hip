@@ -208,7 +208,9 @@ __global__ __launch_bounds__(kBlock) void csr_block_kernel(T *__restrict__ Au, c
     // adjacent memory.  XCD-chunked order (FDD_TUNE_CSR_XCD=1) does cut the 27-point stencil's L2 fetch traffic
     // from 4.58 to 4.00 GB per launch (x is no longer pulled through all eight L2s; algorithmic 3.80 GB) but
     // runs 3 % slower (785 vs 762 us): the re-fetches are Infinity Cache hits, the eight far-apart streams cost more.
-    const int b = xcd_chunked ? fdd_xcd_chunked_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    // XCD-windowed order (xcd_chunked >= 2 = consecutive row blocks per XCD inside a window of 8x as many; fdd_common.h)
+    // keeps the eight streams adjacent AND puts neighbouring row blocks on one XCD.
+    const int b = xcd_chunked == 1 ? fdd_xcd_chunked_block(blockIdx.x, gridDim.x) : fdd_xcd_windowed_block(blockIdx.x, gridDim.x, xcd_chunked);
     const int r0 = row_blocks[b];
     const int r1 = row_blocks[b + 1];
     const int base = A_ptr[r0];
@@ -909,7 +911,9 @@ static int plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows,
     if (const char *e = getenv("FDD_TUNE_CSR_BLOCK_NNZ")) p->block_nnz = (atoi(e) <= kBlockNnzSmall) ? kBlockNnzSmall : kBlockNnzMax;
     p->value_bytes = f32 ? 4 : 8;
     p->one_per_row = 0;
-    p->xcd_chunked = fdd_env_int("FDD_TUNE_CSR_XCD", 0);
+    // 0: dispatch order; 1: XCD-chunked; >= 2: XCD-windowed with that many consecutive row blocks per XCD.  Short-row
+    // (boolean gather) plans and wide-row plans have their own knobs: what neighbouring blocks share differs.
+    p->xcd_chunked = (p->block_nnz == kBlockNnzSmall) ? fdd_env_int("FDD_TUNE_CSR_XCD_SHORT", 0) : fdd_env_int("FDD_TUNE_CSR_XCD", 0);
     p->num_blocks = 0;
     p->row_blocks_dev = nullptr;
 

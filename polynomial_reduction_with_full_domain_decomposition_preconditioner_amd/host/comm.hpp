@@ -55,8 +55,8 @@ struct CommError : public std::runtime_error
 };
 
 // one peer of a grouped point-to-point exchange: `send_bytes` from `send` go to `peer`, `recv_bytes` arrive from it
-// in `recv` (device buffers; either side may be empty).  A peer appears at most once per call and is never the
-// calling rank.
+// in `recv` (device buffers; either side may be empty).  A peer is never the calling rank; it may appear more than once
+// in a call, and its k-th op then pairs with the peer's k-th op for this rank (both sides list their parts in one order).
 struct ExchangeOp
 {
     int peer = 0;
@@ -551,10 +551,16 @@ class LocalComm : public Comm
         {
             for (int i = 0; i < n and error.empty(); i++)
             {
+                // a peer may appear more than once in a call (ring part + coarse part): the k-th op for a peer pairs with that
+                // peer's k-th op for this rank, as grouped ncclSend / ncclRecv to one peer match in order
+                int nth = 0;
+                for (int j = 0; j < i; j++)
+                    if (ops[j].peer == ops[i].peer) nth++;
                 if (ops[i].recv_bytes == 0) continue;
                 const ExchangeOp *theirs = nullptr;
+                int seen = 0;
                 for (const ExchangeOp &o : w_->ops[ops[i].peer])
-                    if (o.peer == rank) theirs = &o;
+                    if (o.peer == rank and seen++ == nth) theirs = &o;
                 if (theirs == nullptr or theirs->send_bytes != ops[i].recv_bytes)
                     error = "local world: rank " + std::to_string(rank) + " expects " + std::to_string(ops[i].recv_bytes) + " bytes from rank " + std::to_string(ops[i].peer) + ", which sends " + std::to_string(theirs ? theirs->send_bytes : 0);
                 else

@@ -83,6 +83,21 @@ class Domain
     int num_interface_slots = 0;
     fdd::memory bdary_slot;       // int[num_bdary_nodes]: slot of each boundary node
     fdd::memory interface_slots;  // double[num_interface_slots]
+    // Neighbour form of the same exchange (xGMI is point-to-point, every pair of GPUs has its own link): each peer gets only
+    // the nodes the two ranks share, by one grouped send / receive, and every sharer adds a node's copies in ascending rank
+    // order.  Buffer (entries of 1 or 2 interleaved vectors): [own prefix | parts to the peers | parts from the peers].
+    struct InterfacePeer
+    {
+        int rank = 0;
+        int first = 0; // first entry of this peer's part inside the send region (= inside the receive region)
+        int count = 0; // shared nodes
+    };
+    std::vector<InterfacePeer> iface_peers;
+    int iface_shared_entries = 0;          // sum of the peers' counts
+    fdd::memory iface_buf;                 // double[2 * (num_bdary_nodes + 2 * iface_shared_entries)]
+    fdd::memory iface_gather_index;        // int[num_bdary_nodes + iface_shared_entries]: prefix node of every own / sent entry
+    fdd::memory iface_sum_ptr, iface_sum_col; // CSR over the boundary nodes: the entries of iface_buf a node's sum reads, by contributor rank
+    std::vector<fdd::ExchangeOp> iface_ops;
 
     // Reductions
     fdd::memory reduce_ws;
@@ -138,9 +153,110 @@ class Domain
 
     const double *G_ptrs[NUM_GEOM_FACTS];
 
+    // From the all-gathered boundary ids (rank order, counts[r] per rank; every rank holds the same lists, so no further
+    // communication): who shares which of this rank's boundary nodes.  Peer parts are ordered by global id on both sides.
+    void build_interface_neighbour_plan(const std::vector<long long> &ids_by_rank, const std::vector<int> &counts, const std::vector<long long> &mine)
+    {
+        const int me = fdd::comm().rank, R = fdd::comm().size, nb = (int)mine.size();
+        std::vector<std::pair<long long, int>> holders; // (global id, rank), sorted: the ranks of an id come out ascending
+        holders.reserve(ids_by_rank.size());
+        size_t at = 0;
+        for (int r = 0; r < R; r++)
+            for (int k = 0; k < counts[r]; k++, at++) holders.emplace_back(ids_by_rank[at], r);
+        std::sort(holders.begin(), holders.end());
+        // this rank's boundary nodes by global id
+        std::vector<std::pair<long long, int>> own(nb);
+        for (int b = 0; b < nb; b++) own[b] = {mine[b], b};
+        std::sort(own.begin(), own.end());
+
+        // per peer: the shared nodes in ascending global id (the walk over `own` is in that order)
+        std::vector<std::vector<int>> shared(R);      // prefix node
+        std::vector<std::vector<int>> sharers(nb);    // ranks holding node b, ascending (this rank included)
+        for (int k = 0; k < nb; k++)
+        {
+            const long long g = own[k].first;
+            const int b = own[k].second;
+            auto lo = std::lower_bound(holders.begin(), holders.end(), std::make_pair(g, -1));
+            for (auto it = lo; it != holders.end() and it->first == g; ++it)
+            {
+                sharers[b].push_back(it->second);
+                if (it->second != me) shared[it->second].push_back(b);
+            }
+        }
+        iface_peers.clear();
+        iface_shared_entries = 0;
+        std::vector<int> first_of(R, -1);
+        for (int r = 0; r < R; r++)
+        {
+            if (shared[r].empty()) continue;
+            InterfacePeer pr;
+            pr.rank = r;
+            pr.first = iface_shared_entries;
+            pr.count = (int)shared[r].size();
+            first_of[r] = pr.first;
+            iface_shared_entries += pr.count;
+            iface_peers.push_back(pr);
+        }
+        std::vector<int> gidx((size_t)nb + iface_shared_entries);
+        for (int b = 0; b < nb; b++) gidx[b] = b;
+        std::vector<std::vector<int>> pos(R); // position of node b inside peer r's part
+        for (const InterfacePeer &pr : iface_peers)
+        {
+            pos[pr.rank].assign(nb, -1);
+            for (int k = 0; k < pr.count; k++)
+            {
+                gidx[(size_t)nb + pr.first + k] = shared[pr.rank][k];
+                pos[pr.rank][shared[pr.rank][k]] = k;
+            }
+        }
+        std::vector<int> sptr(nb + 1, 0), scol;
+        for (int b = 0; b < nb; b++)
+        {
+            for (int r : sharers[b]) scol.push_back(r == me ? b : nb + iface_shared_entries + first_of[r] + pos[r][b]);
+            sptr[b + 1] = (int)scol.size();
+        }
+        iface_buf = fdd::dev().malloc<double>(2 * ((size_t)nb + 2 * (size_t)iface_shared_entries) + 2);
+        iface_gather_index = fdd::dev().malloc<int>(std::max<size_t>(gidx.size(), 1));
+        if (not gidx.empty()) iface_gather_index.copyFrom(gidx.data(), gidx.size() * sizeof(int));
+        iface_sum_ptr = fdd::dev().malloc<int>(sptr.size());
+        iface_sum_ptr.copyFrom(sptr.data(), sptr.size() * sizeof(int));
+        iface_sum_col = fdd::dev().malloc<int>(std::max<size_t>(scol.size(), 1));
+        if (not scol.empty()) iface_sum_col.copyFrom(scol.data(), scol.size() * sizeof(int));
+    }
+
+    // the grouped send / receive of the neighbour form for `nc` interleaved vectors
+    void iface_exchange(int nc)
+    {
+        iface_ops.resize(iface_peers.size());
+        double *base = iface_buf.as<double>();
+        for (size_t k = 0; k < iface_peers.size(); k++)
+        {
+            const InterfacePeer &pr = iface_peers[k];
+            fdd::ExchangeOp &op = iface_ops[k];
+            op.peer = pr.rank;
+            op.send = base + (size_t)nc * (num_bdary_nodes + pr.first);
+            op.recv = base + (size_t)nc * (num_bdary_nodes + iface_shared_entries + pr.first);
+            op.send_bytes = op.recv_bytes = (size_t)nc * pr.count * sizeof(double);
+        }
+        fdd::comm().exchange(iface_ops.data(), (int)iface_ops.size()); // every rank calls it, peers or not (one back-end meets world-wide)
+    }
+
+    void gs_add_boundary_neighbours(fdd::memory &a, fdd::memory *b)
+    {
+        void *stream = fdd::dev().stream;
+        FDD_CALL(fdd_interface_gather(iface_buf.as<double>(), iface_gather_index.as<int>(), num_bdary_nodes + iface_shared_entries, a.as<double>(), b ? b->as<double>() : nullptr, stream));
+        iface_exchange(b ? 2 : 1);
+        FDD_CALL(fdd_interface_sum(a.as<double>(), b ? b->as<double>() : nullptr, iface_sum_ptr.as<int>(), iface_sum_col.as<int>(), num_bdary_nodes, iface_buf.as<double>(), stream));
+    }
+
     void gs_add_boundary(fdd::memory &t)
     {
         if (fdd::comm().size == 1 or num_interface_slots == 0) return;
+        if (neighbour_interface_exchange)
+        {
+            gs_add_boundary_neighbours(t, nullptr);
+            return;
+        }
         FDD_CALL(fdd_memset(interface_slots.ptr(), 0, (size_t)num_interface_slots * sizeof(double), fdd::dev().stream));
         FDD_CALL(fdd_interface_pack(interface_slots.as<double>(), bdary_slot.as<int>(), t.as<double>(), num_bdary_nodes, fdd::dev().stream));
         fdd::comm().allreduce_sum(interface_slots.as<double>(), num_interface_slots);
@@ -151,6 +267,11 @@ class Domain
     void gs_add_boundary_pair(fdd::memory &a, fdd::memory &b)
     {
         if (fdd::comm().size == 1 or num_interface_slots == 0) return;
+        if (neighbour_interface_exchange)
+        {
+            gs_add_boundary_neighbours(a, &b);
+            return;
+        }
         const int S = num_interface_slots;
         void *stream = fdd::dev().stream;
         FDD_CALL(fdd_memset(interface_slots.ptr(), 0, 2 * (size_t)S * sizeof(double), stream));
@@ -285,6 +406,7 @@ class Domain
     int preconditioner_type = 1;
     bool use_preconditioner = true;
     bool fused_dssum = true; // gather-scatter kernel instead of the reference's Qt / Q SpMV pair
+    bool neighbour_interface_exchange = true; // gs_add on the boundary prefix: grouped sends / receives between the sharing ranks (false: the dense interface-slot all-reduce)
     bool restructured_outer = true; // outer GMRES: cached assembled basis, multi-dot, multi-axpy
     bool assembled_outer = true; // flexible CG on node vectors (one value per assembled node) when the configuration allows it
     bool device_scalars = true;  // node-space flexible CG: alpha / beta read by the update kernels from device memory, residual norm fetched late
@@ -311,11 +433,16 @@ class Domain
     int interface_slots_count() const { return num_interface_slots; }
     // one interface exchange of `vectors` (1 or 2) prefixes, as gs_add_boundary[_pair] issues it: the collective alone,
     // on the exchange buffer's current contents (bench.py's communication timings)
-    void comm_probe_interface(int vectors)
+    void comm_probe_interface(int vectors, bool neighbours)
     {
         if (fdd::comm().size == 1 or num_interface_slots == 0) return;
-        fdd::comm().allreduce_sum(interface_slots.as<double>(), (size_t)num_interface_slots * (vectors == 2 ? 2 : 1));
+        if (neighbours)
+            iface_exchange(vectors == 2 ? 2 : 1);
+        else
+            fdd::comm().allreduce_sum(interface_slots.as<double>(), (size_t)num_interface_slots * (vectors == 2 ? 2 : 1));
     }
+    // bytes this rank sends in one neighbour exchange of `vectors` prefixes
+    double comm_interface_neighbour_bytes(int vectors) const { return (double)vectors * iface_shared_entries * sizeof(double); }
     CSR_Matrix<DType> &gather_matrix() { return Qt; }
     CSR_Matrix<DType> &scatter_matrix() { return Q; }
     fdd::memory &dirichlet_mask_memory() { return dirichlet_mask; }
@@ -513,6 +640,7 @@ class Domain
         {
             std::vector<int> counts;
             std::vector<long long> all = fdd::comm().allgatherv_host(boundary_nodes, counts);
+            if (fdd::comm().size > 1) build_interface_neighbour_plan(all, counts, boundary_nodes);
             std::sort(all.begin(), all.end());
             all.erase(std::unique(all.begin(), all.end()), all.end());
             num_interface_slots = (int)all.size();

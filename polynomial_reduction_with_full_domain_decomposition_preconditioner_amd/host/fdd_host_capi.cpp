@@ -946,6 +946,17 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
             if (p->subdomain) p->subdomain->restructured = value != 0;
             for (auto &kv : p->domains) kv.second.restructured_outer = value != 0; // the same restructure of the outer GMRES
         }
+        else if (s == "neighbour_interface_exchange")
+        {
+            // gs_add on the boundary prefix as grouped sends / receives between the ranks that share nodes (default) or as
+            // the dense interface-slot all-reduce; must be set alike on every rank
+            for (auto &kv : p->domains) kv.second.neighbour_interface_exchange = value != 0;
+        }
+        else if (s == "fold_coarse_exchange")
+        {
+            // the coarse level's blocks inside the ring pull's group (default) or as an all-gather of their own; alike on every rank
+            if (p->subdomain) p->subdomain->fold_coarse_exchange = value != 0;
+        }
         else if (s == "assembled_outer_solve")
         {
             for (auto &kv : p->domains) kv.second.assembled_outer = value != 0;
@@ -1590,7 +1601,7 @@ int fddh_problem_comm_time(fddh_problem *p, int iterations, double *avg_us, doub
     {
         if (int rc = rank_check(p)) return rc;
         if (!p || !avg_us || !bytes || iterations < 1) return fail("bad argument");
-        for (int k = 0; k < 4; k++) avg_us[k] = bytes[k] = 0.0;
+        for (int k = 0; k < FDDH_COMM_TIME_COUNT; k++) avg_us[k] = bytes[k] = 0.0;
         fdd::Comm &c = fdd::comm();
         if (c.size == 1) return 0;
         Domain<SType> &d = p->fine();
@@ -1609,14 +1620,18 @@ int fddh_problem_comm_time(fddh_problem *p, int iterations, double *avg_us, doub
         // every rank makes the same calls in the same order
         avg_us[0] = timed([&] { c.allreduce_sum(scal.as<double>(), 3); });
         bytes[0] = 3 * sizeof(double);
-        avg_us[1] = timed([&] { d.comm_probe_interface(2); });
+        avg_us[1] = timed([&] { d.comm_probe_interface(2, false); });
         bytes[1] = 2.0 * d.interface_slots_count() * sizeof(double);
+        avg_us[4] = timed([&] { d.comm_probe_interface(2, true); });
+        bytes[4] = d.comm_interface_neighbour_bytes(2);
         if (p->subdomain)
         {
             avg_us[2] = timed([&] { p->subdomain->comm_probe_coarse(); });
             bytes[2] = p->subdomain->comm_coarse_bytes();
             avg_us[3] = timed([&] { p->subdomain->comm_probe_ring(); });
             bytes[3] = p->subdomain->comm_ring_bytes();
+            avg_us[5] = timed([&] { p->subdomain->comm_probe_ring_and_coarse(); });
+            bytes[5] = p->subdomain->comm_ring_and_coarse_bytes();
         }
         scal.free();
         return 0;

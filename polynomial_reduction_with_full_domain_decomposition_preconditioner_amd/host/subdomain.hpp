@@ -163,6 +163,12 @@ class Subdomain
     // tree exchange (subdomain.tpp:4615-4644), all on device buffers
     fdd::memory send_index, send_all, recv_all, unpack_index; // pack: send_all[k] = tree[send_index[k]]; unpack: head ring part [i] = recv_all[unpack_index[i]]
     std::vector<fdd::ExchangeOp> exchange_ops;
+    // The coarse level's all-gather folded into the ring pull's group: every rank sends its degree-1 block straight to every
+    // other rank in the same grouped send / receive (xGMI gives every pair of GPUs its own link: 7 direct messages of one
+    // block each instead of a ring all-gather that carries 7 blocks over every link, and one group instead of two
+    // collectives per preconditioner application).  Same bytes in the same places; fold_coarse_exchange = false keeps
+    // the all-gather (subdomain.tpp:4620-4621).
+    std::vector<fdd::ExchangeOp> exchange_ops_folded;
     int num_send_points = 0, num_ring_points = 0;
     fdd::memory coarse_all;                    // the all-gathered degree-1 level of every rank, `coarse_pad` values per rank
     int coarse_pad = 0;
@@ -282,7 +288,17 @@ class Subdomain
         fdd_timer().start("subdomain.tree_exchange.subdomain");
         // level 0 of the tree is `u` itself, the restricted levels are in work_dev[0] at their tree offsets
         if (num_send_points > 0) FDD_CALL(fdd_gather_indexed_split(send_all.as<double>(), u.as<double>(), work_dev[0].as<double>(), levels[0].num_points, send_index.template as<int>(), num_send_points, stream));
-        fdd::comm().exchange(exchange_ops.data(), (int)exchange_ops.size()); // every rank calls it (a rank without peers passes none): one back-end meets world-wide
+        const bool coarse_needed = fdd::comm().size > 1 or superdomain_operator.num_extended_dofs > 0; // rank-uniform (see below)
+        const bool folded = fold_coarse_exchange and fdd::comm().size > 1;
+        fdd::memory coarse = work_dev[0].slice(levels[num_levels - 1].offset, coarse_pad);
+        if (folded)
+        {
+            // own block in place, the others by the group below
+            FDD_CALL(fdd_memcpy_d2d(coarse_all.as<DType>() + (size_t)fdd::comm().rank * coarse_pad, coarse.ptr(), (size_t)coarse_pad * sizeof(DType), stream));
+            fdd::comm().exchange(exchange_ops_folded.data(), (int)exchange_ops_folded.size());
+        }
+        else
+            fdd::comm().exchange(exchange_ops.data(), (int)exchange_ops.size()); // every rank calls it (a rank without peers passes none): one back-end meets world-wide
         // the rank's own elements: the level-0 slice (:4630); nothing to do when the caller keeps its vector in place (tree_points())
         if (Tu.ptr() != u.ptr()) Tu.copyFrom(u, (size_t)own_points * sizeof(DType));
         if (num_ring_points > 0) FDD_CALL(fdd_gather_indexed(Tu.as<double>() + own_points, recv_all.as<double>(), unpack_index.template as<int>(), nullptr, num_ring_points, stream));
@@ -293,8 +309,7 @@ class Subdomain
         // none while its peers do), and a collective gated on it would leave the peers waiting.  Only the local
         // products below are skipped by such a rank.
         fdd_timer().start("subdomain.tree_exchange.superdomain");
-        fdd::memory coarse = work_dev[0].slice(levels[num_levels - 1].offset, coarse_pad);
-        if (fdd::comm().size > 1 or superdomain_operator.num_extended_dofs > 0) fdd::comm().allgather(coarse.ptr(), coarse_all.ptr(), (size_t)coarse_pad * sizeof(DType));
+        if (coarse_needed and not folded) fdd::comm().allgather(coarse.ptr(), coarse_all.ptr(), (size_t)coarse_pad * sizeof(DType));
         fdd_timer().stop("subdomain.tree_exchange.superdomain");
         if (superdomain_operator.num_extended_dofs == 0) return;
 
@@ -1182,6 +1197,18 @@ class Subdomain
         if (not is_composite) return;
         fdd::comm().exchange(exchange_ops.data(), (int)exchange_ops.size());
     }
+    // ring pull and coarse blocks in one group, as tree_exchange issues them by default
+    void comm_probe_ring_and_coarse()
+    {
+        if (not is_composite) return;
+        fdd::comm().exchange(exchange_ops_folded.data(), (int)exchange_ops_folded.size());
+    }
+    double comm_ring_and_coarse_bytes() const
+    {
+        double b = 0.0;
+        for (const fdd::ExchangeOp &op : exchange_ops_folded) b += (double)op.send_bytes;
+        return b;
+    }
     double comm_coarse_bytes() const { return is_composite ? (double)coarse_pad * sizeof(DType) * fdd::comm().size : 0.0; }
     double comm_ring_bytes() const
     {
@@ -1366,6 +1393,7 @@ class Subdomain
     bool device_bookkeeping = true;       // assembled inner GMRES: Givens / stopping tests in one-thread kernels, one host sync per cycle
     bool unit_norm_weight() const { return norm_weight_is_one; }
     const double *known_rhs_norm2_dev = nullptr; // set by the caller around one solve: |f~|^2 over the dofs, already on the device (double-precision device GMRES only)
+    bool fold_coarse_exchange = true;     // the coarse level's blocks travel inside the ring pull's group (false: an all-gather of their own)
     bool skip_last_basis_store = true;    // device GMRES: the last Arnoldi step of a cycle forms the norm of its vector without storing it (nobody reads it)
     bool lazy_history = false;            // single-cycle inner solves do not synchronise at all; finish_history() fetches on demand
     bool history_pending = false;
@@ -1804,6 +1832,22 @@ class Subdomain
             size_t W = std::max({total_level_points + (size_t)coarse_pad, (size_t)NP, (size_t)(nse + nue), (size_t)c.num_coarse_dofs, (size_t)num_dofs}) + 16;
             work_dev.resize(3);
             for (int w = 0; w < 3; w++) work_dev[w] = fdd::dev().malloc<DType>(W);
+        }
+        // the ring pull's ops followed by one op per other rank for the coarse blocks (both sides list them in this order)
+        {
+            exchange_ops_folded = exchange_ops;
+            const int R = fdd::comm().size, me = fdd::comm().rank;
+            DType *coarse = work_dev[0].template as<DType>() + levels[num_levels - 1].offset;
+            for (int r = 0; r < R and coarse_pad > 0; r++)
+            {
+                if (r == me) continue;
+                fdd::ExchangeOp op;
+                op.peer = r;
+                op.send = coarse;
+                op.recv = coarse_all.template as<DType>() + (size_t)r * coarse_pad;
+                op.send_bytes = op.recv_bytes = (size_t)coarse_pad * sizeof(DType);
+                exchange_ops_folded.push_back(op);
+            }
         }
 
         setup_timing.lap("exchange plan, work arrays");

@@ -452,10 +452,12 @@ class Problem:
 
     def comm_time(self, iterations=20):
         """the solve path's collectives alone (collective call): dict name -> (avg us, bytes)"""
-        us = (ctypes.c_double * 4)()
-        nbytes = (ctypes.c_double * 4)()
+        us = (ctypes.c_double * 6)()
+        nbytes = (ctypes.c_double * 6)()
         _H().call("fddh_problem_comm_time", self.h, int(iterations), us, nbytes)
-        names = ["allreduce_3_scalars", "interface_pair_allreduce", "coarse_allgather", "ring_exchange"]
+        # the last two are what the solve issues by default (point-to-point groups: xGMI links every pair of GPUs directly);
+        # the dense all-reduce / all-gather forms before them are the flags' other setting, timed for comparison
+        names = ["allreduce_3_scalars", "interface_pair_allreduce", "coarse_allgather", "ring_exchange", "interface_pair_neighbour_exchange", "ring_and_coarse_exchange"]
         return {n: {"avg_us": us[k], "bytes": nbytes[k]} for k, n in enumerate(names)}
 
     def sub_op(self, op, u):

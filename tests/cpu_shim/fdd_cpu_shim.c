@@ -367,6 +367,34 @@ int fdd_csr_plan_gather_weighted_norm2(const fdd_csr_plan *plan, double *out, do
 /* ---- interface exchange ---- */
 int fdd_interface_pack(double *slots, const int *slot_of, const double *prefix, int n, void *s) { (void)s; for (int i = 0; i < n; i++) slots[slot_of[i]] = prefix[i]; return 0; }
 int fdd_interface_unpack(double *prefix, const double *slots, const int *slot_of, int n, void *s) { (void)s; for (int i = 0; i < n; i++) prefix[i] = slots[slot_of[i]]; return 0; }
+int fdd_interface_gather(double *buf, const int *index, int n, const double *a, const double *b, void *s)
+{
+    (void)s;
+    const int nc = b ? 2 : 1;
+    for (int i = 0; i < n; i++)
+    {
+        buf[(size_t)i * nc] = a[index[i]];
+        if (b) buf[(size_t)i * nc + 1] = b[index[i]];
+    }
+    return 0;
+}
+int fdd_interface_sum(double *a, double *b, const int *ptr, const int *col, int rows, const double *buf, void *s)
+{
+    (void)s;
+    const int nc = b ? 2 : 1;
+    for (int r = 0; r < rows; r++)
+    {
+        double sa = 0.0, sb = 0.0;
+        for (int k = ptr[r]; k < ptr[r + 1]; k++)
+        {
+            sa += buf[(size_t)col[k] * nc];
+            if (b) sb += buf[(size_t)col[k] * nc + 1];
+        }
+        a[r] = sa;
+        if (b) b[r] = sb;
+    }
+    return 0;
+}
 
 /* ---- device-side GMRES bookkeeping (csrc/fdd_krylov.hip), same statements on the host ---- */
 #define KMAX FDD_MULTI_MAX

@@ -305,5 +305,5 @@ def test_bench_line_of_an_n_rank_run(gpu):
     rd = line["reference_default"]
     assert "composite" in rd["preconditioner"] and rd["f64"]["to_1e-7"]["converged"] is True and rd["f64"]["to_1e-7"]["iterations"] < line["to_1e-7"]["iterations"]
     assert line["cpu_baseline"]["cores"] == 4 and "4 ranks = 4 host threads" in line["cpu_baseline"]["sample"]  # one host core per subdomain
-    assert set(line["comm_us"]) == {"allreduce_3_scalars", "interface_pair_allreduce", "coarse_allgather", "ring_exchange"}
+    assert set(line["comm_us"]) == {"allreduce_3_scalars", "interface_pair_allreduce", "coarse_allgather", "ring_exchange", "interface_pair_neighbour_exchange", "ring_and_coarse_exchange"}
     assert line["config"]["composite"]["num_peers"] == 3
