@@ -913,7 +913,7 @@ static int plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows,
     p->one_per_row = 0;
     // 0: dispatch order; 1: XCD-chunked; >= 2: XCD-windowed with that many consecutive row blocks per XCD.  Short-row
     // (boolean gather) plans and wide-row plans have their own knobs: what neighbouring blocks share differs.
-    p->xcd_chunked = (p->block_nnz == kBlockNnzSmall) ? fdd_env_int("FDD_TUNE_CSR_XCD_SHORT", 0) : fdd_env_int("FDD_TUNE_CSR_XCD", 0);
+    p->xcd_chunked = (p->block_nnz == kBlockNnzSmall) ? fdd_env_int("FDD_TUNE_CSR_XCD_SHORT", 32) : fdd_env_int("FDD_TUNE_CSR_XCD", 0);
     p->num_blocks = 0;
     p->row_blocks_dev = nullptr;
 
@@ -1078,7 +1078,7 @@ int fdd_csr_plan_gather_f32(const fdd_csr_plan *plan, float *t, const int *Qt_pt
     if (last > plan->num_blocks) last = plan->num_blocks;
     if (last <= first) return 0;
     const dim3 grid(last - first), block(kBlock);
-    static const int xcd_window = fdd_env_int("FDD_TUNE_DSSUM_XCD_WINDOW", 0);
+    static const int xcd_window = fdd_env_int("FDD_TUNE_DSSUM_XCD_WINDOW", 32);
     if (plan->block_nnz == kBlockNnzSmall)
         hipLaunchKernelGGL((gather_block_f32_kernel<kBlockNnzSmall>), grid, block, 0, fdd_stream(stream), t, Qt_ptr, Qt_col, u, plan->row_blocks_dev, first, row_lo, row_hi, xcd_window);
     else
@@ -1119,7 +1119,7 @@ int fdd_csr_plan_dssum(const fdd_csr_plan *plan, double *QQtu, double *t, const 
     const dim3 grid(last - first), block(kBlock);
     hipStream_t s = fdd_stream(stream);
     const bool W = node_weight != nullptr && mode != 2, M = point_mask != nullptr && mode != 1;
-    static const int xcd_window = fdd_env_int("FDD_TUNE_DSSUM_XCD_WINDOW", 0); // consecutive row blocks per XCD inside a window of 8x as many (0: dispatch order)
+    static const int xcd_window = fdd_env_int("FDD_TUNE_DSSUM_XCD_WINDOW", 32); // consecutive row blocks per XCD inside a window of 8x as many (0: dispatch order).  C2's Qt gather: L2 fetches 415 -> 356 MB per launch (1.23 -> 1.05 x the 338 MB it must move; profiles/r04_pmc_traffic_c2*.json), 74 -> 72 us
 #define FDD_DSB(MODE, WW, MM)                                                                                                                                                                    \
     do                                                                                                                                                                                          \
     {                                                                                                                                                                                           \

@@ -382,7 +382,8 @@ int launch_mfma(double *Au, const double *u, const int *point_dof, const double 
     const int grid = num_elements < FDD_CU_COUNT ? num_elements : FDD_CU_COUNT;
     // consecutive elements per XCD and sweep (fdd_xcd_windowed_block; 0 = dispatch order, -1 = grid / 8: every XCD's
     // workgroups take one run of consecutive elements per sweep)
-    static const int xcd_env = fdd_env_int("FDD_TUNE_MFMA_XCD_WINDOW", 0);
+    // C3: L2 fetches of the gather form 10.03 -> 9.38 GB per launch with 8 (1.12 -> 1.05 x algorithmic), 1.74 -> 1.62 ms with grid / 8
+    static const int xcd_env = fdd_env_int("FDD_TUNE_MFMA_XCD_WINDOW", -1);
     const int xcd_window = xcd_env < 0 ? grid / FDD_NUM_XCD : xcd_env;
     if (point_dof)
         hipLaunchKernelGGL((mfma_stiffness_kernel<n, true, kAffine>), dim3(grid), dim3(kThreads), lds, fdd_stream(stream), Au, u, point_dof, u_scale, D_hat, G, elem_offset, num_elements, xcd_window);

@@ -144,6 +144,12 @@ class Domain
     int nodes_sub_dofs = -1;
     int dof_shift = -1; // >= 0: subdomain dof d is node d + dof_shift (the numbering makes it so), no renumbering pass
     fdd::memory nu, nr, nr1, nq, nz, np, nt, sub_f, sub_u;
+    // node-space outer GMRES (gmres_nodes): f^ = Qt f, the basis and the preconditioned basis as node vectors, with more
+    // than one rank the basis once more with the interface prefix summed over the ranks, on a composite the basis on the
+    // points as well (the degree tree restricts point data)
+    fdd::memory nf;
+    std::vector<fdd::memory> VN, ZN, VNA, VP;
+    int gmres_nodes_vectors = 0;
     fdd::memory fcg_u_pts;
     bool composite_rhs_from_nodes = true; // composite preconditioner: own part of its right-hand side = the node residual (no second gather of the own points)
     fdd::memory rp;                 // composite preconditioner: the residual on the element-local points (the degree tree and the ring / superdomain exchange start from it)
@@ -1468,10 +1474,237 @@ class Domain
         fcg_finish();
     }
 
+    // ------------------------------------------------------------------
+    // Node-space flexible GMRES(m): the recurrences of domain.tpp:727-914 on one value per assembled node.  The outer
+    // iteration sees its dual vectors (r, q, V_i) only through Qt -- <a, b> = sum_points a (QQt b) mask = sum_nodes
+    // (Qt a) gs(Qt b) mask -- and its continuous ones (Z_j, u) only through Q, so basis, preconditioned basis, residual
+    // and solution are node vectors (0.68 x the points at N = 7), an operator application is the gather-on-load stiffness
+    // + one Qt gather, and no direct-stiffness summation is left: with more than one rank the interface prefix of a new
+    // basis vector is exchanged once (VNA) and the norm exchanges its own.  Same Hessenberg entries, rotations, stopping
+    // tests and iteration count as the point-space form to rounding (test_reference_shaped_and_restructured_paths_agree).
+    // On a composite the basis is kept on the points as well: the preconditioner's degree tree restricts point data.
+    // ------------------------------------------------------------------
+    template <typename PType>
+    void gmres_nodes(fdd::memory &u, fdd::memory &f, PType &subdomain, bool use_relative)
+    {
+        setup_nodes();
+        if (use_preconditioner) setup_dof_maps(subdomain);
+        const int nn = num_local_nodes, m = num_vectors;
+        void *stream = fdd::dev().stream;
+        const bool multi = fdd::comm().size > 1 and num_interface_slots > 0; // rank-uniform
+        const bool points_too = use_preconditioner and composite_precond;
+        if (gmres_nodes_vectors != m or (multi and VNA.empty()) or (points_too and VP.empty()))
+        {
+            for (auto *set : {&VN, &ZN, &VNA, &VP})
+            {
+                for (auto &v : *set) v.free();
+                set->clear();
+            }
+            nf.free();
+            nf = fdd::dev().malloc<DType>(std::max(nn, 1));
+            VN.resize(m + 1);
+            for (auto &v : VN) v = fdd::dev().malloc<DType>(std::max(nn, 1));
+            ZN.resize(m);
+            for (auto &v : ZN)
+            {
+                v = fdd::dev().malloc<DType>(std::max(nn, 1));
+                FDD_CALL(fdd_set_to_value(v.as<double>(), 0.0, nn, 0, stream)); // the Dirichlet ends stay zero: nothing writes them
+            }
+            if (multi)
+            {
+                VNA.resize(m + 1);
+                for (auto &v : VNA) v = fdd::dev().malloc<DType>(std::max(nn, 1));
+            }
+            if (points_too)
+            {
+                VP.resize(m + 1);
+                for (auto &v : VP) v = fdd::dev().malloc<DType>(std::max(num_local_points, 1));
+            }
+            H.assign(m, std::vector<DType>(m, 0.0));
+            c_gmres.assign(m, 0.0);
+            s_gmres.assign(m, 0.0);
+            gamma.assign(m + 1, 0.0);
+            gmres_nodes_vectors = m;
+        }
+        residual_history.clear();
+
+        // the assembled copy <., .> reads: gs over the ranks on the interface prefix, nothing to do on one rank
+        auto assembled = [&](int i) -> fdd::memory & {
+            if (not multi) return VN[i];
+            VNA[i].copyFrom(VN[i], (size_t)nn * sizeof(DType));
+            gs_add_boundary(VNA[i]);
+            return VNA[i];
+        };
+
+        fdd_timer().start("domain.vector_operations");
+        gather_nodes(nf, f); // f^ = Qt f
+        FDD_CALL(fdd_set_to_value(nu.as<double>(), 0.0, nn, 0, stream));
+        nr.copyFrom(nf, (size_t)nn * sizeof(DType));
+        if (points_too) VP[0].copyFrom(f, (size_t)num_local_points * sizeof(DType));
+        fdd_timer().stop("domain.vector_operations");
+
+        DType r_norm, r_0_norm;
+        fdd_timer().start("domain.residual_norm");
+        node_norm(r_0_norm, nr);
+        fdd_timer().stop("domain.residual_norm");
+        residual_history.push_back(r_0_norm);
+        rstdout("Iter %2d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", 0, r_0_norm, 1.0);
+
+        bool converged = false;
+        int iter = 0, j;
+        DType alpha_j, beta_j, gamma_j, gamma_k;
+
+        while (iter < max_iterations)
+        {
+            if (iter > 0)
+            {
+                fdd_timer().start("domain.operator_application");
+                stiffness_from_nodes(q_k, nu);
+                gather_nodes(nq, q_k);
+                fdd_timer().stop("domain.operator_application");
+                fdd_timer().start("domain.vector_operations");
+                FDD_CALL(fdd_vector_vector_addition(nr.as<double>(), 1.0, nf.as<double>(), -1.0, nq.as<double>(), nn, stream));
+                if (points_too) FDD_CALL(fdd_vector_vector_addition(VP[0].as<double>(), 1.0, f.as<double>(), -1.0, q_k.as<double>(), num_local_points, stream));
+                fdd_timer().stop("domain.vector_operations");
+                fdd_timer().start("domain.residual_norm");
+                node_norm(r_norm, nr);
+                fdd_timer().stop("domain.residual_norm");
+                gamma[0] = r_norm;
+            }
+            else
+                gamma[0] = r_0_norm;
+
+            fdd_timer().start("domain.vector_operations");
+            FDD_CALL(fdd_vector_scaling(VN[0].as<double>(), 1.0 / gamma[0], nr.as<double>(), nn, stream));
+            if (points_too) FDD_CALL(fdd_vector_scaling(VP[0].as<double>(), 1.0 / gamma[0], VP[0].as<double>(), num_local_points, stream));
+            fdd_timer().stop("domain.vector_operations");
+            std::vector<const double *> va(m + 1, nullptr); // assembled basis of this cycle
+            va[0] = assembled(0).template as<double>();
+
+            for (j = 0; j < m; j++)
+            {
+                if (points_too) rp.copyFrom(VP[j], (size_t)num_local_points * sizeof(DType)); // the tree restricts V_j on the points
+                precondition_nodes(ZN[j], VN[j], subdomain);
+
+                fdd_timer().start("domain.operator_application");
+                stiffness_from_nodes(q_k, ZN[j]);
+                gather_nodes(nq, q_k);
+                fdd_timer().stop("domain.operator_application");
+
+                // classical Gram-Schmidt: every H[i][j] from the same q (domain.tpp:810-815), then the updates
+                fdd_timer().start("domain.inner_products");
+                std::vector<double> h(j + 1);
+                for (int g0 = 0; g0 < j + 1; g0 += FDD_MULTI_MAX)
+                {
+                    const int cnt = std::min(FDD_MULTI_MAX, j + 1 - g0);
+                    FDD_CALL(fdd_multi_weighted_inner_product(scalars.as<double>(), reduce_ws.as<double>(), nq.as<double>(), va.data() + g0, cnt, node_mask.as<double>(), nn, stream));
+                    fetch_scalars(h.data() + g0, cnt);
+                }
+                for (int i = 0; i < j + 1; i++) H[i][j] = h[i];
+                fdd_timer().stop("domain.inner_products");
+
+                fdd_timer().start("domain.vector_operations");
+                for (int g0 = 0; g0 < j + 1; g0 += FDD_MULTI_MAX)
+                {
+                    const int cnt = std::min(FDD_MULTI_MAX, j + 1 - g0);
+                    const double *ptrs[FDD_MULTI_MAX], *pptrs[FDD_MULTI_MAX];
+                    double coeffs[FDD_MULTI_MAX];
+                    for (int i = 0; i < cnt; i++)
+                    {
+                        ptrs[i] = VN[g0 + i].template as<double>();
+                        if (points_too) pptrs[i] = VP[g0 + i].template as<double>();
+                        coeffs[i] = -H[g0 + i][j];
+                    }
+                    FDD_CALL(fdd_multi_axpy(nq.as<double>(), coeffs, ptrs, cnt, nn, stream));
+                    if (points_too) FDD_CALL(fdd_multi_axpy(q_k.as<double>(), coeffs, pptrs, cnt, num_local_points, stream));
+                }
+                fdd_timer().stop("domain.vector_operations");
+
+                for (int i = 0; i < j; i++)
+                {
+                    DType h_ij = H[i][j];
+                    H[i][j] = c_gmres[i] * h_ij + s_gmres[i] * H[i + 1][j];
+                    H[i + 1][j] = -s_gmres[i] * h_ij + c_gmres[i] * H[i + 1][j];
+                }
+
+                fdd_timer().start("domain.residual_norm");
+                node_norm(alpha_j, nq);
+                fdd_timer().stop("domain.residual_norm");
+
+                if (std::abs(alpha_j) == 0.0)
+                {
+                    converged = true;
+                    break;
+                }
+
+                beta_j = std::sqrt(H[j][j] * H[j][j] + alpha_j * alpha_j);
+                gamma_j = 1.0 / beta_j;
+                c_gmres[j] = H[j][j] * gamma_j;
+                s_gmres[j] = alpha_j * gamma_j;
+                H[j][j] = beta_j;
+                gamma[j + 1] = -s_gmres[j] * gamma[j];
+                gamma[j] = c_gmres[j] * gamma[j];
+
+                r_norm = std::abs(gamma[j + 1]);
+                residual_history.push_back(r_norm);
+                rstdout("Iter %2d: | residual_norm = %24.16g | relative_residual_norm = %24.16g | \n", iter + 1, r_norm, r_norm / r_0_norm);
+
+                if (use_relative ? (r_norm / r_0_norm < tolerance) : (r_norm < tolerance))
+                {
+                    converged = true;
+                    break;
+                }
+                if (iter >= max_iterations or std::isnan(r_norm))
+                {
+                    converged = true;
+                    break;
+                }
+
+                fdd_timer().start("domain.vector_operations");
+                FDD_CALL(fdd_vector_scaling(VN[j + 1].as<double>(), 1.0 / alpha_j, nq.as<double>(), nn, stream));
+                if (points_too) FDD_CALL(fdd_vector_scaling(VP[j + 1].as<double>(), 1.0 / alpha_j, q_k.as<double>(), num_local_points, stream));
+                fdd_timer().stop("domain.vector_operations");
+                if (j + 1 < m) va[j + 1] = assembled(j + 1).template as<double>(); // the last vector of a cycle is never projected on
+
+                iter++;
+            }
+
+            if (j == m) j--;
+
+            // back substitution stored into c_gmres (domain.tpp:891-899)
+            for (int k = j; k >= 0; k--)
+            {
+                gamma_k = gamma[k];
+                for (int i = j; i > k; i--) gamma_k -= H[k][i] * c_gmres[i];
+                c_gmres[k] = gamma_k / H[k][k];
+            }
+
+            fdd_timer().start("domain.vector_operations");
+            for (int g0 = 0; g0 < j + 1; g0 += FDD_MULTI_MAX)
+            {
+                const int cnt = std::min(FDD_MULTI_MAX, j + 1 - g0);
+                const double *ptrs[FDD_MULTI_MAX];
+                for (int i = 0; i < cnt; i++) ptrs[i] = ZN[g0 + i].template as<double>();
+                FDD_CALL(fdd_multi_axpy(nu.as<double>(), c_gmres.data() + g0, ptrs, cnt, nn, stream));
+            }
+            fdd_timer().stop("domain.vector_operations");
+
+            if (converged) break;
+        }
+
+        Q.multiply(u, nu); // the solution back on the element-local points
+        num_iterations = iter;
+    }
+
     // domain.tpp:727-914
     template <typename PType>
     void generalized_minimum_residual(fdd::memory &u, fdd::memory &f, PType &subdomain, bool use_relative = true)
     {
+        if (restructured_outer and can_fcg_nodes(subdomain))
+        {
+            gmres_nodes(u, f, subdomain, use_relative);
+            return;
+        }
         allocate_gmres();
         residual_history.clear();
 

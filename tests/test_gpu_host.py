@@ -386,6 +386,52 @@ def test_curved_mesh_from_files(setup, tmp_path):
         p.close()
 
 
+@pytest.mark.parametrize("E,N,red", [((4, 4, 4), 3, 2), ((3, 3, 3), 7, 6), ((6, 4, 4), 5, 2)])
+def test_kershaw_mesh(setup, E, N, red):
+    """The reference's experiment geometry (run.py:25-47, run.sh:30: Kershaw, eps = 0.3) generated by the host layer
+    (host/box_mesh.hpp: all six geometric factors non-zero, level by level at each level's own degree), against the numpy
+    statement of the same map and, on the problem's own arrays, against the oracle: the fused stiffness bit for bit, the
+    outer PCG and GMRES with the full-domain-decomposition preconditioner iteration for iteration.  4^3 and 3^3 elements
+    do not align with the map's six x-layers (the reference's 16^3 and 64^3 meshes do not either); 6 x 4 x 4 does."""
+    p = H.Problem.kershaw(E, (1, 1, 1), N, red, 0.3)
+    p.set_flag("sub_use_preconditioner", 0)
+    for lvl in range(p.info["num_levels"]):
+        p.set_D_hat(lvl, S.gll(p.level_degree(lvl))[2])
+    meshes = [S.ArrayMesh.from_problem(p, lvl) for lvl in range(p.info["num_levels"])]
+    W = S.OracleWorld([meshes[0]], N)
+    sd = S.OracleSubdomain(None, N, red, meshes=meshes)
+    try:
+        for lvl, m in enumerate(meshes):
+            twin = S.KershawMesh(E, p.level_degree(lvl), 0.3)
+            gmax = max(np.abs(g).max() for g in twin.g)
+            for a, b in [(m.x, twin.x), (m.y, twin.y), (m.z, twin.z)]:
+                assert np.abs(a - b).max() <= 1e-13
+            for k in range(6):
+                assert np.abs(m.g[k] - twin.g[k]).max() <= 1e-13 * gmax, (lvl, k)
+        assert all(np.abs(meshes[0].g[k]).max() > 1e-3 * np.abs(meshes[0].g[0]).max() for k in (3, 4, 5))  # the off-diagonal factors are live
+        p.set_flag("affine_geometry", 1)
+        assert not p.affine_info()["fine_domain"] and p.affine_info()["max_deviation"] > 1e-3  # nothing switches to the affine-elements option
+        p.set_flag("affine_geometry", 0)
+        u = S.seeded_uniform(p.n, 8)
+        assert np.array_equal(p.stiffness(u), W.stiffness([u])[0])
+        u_star, f = p.make_rhs_from(S.seeded_uniform(p.n, 1234))
+
+        def pre(z, r):
+            out, _, _ = sd.solve(r[0], "gmres")
+            z[0][:] = out
+
+        for method in ("fcg", "gmres"):
+            x, its, hist = p.solve(f, method)
+            ox, oits, ohist = W.solve([f], method, precond=pre)
+            assert its == oits, (method, its, oits)
+            assert np.abs(hist - ohist).max() <= 1e-8 * ohist[0]
+            assert np.abs(x - ox[0]).max() <= 1e-6 * np.abs(ox[0]).max()  # long iterations on a badly conditioned operator (test_cpu_multirank's note)
+    finally:
+        sd.close()
+        W.close()
+        p.close()
+
+
 def test_two_dimensional_mesh_from_files(setup, tmp_path):
     """The `dim == 2` branches of Domain / Subdomain and their kernels, end to end (dim2_checks.py)."""
     import dim2_checks
