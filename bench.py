@@ -96,7 +96,7 @@ def parse():
     ap.add_argument("--no-kershaw", action="store_true", help="skip the `kershaw` leg (a second problem on the deformed mesh)")
     ap.add_argument("--print-launch", action="store_true", help="print the launcher command `--gpus N` would start (JSON list) and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-elements", type=int, default=32, help="elements per direction and rank of the CPU baseline's sample (32 = the workload itself, config C2)")
+    ap.add_argument("--cpu-sample-elements", type=int, default=None, help="elements per direction and rank of the CPU baseline's sample (default: the workload itself up to degree 7 -- 32 = config C2 --, 16 beyond: as many points)")
     ap.add_argument("--cpu-sample-steps", type=int, default=3, help="outer PCG iterations of the sample (one rank at C2: about 6 s each on the box's host)")
     return ap.parse_args()
 
@@ -193,7 +193,7 @@ def cpu_baseline_ranks(args, world, P):
     }
 
 
-PMC_FILES = ["profiles/r03_pmc_traffic_c2.json", "profiles/r02_pmc_traffic_c3.json"]  # one per profiled workload
+PMC_FILES = ["profiles/r04_pmc_traffic_c2.json", "profiles/r04_pmc_traffic_c3.json"]  # one per profiled workload (tools/profile_bench.sh at HEAD)
 
 
 def pmc_traffic(kernel_key, elements, degree):
@@ -268,6 +268,8 @@ class _ThreadRanks:
 
 def main():
     args = parse()
+    if args.cpu_sample_elements is None:
+        args.cpu_sample_elements = min(args.elements, 32 if args.degree <= 7 else 16)
     if (args.gpus > 1 or args.print_launch) and "RANK" not in os.environ and args.rehearse_ranks <= 1:
         # `python bench.py --gpus N` from a bare shell: this process launches its own ranks, as the reference's harness
         # does (run.py:160, `jsrun -n P -a 1 -g 1`) -- one CHILD process per GPU under torch.distributed.run (never an
@@ -683,7 +685,10 @@ def run(args, rank, world, max_over_ranks, comm_label):
                 kershaw_leg["reference_default"]["to_1e-7"] = to_tolerance(kp, kf)
                 kershaw_leg["reference_default"]["gmres_to_1e-7"] = to_tolerance(kp, kf, "gmres")
                 configure(True, 32, problem=kp)
+                dk32, _, _ = timed_steps(args.steps, 1, False, problem=kp, rhs=kf)  # also builds the float copies outside the solve's clock
+                kershaw_leg["reference_default"]["f32_ms_per_step"] = dk32 / args.steps * 1e3
                 kershaw_leg["reference_default"]["f32_to_1e-7"] = to_tolerance(kp, kf)
+                kershaw_leg["reference_default"]["f32_gmres_to_1e-7"] = to_tolerance(kp, kf, "gmres")
             progress("Kershaw leg: reference default done")
             kp.close()
 
