@@ -104,3 +104,27 @@ def test_bench_uses_oracle_only_in_cpu_baseline():
     assert "support" not in head and "oracle" not in head.replace("CPU oracle", "").replace("the oracle's N-rank world", "")
     assert "import support" in body
     assert "import support" not in rest
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` from a bare shell starts N ranks itself (the reference's harness does: run.py:160, `jsrun -n P
+    -a 1 -g 1`): the launcher line it would run -- one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1 at a
+    port the launcher's own agent binds and keeps, the same arguments passed through -- and no launch under a launcher."""
+    import json
+    import sys
+
+    bench = os.path.join(S.ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "5", "--comm", "rccl", "--print-launch"], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--standalone"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert "127.0.0.1" in cmd and "--nnodes=1" in cmd and not any("master-port" in c for c in cmd)  # no port number is passed around
+    tail = cmd[cmd.index(bench):]
+    assert tail == [bench, "--gpus", "8", "--steps", "5", "--comm", "rccl"]  # --print-launch itself is not passed on
+    src = open(bench).read()
+    launch = src[src.index("def launch_ranks(args):"):src.index("class _ThreadRanks")]
+    assert "subprocess.run(" in launch and "exec" not in launch.replace("never an exec", "")  # a child process, never an exec
+    main = src[src.index("def main():"):]
+    assert main.index("launch_ranks(args)") < main.index("import torch")  # decided before anything can touch the GPU
+    assert '"RANK" not in os.environ' in main  # under a launcher it is one rank

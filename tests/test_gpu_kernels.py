@@ -1591,3 +1591,70 @@ def test_flexible_dot_with_the_next_gamma(gpu, n):
     k("fdd_dom_inner_product_flexible", flex, ws, r, r1, z, n)
     k("fdd_dom_projection_inner_products", proj, ws, z, r1, z, r1, n)
     assert host(out2)[1] == host(flex)[0] and host(out2)[0] == host(proj)[0]
+
+
+# ------------------------------------------------------------------ the interface exchange's kernels (gs_add on the boundary prefix, domain.tpp:590-594)
+@pytest.mark.parametrize("nb,peers", [(1, 1), (37, 2), (5000, 3), (152000, 7)])
+def test_interface_exchange_kernels(gpu, nb, peers):
+    """Both forms of gs(gs_add) on a rank's boundary prefix.  Dense form: pack into / unpack from the interface-slot vector.
+    Neighbour form: gather (own copies + the parts each sharing rank gets, one or two interleaved vectors), and after the
+    exchange the sum of every node's copies IN THE ORDER ITS ROW LISTS THEM (ascending rank: all sharers must form the same
+    bits) -- against plain numpy loops of the same statements, bit for bit."""
+    rng = np.random.default_rng(1000 + nb)
+    a, b = rnd(nb + 13, 1), rnd(nb + 13, 2)
+    # dense form
+    slots_n = 3 * nb + 5
+    slot_of = rng.permutation(slots_n)[:nb].astype(np.int32)
+    slots = torch.zeros(slots_n, dtype=torch.float64, device=gpu)
+    k("fdd_interface_pack", slots, dev(slot_of, gpu), dev(a, gpu), nb)
+    ref = np.zeros(slots_n)
+    ref[slot_of] = a[:nb]
+    assert np.array_equal(host(slots), ref)
+    back = torch.full((nb,), 9.0, dtype=torch.float64, device=gpu)
+    k("fdd_interface_unpack", back, slots, dev(slot_of, gpu), nb)
+    assert np.array_equal(host(back), a[:nb])
+    # neighbour form: every peer shares a random subset of the prefix
+    shared = [np.sort(rng.choice(nb, size=max(1, nb // (p + 2)), replace=False)).astype(np.int32) for p in range(peers)]
+    index = np.concatenate([np.arange(nb, dtype=np.int32)] + shared)
+    total = sum(len(x) for x in shared)
+    first = np.cumsum([0] + [len(x) for x in shared])
+    me = peers // 2  # this rank's place among the sharers: peers 0..me-1 come before it, the rest after
+    ptr, col = [0], []
+    for node in range(nb):
+        for p in range(peers + 1):
+            if p == me:
+                col.append(node)
+                continue
+            q = p if p < me else p - 1
+            pos = np.searchsorted(shared[q], node)
+            if pos < len(shared[q]) and shared[q][pos] == node:
+                col.append(nb + total + first[q] + pos)
+        ptr.append(len(col))
+    ptr, col = np.array(ptr, np.int32), np.array(col, np.int32)
+    for nc in (1, 2):
+        buf = torch.full((nc * (nb + 2 * total),), -7.0, dtype=torch.float64, device=gpu)
+        k("fdd_interface_gather", buf, dev(index, gpu), nb + total, dev(a, gpu), dev(b, gpu) if nc == 2 else None)
+        got = host(buf).copy()
+        want = np.full(nc * (nb + 2 * total), -7.0)
+        want[0:nc * (nb + total):nc] = a[index]
+        if nc == 2:
+            want[1:nc * (nb + total):nc] = b[index]
+        assert np.array_equal(got, want), nc
+        recv = rnd(nc * total, 30 + nc)  # what the peers would have sent
+        want[nc * (nb + total):] = recv
+        buf = dev(want, gpu)
+        oa, ob = dev(a, gpu).clone(), dev(b, gpu).clone()
+        k("fdd_interface_sum", oa, ob if nc == 2 else None, dev(ptr, gpu), dev(col, gpu), nb, buf)
+        ra, rb = a.copy(), b.copy()
+        for node in range(nb):
+            sa = sb = 0.0
+            for c in col[ptr[node]:ptr[node + 1]]:
+                sa += want[c * nc]
+                if nc == 2:
+                    sb += want[c * nc + 1]
+            ra[node] = sa
+            if nc == 2:
+                rb[node] = sb
+        assert np.array_equal(host(oa), ra), nc  # entries past the prefix untouched
+        if nc == 2:
+            assert np.array_equal(host(ob), rb)
