@@ -19,6 +19,8 @@
 //    order, so the result is bit-identical to the thread-per-row kernel.
 //    A row longer than a block is reduced by the whole workgroup (shuffle
 //    tree; order differs).
+#include <type_traits>
+
 #include "fdd_common.h"
 
 #include <algorithm>
@@ -612,6 +614,127 @@ __global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double
     }
 }
 
+// The gather half alone (MODE 1, no weight: the `Qt` of every operator application of the solve) as a PERSISTENT,
+// software-pipelined kernel.  The one-block-per-workgroup form above is bound by neither bytes nor occupancy (16 VGPRs,
+// 8 waves per SIMD; taking 14 % of its L2 fetches away changed its time by 3 %): a row block is a chain of dependent round
+// trips -- block bounds -> row pointer -> col -> u[col] -> LDS -> barrier -> row sums -> store -- of which a workgroup has
+// only one in flight at a time.  Here a workgroup walks its row blocks with three of them in flight: the 16-byte descriptor
+// of block i + 2, the index stream and row pointers of block i + 1 and the value gathers of block i are outstanding
+// together, and the row sums of block i run under them.  Sums in column order by one lane, as everywhere: same bits.
+template <typename T, int kBlockNnz>
+__global__ __launch_bounds__(kBlock) void gather_pipelined_kernel(T *__restrict__ t, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const T *__restrict__ u, const int4 *__restrict__ meta, int block_first, int nblocks, int row_lo, int row_hi, int xcd_window)
+{
+    __shared__ T x[kBlockNnz];
+    __shared__ int sp[kBlockNnz + 1];
+    constexpr int kIts = kBlockNnz / kBlock;
+    constexpr int kRowIts = kBlockNnz / kBlock;
+    const int G = gridDim.x;
+    int b = fdd_xcd_windowed_block(blockIdx.x, G, xcd_window);
+    if (b >= nblocks) return;
+
+    // descriptor -> (r0, nrows, base, nnz) of the rows of the block that lie in [row_lo, row_hi); only the two blocks that
+    // straddle the range's ends take the branch
+    auto bounds = [&](int4 m, int &r0, int &nrows, int &base, int &nnz) {
+        r0 = m.x;
+        int r1 = m.y;
+        base = m.z;
+        nnz = m.w;
+        if (r0 < row_lo || r1 > row_hi)
+        {
+            r0 = r0 > row_lo ? r0 : row_lo;
+            r1 = r1 < row_hi ? r1 : row_hi;
+            if (r1 < r0) r1 = r0;
+            base = Qt_ptr[r0];
+            nnz = Qt_ptr[r1] - base;
+        }
+        nrows = r1 - r0;
+    };
+    auto load_streams = [&](int (&c)[kIts], int (&rp)[kRowIts], int r0, int nrows, int base, int nnz) {
+#pragma unroll
+        for (int it = 0; it < kIts; it++)
+        {
+            const int k = threadIdx.x + it * kBlock;
+            c[it] = __builtin_nontemporal_load(Qt_col + ((k < nnz) ? base + k : ((nnz > 0) ? base : 0))); // unconditional load on a selected index
+        }
+#pragma unroll
+        for (int it = 0; it < kRowIts; it++)
+        {
+            const int r = threadIdx.x + it * kBlock;
+            rp[it] = Qt_ptr[r0 + ((r < nrows) ? r : 0) + 1];
+        }
+    };
+
+    int r0, nrows, base, nnz;
+    bounds(meta[block_first + b], r0, nrows, base, nnz);
+    int c[kIts], rp[kRowIts];
+    load_streams(c, rp, r0, nrows, base, nnz);
+    int bn = b + G;
+    int4 mn = meta[block_first + (bn < nblocks ? bn : b)]; // descriptor of the next block, one iteration ahead of its use
+
+    for (;;)
+    {
+        const bool more = bn < nblocks;
+        // value gathers of this block (its indices were requested one iteration ago)
+        T v[kIts];
+#pragma unroll
+        for (int it = 0; it < kIts; it++) v[it] = u[c[it]];
+        // index stream and row pointers of the next block, and the descriptor of the one after, behind the gathers
+        int r0n, nrowsn, basen, nnzn;
+        bounds(mn, r0n, nrowsn, basen, nnzn);
+        int cn[kIts], rpn[kRowIts];
+        load_streams(cn, rpn, r0n, nrowsn, basen, nnzn);
+        const int bnn = bn + G;
+        const int4 mnn = meta[block_first + (bnn < nblocks ? bnn : (more ? bn : b))];
+
+#pragma unroll
+        for (int it = 0; it < kIts; it++)
+        {
+            const int k = threadIdx.x + it * kBlock;
+            if (k < nnz) x[k] = v[it]; // 1.0 * v of the reference's boolean rows, bit for bit
+        }
+        if (threadIdx.x == 0) sp[0] = 0;
+#pragma unroll
+        for (int it = 0; it < kRowIts; it++)
+        {
+            const int r = threadIdx.x + it * kBlock;
+            if (r < nrows) sp[r + 1] = rp[it] - base;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kRowIts; it++)
+        {
+            const int r = threadIdx.x + it * kBlock;
+            if (r < nrows)
+            {
+                T s = T(0);
+                for (int j = sp[r]; j < sp[r + 1]; j++) s += x[j];
+                t[r0 + r] = s;
+            }
+        }
+        if (!more) break; // every wave leaves here together: `more` is workgroup-uniform
+        __syncthreads();  // x and sp are rewritten by the next block
+        b = bn;
+        bn = bnn;
+        mn = mnn;
+        r0 = r0n;
+        nrows = nrowsn;
+        base = basen;
+        nnz = nnzn;
+#pragma unroll
+        for (int it = 0; it < kIts; it++) c[it] = cn[it];
+#pragma unroll
+        for (int it = 0; it < kRowIts; it++) rp[it] = rpn[it];
+    }
+}
+
+// workgroups per CU of the persistent gather (0: one row block per workgroup, the forms above).  C2's Qt: 72 us with one
+// block per workgroup, 73.6 / 59.1 / 62.9 / 63.3 us with 2 / 4 / 6 / 8 persistent workgroups per CU
+inline int gather_pipelined_per_cu()
+{
+    static const int v = fdd_env_int("FDD_TUNE_GATHER_PIPELINED", 4);
+    return v;
+}
+
 // sum_nodes s*s*w with s = (Qt u)[node]*w[node], on the same row blocks; a
 // capped grid strides over the blocks, one partial per workgroup
 template <int kBlockNnz>
@@ -767,6 +890,7 @@ struct fdd_csr_plan
     int value_bytes;   // 8: the fp64 entries; 4: a plan of the f32 entries (always row blocks; twice the non-zeros per block measured no faster)
     int num_blocks;
     int *row_blocks_dev; // num_blocks + 1
+    int4 *block_meta_dev = nullptr; // per row block {first row, end row, first non-zero, non-zeros}: one 16-byte scalar load instead of a chain row_blocks -> A_ptr (the persistent gather prefetches it two blocks ahead)
     std::vector<int> row_blocks_host;
     // sliced-ELL copy of the matrix (fdd_csr_plan_attach_sell): the SpMV entries then run on it
     int sell_slices = 0;
@@ -776,6 +900,22 @@ struct fdd_csr_plan
     int *sell_order_dev = nullptr; // slices by decreasing width (nullptr: widths are even, natural order)
     long long sell_entries = 0;
 };
+
+// t[rows of blocks first..last) in [row_lo, row_hi)] = sum of the rows' u entries, boolean short-row plan: the persistent
+// pipelined gather.  false: not applicable (the caller takes the one-block-per-workgroup form)
+template <typename T>
+static bool launch_gather_pipelined(const fdd_csr_plan *plan, T *t, const int *ptr, const int *col, const T *u, int first, int last, int row_lo, int row_hi, hipStream_t s)
+{
+    const int per_cu = gather_pipelined_per_cu();
+    if (per_cu <= 0 || plan->block_nnz != kBlockNnzSmall || plan->block_meta_dev == nullptr || plan->has_long_rows || !plan->unit_values) return false;
+    const int nblocks = last - first;
+    if (nblocks <= 0) return true;
+    int g = per_cu * FDD_CU_COUNT;
+    if (g > nblocks) g = nblocks;
+    static const int xcd_window = fdd_env_int("FDD_TUNE_DSSUM_XCD_WINDOW", 32);
+    hipLaunchKernelGGL((gather_pipelined_kernel<T, kBlockNnzSmall>), dim3(g), dim3(kBlock), 0, s, t, ptr, col, u, plan->block_meta_dev, first, nblocks, row_lo, row_hi, xcd_window);
+    return true;
+}
 
 template <typename T, typename Epi>
 static int sell_launch(const fdd_csr_plan *plan, T *y, const T *x, const Epi &epi, void *stream)
@@ -809,7 +949,11 @@ static int plan_launch(const fdd_csr_plan *plan, double *y, const int *A_ptr, co
     if (plan->kind == 0) return launch_rows(y, A_ptr, A_col, A_val, x, epi, 0, plan->num_rows, stream, plan->unit_values != 0);
     const dim3 grid(plan->num_blocks), block(kBlock);
     static const int split_rows = fdd_env_int("FDD_TUNE_CSR_SPLIT_ROWS", 1);
-    if (plan->unit_values)
+    if (std::is_same<Epi, EpiPlain>::value && plan->unit_values && launch_gather_pipelined<double>(plan, y, A_ptr, A_col, x, 0, plan->num_blocks, 0, plan->num_rows, fdd_stream(stream)))
+    {
+        // y = A x of a boolean short-row matrix (the gather Qt): the persistent pipelined gather, same sums in the same order
+    }
+    else if (plan->unit_values)
         FDD_CSR_BLOCK(Epi, true, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked, split_rows);
     else
         FDD_CSR_BLOCK(Epi, false, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked, split_rows);
@@ -960,9 +1104,17 @@ static int plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows,
 
     hipError_t err = hipMalloc((void **)&p->row_blocks_dev, blocks.size() * sizeof(int));
     if (err == hipSuccess) err = upload_table(p->row_blocks_dev, blocks.data(), blocks.size() * sizeof(int));
+    if (err == hipSuccess)
+    {
+        std::vector<int4> meta((size_t)p->num_blocks);
+        for (int b = 0; b < p->num_blocks; b++) meta[b] = make_int4(blocks[b], blocks[b + 1], A_ptr_host[blocks[b]], A_ptr_host[blocks[b + 1]] - A_ptr_host[blocks[b]]);
+        err = hipMalloc((void **)&p->block_meta_dev, std::max<size_t>(meta.size(), 1) * sizeof(int4));
+        if (err == hipSuccess && not meta.empty()) err = upload_table(p->block_meta_dev, meta.data(), meta.size() * sizeof(int4));
+    }
     if (err != hipSuccess)
     {
         fdd_set_error("fdd_csr_plan_create: %s", hipGetErrorString(err));
+        if (p->block_meta_dev) (void)hipFree(p->block_meta_dev);
         if (p->row_blocks_dev) (void)hipFree(p->row_blocks_dev);
         delete p;
         return (int)err;
@@ -978,6 +1130,7 @@ int fdd_csr_plan_destroy(fdd_csr_plan *plan)
 {
     if (plan == nullptr) return 0;
     if (plan->row_blocks_dev) (void)hipFree(plan->row_blocks_dev);
+    if (plan->block_meta_dev) (void)hipFree(plan->block_meta_dev);
     if (plan->sell_off_dev) (void)hipFree(plan->sell_off_dev);
     if (plan->sell_col_dev) (void)hipFree(plan->sell_col_dev);
     if (plan->sell_val_dev) (void)hipFree(plan->sell_val_dev);
@@ -1079,7 +1232,10 @@ int fdd_csr_plan_gather_f32(const fdd_csr_plan *plan, float *t, const int *Qt_pt
     if (last <= first) return 0;
     const dim3 grid(last - first), block(kBlock);
     static const int xcd_window = fdd_env_int("FDD_TUNE_DSSUM_XCD_WINDOW", 32);
-    if (plan->block_nnz == kBlockNnzSmall)
+    if (launch_gather_pipelined<float>(plan, t, Qt_ptr, Qt_col, u, first, last, row_lo, row_hi, fdd_stream(stream)))
+    {
+    }
+    else if (plan->block_nnz == kBlockNnzSmall)
         hipLaunchKernelGGL((gather_block_f32_kernel<kBlockNnzSmall>), grid, block, 0, fdd_stream(stream), t, Qt_ptr, Qt_col, u, plan->row_blocks_dev, first, row_lo, row_hi, xcd_window);
     else
         hipLaunchKernelGGL((gather_block_f32_kernel<kBlockNnzMax>), grid, block, 0, fdd_stream(stream), t, Qt_ptr, Qt_col, u, plan->row_blocks_dev, first, row_lo, row_hi, xcd_window);
@@ -1138,6 +1294,10 @@ int fdd_csr_plan_dssum(const fdd_csr_plan *plan, double *QQtu, double *t, const 
     else if (mode == 1)
     {
         if (W) FDD_DSB(1, true, false);
+        else if (launch_gather_pipelined<double>(plan, t, Qt_ptr, Qt_col, u, first, last, row_lo, row_hi, s))
+        {
+            // persistent, pipelined form (FDD_TUNE_GATHER_PIPELINED = workgroups per CU; 0: one row block per workgroup)
+        }
         else FDD_DSB(1, false, false);
     }
     else
