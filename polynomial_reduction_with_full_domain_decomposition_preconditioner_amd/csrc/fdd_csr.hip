@@ -475,9 +475,76 @@ __global__ __launch_bounds__(kBlock) void csr_one_per_row_kernel(double *__restr
     }
 }
 
+// The same as a persistent, software-pipelined kernel (as gather_pipelined_kernel below): the index stream (and values,
+// epilogue operands) of a workgroup's next tile are requested behind the gathers of the current one.
+template <typename Epi, bool UNIT, int NPT>
+__global__ __launch_bounds__(kBlock) void csr_one_per_row_pipelined_kernel(double *__restrict__ Au, const int *__restrict__ A_col, const double *__restrict__ A_val, const double *__restrict__ u, Epi epi, int n, int ntiles, int xcd_window)
+{
+    const int G = gridDim.x;
+    int tile = fdd_xcd_windowed_block(blockIdx.x, G, xcd_window);
+    if (tile >= ntiles) return;
+    int c[NPT];
+    double a[NPT];
+    typename Epi::Opnd o[NPT];
+    auto load_streams = [&](int tl, int (&cc)[NPT], double (&aa)[NPT], typename Epi::Opnd (&oo)[NPT]) {
+#pragma unroll
+        for (int r = 0; r < NPT; r++)
+        {
+            const int row = tl * (kBlock * NPT) + r * kBlock + threadIdx.x;
+            const int rs = (row < n) ? row : 0; // unconditional loads on a selected index
+            cc[r] = __builtin_nontemporal_load(A_col + rs);
+            aa[r] = UNIT ? 1.0 : __builtin_nontemporal_load(A_val + rs);
+            oo[r] = epi.operand(rs, Au);
+        }
+    };
+    load_streams(tile, c, a, o);
+    for (;;)
+    {
+        const int next = tile + G;
+        const bool more = next < ntiles;
+        double x[NPT];
+#pragma unroll
+        for (int r = 0; r < NPT; r++) x[r] = u[c[r]];
+        int cn[NPT];
+        double an[NPT];
+        typename Epi::Opnd on[NPT];
+        load_streams(more ? next : tile, cn, an, on);
+#pragma unroll
+        for (int r = 0; r < NPT; r++)
+        {
+            const int row = tile * (kBlock * NPT) + r * kBlock + threadIdx.x;
+            if (row < n) Au[row] = epi.finish(0.0 + a[r] * x[r], o[r], row);
+        }
+        if (!more) break;
+        tile = next;
+#pragma unroll
+        for (int r = 0; r < NPT; r++)
+        {
+            c[r] = cn[r];
+            a[r] = an[r];
+            o[r] = on[r];
+        }
+    }
+}
+
 template <typename Epi>
 int launch_one_per_row(double *Au, const int *A_col, const double *A_val, const double *u, const Epi &epi, int n, void *stream, bool unit_values)
 {
+    // persistent pipelined form: FDD_TUNE_ONE_PER_ROW_PIPELINED = workgroups per CU (0: one tile per workgroup)
+    static const int per_cu = fdd_env_int("FDD_TUNE_ONE_PER_ROW_PIPELINED", 0);
+    if (per_cu > 0)
+    {
+        constexpr int NPT = 4;
+        const int ntiles = (n + kBlock * NPT - 1) / (kBlock * NPT);
+        int g = per_cu * FDD_CU_COUNT;
+        if (g > ntiles) g = ntiles;
+        if (unit_values)
+            hipLaunchKernelGGL((csr_one_per_row_pipelined_kernel<Epi, true, NPT>), dim3(g), dim3(kBlock), 0, fdd_stream(stream), Au, A_col, A_val, u, epi, n, ntiles, 32);
+        else
+            hipLaunchKernelGGL((csr_one_per_row_pipelined_kernel<Epi, false, NPT>), dim3(g), dim3(kBlock), 0, fdd_stream(stream), Au, A_col, A_val, u, epi, n, ntiles, 32);
+        FDD_LAUNCH_CHECK();
+        return 0;
+    }
     static const int npt = fdd_env_int("FDD_TUNE_CSR_ONE_NPT", 4);
     const int per = kBlock * ((npt == 8) ? 8 : 4);
     const int grid = (n + per - 1) / per;
@@ -1371,6 +1438,10 @@ int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr
     {
         if (weight)
             FDD_CSR_BLOCK(EpiWeight, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev, plan->xcd_chunked, 0);
+        else if (launch_gather_pipelined<double>(plan, Au, A_ptr, A_col, u, 0, plan->num_blocks, 0, plan->num_rows, s))
+        {
+            // boolean short rows (the gather Qt): the persistent pipelined gather, same sums in the same order
+        }
         else
             FDD_CSR_BLOCK(EpiPlain, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev, plan->xcd_chunked, 0);
     }
