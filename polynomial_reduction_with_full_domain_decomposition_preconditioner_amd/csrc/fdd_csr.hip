@@ -681,15 +681,17 @@ __global__ __launch_bounds__(kBlock) void dssum_block_kernel(double *out, double
     }
 }
 
-// The gather half alone (MODE 1, no weight: the `Qt` of every operator application of the solve) as a PERSISTENT,
-// software-pipelined kernel.  The one-block-per-workgroup form above is bound by neither bytes nor occupancy (16 VGPRs,
+// Short-row plans (blocks of kBlockNnzSmall non-zeros: the boolean gather `Qt` of every operator application of the solve,
+// the hanging-point rows, the AMG's interpolators) as a PERSISTENT, software-pipelined kernel.  The one-block-per-workgroup
+// form (csr_block_kernel / dssum_block_kernel above) is bound by neither bytes nor occupancy on such matrices (16 VGPRs,
 // 8 waves per SIMD; taking 14 % of its L2 fetches away changed its time by 3 %): a row block is a chain of dependent round
-// trips -- block bounds -> row pointer -> col -> u[col] -> LDS -> barrier -> row sums -> store -- of which a workgroup has
-// only one in flight at a time.  Here a workgroup walks its row blocks with three of them in flight: the 16-byte descriptor
-// of block i + 2, the index stream and row pointers of block i + 1 and the value gathers of block i are outstanding
-// together, and the row sums of block i run under them.  Sums in column order by one lane, as everywhere: same bits.
-template <typename T, int kBlockNnz>
-__global__ __launch_bounds__(kBlock) void gather_pipelined_kernel(T *__restrict__ t, const int *__restrict__ Qt_ptr, const int *__restrict__ Qt_col, const T *__restrict__ u, const int4 *__restrict__ meta, int block_first, int nblocks, int row_lo, int row_hi, int xcd_window)
+// trips -- block bounds -> row pointers -> col (val) -> u[col] -> LDS -> barrier -> row sums -> store -- of which a
+// workgroup has only one in flight at a time.  Here a workgroup walks its row blocks with three of them in flight: the
+// 16-byte descriptor of block i + 2, the index / value streams, row pointers and epilogue operands of block i + 1 and the
+// value gathers of block i are outstanding together, and the row sums of block i run under them.  Products and sums as in
+// csr_block_kernel (column order, one lane per row), the same epilogues: same bits.
+template <typename T, typename Epi, bool UNIT, int kBlockNnz>
+__global__ __launch_bounds__(kBlock) void csr_short_pipelined_kernel(T *__restrict__ Au, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const T *__restrict__ A_val, const T *__restrict__ u, Epi epi, const int4 *__restrict__ meta, int block_first, int nblocks, int row_lo, int row_hi, int xcd_window)
 {
     __shared__ T x[kBlockNnz];
     __shared__ int sp[kBlockNnz + 1];
@@ -711,30 +713,36 @@ __global__ __launch_bounds__(kBlock) void gather_pipelined_kernel(T *__restrict_
             r0 = r0 > row_lo ? r0 : row_lo;
             r1 = r1 < row_hi ? r1 : row_hi;
             if (r1 < r0) r1 = r0;
-            base = Qt_ptr[r0];
-            nnz = Qt_ptr[r1] - base;
+            base = A_ptr[r0];
+            nnz = A_ptr[r1] - base;
         }
         nrows = r1 - r0;
     };
-    auto load_streams = [&](int (&c)[kIts], int (&rp)[kRowIts], int r0, int nrows, int base, int nnz) {
+    auto load_streams = [&](int (&c)[kIts], T (&a)[kIts], int (&rp)[kRowIts], typename Epi::Opnd (&o)[kRowIts], int r0, int nrows, int base, int nnz) {
 #pragma unroll
         for (int it = 0; it < kIts; it++)
         {
             const int k = threadIdx.x + it * kBlock;
-            c[it] = __builtin_nontemporal_load(Qt_col + ((k < nnz) ? base + k : ((nnz > 0) ? base : 0))); // unconditional load on a selected index
+            const int ks = (k < nnz) ? base + k : ((nnz > 0) ? base : 0); // unconditional loads on a selected index
+            c[it] = __builtin_nontemporal_load(A_col + ks);
+            a[it] = UNIT ? T(1) : __builtin_nontemporal_load(A_val + ks);
         }
 #pragma unroll
         for (int it = 0; it < kRowIts; it++)
         {
             const int r = threadIdx.x + it * kBlock;
-            rp[it] = Qt_ptr[r0 + ((r < nrows) ? r : 0) + 1];
+            const int rs = (r < nrows) ? r : 0;
+            rp[it] = A_ptr[r0 + rs + 1];
+            o[it] = epi.operand(r0 + rs, Au);
         }
     };
 
     int r0, nrows, base, nnz;
     bounds(meta[block_first + b], r0, nrows, base, nnz);
     int c[kIts], rp[kRowIts];
-    load_streams(c, rp, r0, nrows, base, nnz);
+    T a[kIts];
+    typename Epi::Opnd o[kRowIts];
+    load_streams(c, a, rp, o, r0, nrows, base, nnz);
     int bn = b + G;
     int4 mn = meta[block_first + (bn < nblocks ? bn : b)]; // descriptor of the next block, one iteration ahead of its use
 
@@ -745,11 +753,13 @@ __global__ __launch_bounds__(kBlock) void gather_pipelined_kernel(T *__restrict_
         T v[kIts];
 #pragma unroll
         for (int it = 0; it < kIts; it++) v[it] = u[c[it]];
-        // index stream and row pointers of the next block, and the descriptor of the one after, behind the gathers
+        // streams of the next block, and the descriptor of the one after, behind the gathers
         int r0n, nrowsn, basen, nnzn;
         bounds(mn, r0n, nrowsn, basen, nnzn);
         int cn[kIts], rpn[kRowIts];
-        load_streams(cn, rpn, r0n, nrowsn, basen, nnzn);
+        T an[kIts];
+        typename Epi::Opnd on[kRowIts];
+        load_streams(cn, an, rpn, on, r0n, nrowsn, basen, nnzn);
         const int bnn = bn + G;
         const int4 mnn = meta[block_first + (bnn < nblocks ? bnn : (more ? bn : b))];
 
@@ -757,7 +767,7 @@ __global__ __launch_bounds__(kBlock) void gather_pipelined_kernel(T *__restrict_
         for (int it = 0; it < kIts; it++)
         {
             const int k = threadIdx.x + it * kBlock;
-            if (k < nnz) x[k] = v[it]; // 1.0 * v of the reference's boolean rows, bit for bit
+            if (k < nnz) x[k] = a[it] * v[it]; // UNIT: 1.0 * v, the reference's boolean rows, bit for bit
         }
         if (threadIdx.x == 0) sp[0] = 0;
 #pragma unroll
@@ -775,7 +785,7 @@ __global__ __launch_bounds__(kBlock) void gather_pipelined_kernel(T *__restrict_
             {
                 T s = T(0);
                 for (int j = sp[r]; j < sp[r + 1]; j++) s += x[j];
-                t[r0 + r] = s;
+                Au[r0 + r] = epi.finish(s, o[it], r0 + r);
             }
         }
         if (!more) break; // every wave leaves here together: `more` is workgroup-uniform
@@ -788,11 +798,27 @@ __global__ __launch_bounds__(kBlock) void gather_pipelined_kernel(T *__restrict_
         base = basen;
         nnz = nnzn;
 #pragma unroll
-        for (int it = 0; it < kIts; it++) c[it] = cn[it];
+        for (int it = 0; it < kIts; it++)
+        {
+            c[it] = cn[it];
+            a[it] = an[it];
+        }
 #pragma unroll
-        for (int it = 0; it < kRowIts; it++) rp[it] = rpn[it];
+        for (int it = 0; it < kRowIts; it++)
+        {
+            rp[it] = rpn[it];
+            o[it] = on[it];
+        }
     }
 }
+
+// the gather of the float preconditioner (subdomain.okl's kernels instantiated with DType = float): no epilogue
+struct EpiPlainF32
+{
+    typedef float Opnd;
+    __device__ float operand(int, const float *) const { return 0.0f; }
+    __device__ float finish(float s, float, int) const { return s; }
+};
 
 // workgroups per CU of the persistent gather (0: one row block per workgroup, the forms above).  C2's Qt: 72 us with one
 // block per workgroup, 73.6 / 59.1 / 62.9 / 63.3 us with 2 / 4 / 6 / 8 persistent workgroups per CU
@@ -968,20 +994,35 @@ struct fdd_csr_plan
     long long sell_entries = 0;
 };
 
-// t[rows of blocks first..last) in [row_lo, row_hi)] = sum of the rows' u entries, boolean short-row plan: the persistent
-// pipelined gather.  false: not applicable (the caller takes the one-block-per-workgroup form)
-template <typename T>
-static bool launch_gather_pipelined(const fdd_csr_plan *plan, T *t, const int *ptr, const int *col, const T *u, int first, int last, int row_lo, int row_hi, hipStream_t s)
+// y[rows of blocks first..last) in [row_lo, row_hi)] = epi(A x) on a short-row plan: the persistent pipelined kernel.
+// false: not applicable (the caller takes the one-block-per-workgroup form)
+template <typename T, typename Epi>
+static bool launch_short_pipelined(const fdd_csr_plan *plan, T *y, const int *ptr, const int *col, const T *val, const T *x, const Epi &epi, int first, int last, int row_lo, int row_hi, hipStream_t s, bool unit)
 {
     const int per_cu = gather_pipelined_per_cu();
-    if (per_cu <= 0 || plan->block_nnz != kBlockNnzSmall || plan->block_meta_dev == nullptr || plan->has_long_rows || !plan->unit_values) return false;
+    if (per_cu <= 0 || plan->block_nnz != kBlockNnzSmall || plan->block_meta_dev == nullptr || plan->has_long_rows) return false;
     const int nblocks = last - first;
     if (nblocks <= 0) return true;
     int g = per_cu * FDD_CU_COUNT;
     if (g > nblocks) g = nblocks;
     static const int xcd_window = fdd_env_int("FDD_TUNE_DSSUM_XCD_WINDOW", 32);
-    hipLaunchKernelGGL((gather_pipelined_kernel<T, kBlockNnzSmall>), dim3(g), dim3(kBlock), 0, s, t, ptr, col, u, plan->block_meta_dev, first, nblocks, row_lo, row_hi, xcd_window);
+    if (unit)
+        hipLaunchKernelGGL((csr_short_pipelined_kernel<T, Epi, true, kBlockNnzSmall>), dim3(g), dim3(kBlock), 0, s, y, ptr, col, val, x, epi, plan->block_meta_dev, first, nblocks, row_lo, row_hi, xcd_window);
+    else
+        hipLaunchKernelGGL((csr_short_pipelined_kernel<T, Epi, false, kBlockNnzSmall>), dim3(g), dim3(kBlock), 0, s, y, ptr, col, val, x, epi, plan->block_meta_dev, first, nblocks, row_lo, row_hi, xcd_window);
     return true;
+}
+
+// the boolean gather t = Qt u (no values read, no epilogue)
+static bool launch_gather_pipelined(const fdd_csr_plan *plan, double *t, const int *ptr, const int *col, const double *u, int first, int last, int row_lo, int row_hi, hipStream_t s)
+{
+    if (!plan->unit_values) return false;
+    return launch_short_pipelined<double, EpiPlain>(plan, t, ptr, col, nullptr, u, EpiPlain{}, first, last, row_lo, row_hi, s, true);
+}
+static bool launch_gather_pipelined(const fdd_csr_plan *plan, float *t, const int *ptr, const int *col, const float *u, int first, int last, int row_lo, int row_hi, hipStream_t s)
+{
+    if (!plan->unit_values) return false;
+    return launch_short_pipelined<float, EpiPlainF32>(plan, t, ptr, col, nullptr, u, EpiPlainF32{}, first, last, row_lo, row_hi, s, true);
 }
 
 template <typename T, typename Epi>
@@ -1016,9 +1057,10 @@ static int plan_launch(const fdd_csr_plan *plan, double *y, const int *A_ptr, co
     if (plan->kind == 0) return launch_rows(y, A_ptr, A_col, A_val, x, epi, 0, plan->num_rows, stream, plan->unit_values != 0);
     const dim3 grid(plan->num_blocks), block(kBlock);
     static const int split_rows = fdd_env_int("FDD_TUNE_CSR_SPLIT_ROWS", 1);
-    if (std::is_same<Epi, EpiPlain>::value && plan->unit_values && launch_gather_pipelined<double>(plan, y, A_ptr, A_col, x, 0, plan->num_blocks, 0, plan->num_rows, fdd_stream(stream)))
+    if (launch_short_pipelined<double, Epi>(plan, y, A_ptr, A_col, A_val, x, epi, 0, plan->num_blocks, 0, plan->num_rows, fdd_stream(stream), plan->unit_values != 0))
     {
-        // y = A x of a boolean short-row matrix (the gather Qt): the persistent pipelined gather, same sums in the same order
+        // a short-row plan (the gather Qt, the hanging-point rows, the AMG's interpolators): the persistent pipelined
+        // kernel, the same products and sums in the same order
     }
     else if (plan->unit_values)
         FDD_CSR_BLOCK(Epi, true, grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked, split_rows);
@@ -1040,7 +1082,10 @@ static int plan_launch_f32(const fdd_csr_plan *plan, float *y, const int *A_ptr,
     if (plan->sell_slices > 0) return sell_launch<float, Epi>(plan, y, x, epi, stream);
     const dim3 grid(plan->num_blocks), block(kBlock);
     static const int split_rows = fdd_env_int("FDD_TUNE_CSR_SPLIT_ROWS", 1);
-    if (plan->block_nnz == kBlockNnzSmall)
+    if (launch_short_pipelined<float, Epi>(plan, y, A_ptr, A_col, A_val, x, epi, 0, plan->num_blocks, 0, plan->num_rows, fdd_stream(stream), false))
+    {
+    }
+    else if (plan->block_nnz == kBlockNnzSmall)
         hipLaunchKernelGGL((csr_block_kernel<float, Epi, false, kBlockNnzSmall>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked, split_rows);
     else
         hipLaunchKernelGGL((csr_block_kernel<float, Epi, false, kBlockNnzMax>), grid, block, 0, fdd_stream(stream), y, A_ptr, A_col, A_val, x, epi, plan->row_blocks_dev, plan->xcd_chunked, split_rows);
@@ -1299,7 +1344,7 @@ int fdd_csr_plan_gather_f32(const fdd_csr_plan *plan, float *t, const int *Qt_pt
     if (last <= first) return 0;
     const dim3 grid(last - first), block(kBlock);
     static const int xcd_window = fdd_env_int("FDD_TUNE_DSSUM_XCD_WINDOW", 32);
-    if (launch_gather_pipelined<float>(plan, t, Qt_ptr, Qt_col, u, first, last, row_lo, row_hi, fdd_stream(stream)))
+    if (launch_gather_pipelined(plan, t, Qt_ptr, Qt_col, u, first, last, row_lo, row_hi, fdd_stream(stream)))
     {
     }
     else if (plan->block_nnz == kBlockNnzSmall)
@@ -1361,7 +1406,7 @@ int fdd_csr_plan_dssum(const fdd_csr_plan *plan, double *QQtu, double *t, const 
     else if (mode == 1)
     {
         if (W) FDD_DSB(1, true, false);
-        else if (launch_gather_pipelined<double>(plan, t, Qt_ptr, Qt_col, u, first, last, row_lo, row_hi, s))
+        else if (launch_gather_pipelined(plan, t, Qt_ptr, Qt_col, u, first, last, row_lo, row_hi, s))
         {
             // persistent, pipelined form (FDD_TUNE_GATHER_PIPELINED = workgroups per CU; 0: one row block per workgroup)
         }
@@ -1437,8 +1482,11 @@ int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr
     if (plan->unit_values)
     {
         if (weight)
-            FDD_CSR_BLOCK(EpiWeight, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev, plan->xcd_chunked, 0);
-        else if (launch_gather_pipelined<double>(plan, Au, A_ptr, A_col, u, 0, plan->num_blocks, 0, plan->num_rows, s))
+        {
+            if (!launch_short_pipelined<double, EpiWeight>(plan, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, 0, plan->num_blocks, 0, plan->num_rows, s, true))
+                FDD_CSR_BLOCK(EpiWeight, true, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev, plan->xcd_chunked, 0);
+        }
+        else if (launch_gather_pipelined(plan, Au, A_ptr, A_col, u, 0, plan->num_blocks, 0, plan->num_rows, s))
         {
             // boolean short rows (the gather Qt): the persistent pipelined gather, same sums in the same order
         }
