@@ -1263,7 +1263,11 @@ int fdd_csr_plan_attach_sell(fdd_csr_plan *plan, const int *A_ptr_host, const in
     if (!fdd_env_int("FDD_TUNE_CSR_SELL", 1)) return 0;
     // one lane per row pays for short rows; wide-row matrices (the coarser Galerkin operators, 40-160 entries per row)
     // stay on the row-block kernel (measured equal at 164 per row, far slower at 41 with rows sorted by length)
-    if ((long long)plan->num_nnz > 32LL * plan->num_rows) return 0;
+    // (round 4: 27-entry rows -- AMG level 1 of the geometric hierarchy -- are faster on the row-block kernel: reference-default
+    // PCG step 8.79 -> 8.50 ms at C2 with the threshold at 16 instead of 32; 15-entry rows -- level 0 on a deformed mesh --
+    // stay here: with 12 the float V-cycle on the Kershaw mesh loses 9 %)
+    static const int sell_max_row = fdd_env_int("FDD_TUNE_CSR_SELL_MAX_ROW", 16);
+    if ((long long)plan->num_nnz > (long long)sell_max_row * plan->num_rows) return 0;
     FDD_REQUIRE(A_ptr_host != nullptr && A_ptr != nullptr && A_col != nullptr && A_val != nullptr);
     const int n = plan->num_rows, slices = (n + kSellSlice - 1) / kSellSlice;
     std::vector<int> off(slices + 1, 0), width(slices, 0);
@@ -1495,9 +1499,13 @@ int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr
     }
     else
     {
+        // valued matrices: short rows on the persistent pipelined kernel
         if (weight)
-            FDD_CSR_BLOCK(EpiWeight, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev, plan->xcd_chunked, 0);
-        else
+        {
+            if (!launch_short_pipelined<double, EpiWeight>(plan, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, 0, plan->num_blocks, 0, plan->num_rows, s, false))
+                FDD_CSR_BLOCK(EpiWeight, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiWeight{weight}, plan->row_blocks_dev, plan->xcd_chunked, 0);
+        }
+        else if (!launch_short_pipelined<double, EpiPlain>(plan, Au, A_ptr, A_col, A_val, u, EpiPlain{}, 0, plan->num_blocks, 0, plan->num_rows, s, false))
             FDD_CSR_BLOCK(EpiPlain, false, grid, block, 0, s, Au, A_ptr, A_col, A_val, u, EpiPlain{}, plan->row_blocks_dev, plan->xcd_chunked, 0);
     }
     FDD_LAUNCH_CHECK();
