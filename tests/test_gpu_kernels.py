@@ -354,7 +354,7 @@ def run_csr_case(gpu, ptr, col, val, ncols, expect_kind=None, exact=True):
             k("fdd_csr_plan_attach_sell", plan, P(ptr), dptr, dcol, dval, ctypes.c_double(1.5), ctypes.byref(attached))
             widths = np.diff(ptr)
             padded = sum(int(widths[i:i + 64].max()) * 64 for i in range(0, rows, 64))
-            assert attached.value == int(padded <= 1.5 * len(val) and len(val) <= 32 * rows)
+            assert attached.value == int(padded <= 1.5 * len(val) and len(val) <= 16 * rows)  # one lane per row pays up to 16 entries per row (27-entry rows measured faster on the row-block kernel)
             if attached.value:
                 out.fill_(7.0)
                 k("fdd_csr_plan_multiply", plan, out, dptr, dcol, dval, du, None)
