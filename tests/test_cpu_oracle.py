@@ -441,3 +441,33 @@ def test_element_diagonal_closed_form_against_the_kernels():
         assert sd.element_diagonal_check() <= 1e-12
         assert np.all(sd.jacobi_diagonal() > 0)
         sd.close()
+
+
+def test_kershaw_map_properties():
+    """The generalized Kershaw map the meshes of the reference's experiments come from (run.py:25-47: eps = 0.3; here
+    tests/support.py: kershaw_map, the numpy statement host/box_mesh.hpp is held to): the identity at eps = 1, x kept, the
+    boundary of the cube mapped onto itself, continuous across the six x-layers, monotone in y and z (positive Jacobian),
+    and the isoparametric factors of a mesh on it symmetric positive definite point by point with all six live."""
+    rng = np.random.default_rng(3)
+    x, y, z = rng.uniform(0, 1, (3, 20000))
+    X, Y, Z = S.kershaw_map(1.0, 1.0, x, y, z)
+    assert np.array_equal(X, x) and np.abs(Y - y).max() <= 1e-15 and np.abs(Z - z).max() <= 1e-15
+    for eps in (0.3, 0.6):
+        X, Y, Z = S.kershaw_map(eps, eps, x, y, z)
+        assert np.array_equal(X, x) and Y.min() >= 0 and Y.max() <= 1 and Z.min() >= 0 and Z.max() <= 1
+        for face in (0.0, 1.0):  # y = 0, 1 and z = 0, 1 stay put
+            assert np.abs(S.kershaw_map(eps, eps, x, np.full_like(y, face), z)[1] - face).max() <= 1e-15
+            assert np.abs(S.kershaw_map(eps, eps, x, y, np.full_like(z, face))[2] - face).max() <= 1e-15
+        for k in range(1, 6):  # continuity across the layer boundaries x = k / 6
+            lo, hi = S.kershaw_map(eps, eps, np.full_like(y, k / 6.0 - 1e-13), y, z), S.kershaw_map(eps, eps, np.full_like(y, k / 6.0 + 1e-13), y, z)
+            assert np.abs(lo[1] - hi[1]).max() <= 1e-11 and np.abs(lo[2] - hi[2]).max() <= 1e-11
+        ys = np.sort(y)
+        for xv in (0.05, 0.21, 0.4, 0.62, 0.77, 0.95):  # monotone sections
+            assert np.all(np.diff(S.kershaw_map(eps, eps, np.full_like(ys, xv), ys, ys)[1]) > 0)
+    m = S.KershawMesh((6, 4, 4), 3, 0.3)
+    G = np.stack(m.g)  # rr, ss, tt, rs, rt, st
+    assert all(np.abs(G[k]).max() > 1e-3 * np.abs(G[0]).max() for k in (3, 4, 5))
+    M = np.empty((m.num_local_points, 3, 3))
+    for (a, b), k in zip([(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)], range(6)):
+        M[:, a, b] = M[:, b, a] = G[k]
+    assert np.linalg.eigvalsh(M).min() > 0
