@@ -95,6 +95,7 @@ int fdd_csr_plan_create(fdd_csr_plan **plan, const int *A_ptr_host, int num_rows
 int fdd_csr_plan_destroy(fdd_csr_plan *plan);
 int fdd_csr_plan_num_blocks(const fdd_csr_plan *plan, int *num_blocks);
 int fdd_csr_plan_kind(const fdd_csr_plan *plan, int *kind); /* 0 = thread-per-row, 1 = LDS-staged row blocks */
+int fdd_csr_plan_pipelined(const fdd_csr_plan *plan, int *pipelined); /* 1: a short-row plan whose SpMV / gather entries run on the persistent, software-pipelined kernel (profile labels) */
 /* Tell the plan that every stored value is exactly 1.0 (the boolean gather / scatter matrices Q, Qt,
  * Q_int, ...; CSR_Matrix::assemble checks its host values): the kernels then skip the val array --
  * 1.0*x is x, so results are unchanged and 8 of the 12 bytes per non-zero are not moved. */

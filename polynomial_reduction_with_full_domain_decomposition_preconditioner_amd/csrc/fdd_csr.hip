@@ -1461,6 +1461,15 @@ int fdd_csr_plan_kind(const fdd_csr_plan *plan, int *kind)
     return 0;
 }
 
+// 1 where the plan's SpMV / gather entries run on the persistent pipelined short-row kernel (csr_short_pipelined_kernel):
+// what a profile label should name
+int fdd_csr_plan_pipelined(const fdd_csr_plan *plan, int *pipelined)
+{
+    FDD_REQUIRE(plan != nullptr && pipelined != nullptr);
+    *pipelined = (gather_pipelined_per_cu() > 0 && plan->kind == 1 && plan->block_nnz == kBlockNnzSmall && plan->block_meta_dev != nullptr && !plan->has_long_rows && plan->sell_slices == 0) ? 1 : 0;
+    return 0;
+}
+
 // launch csr_block_kernel for the plan's block size
 
 int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const double *weight, void *stream)

@@ -34,6 +34,7 @@ class CSR_Matrix
     std::vector<std::tuple<int, int, DType>> entries;
     fdd_csr_plan *plan = nullptr;
     int plan_kind = 0;
+    bool plan_pipelined = false; // a short-row plan served by the persistent pipelined kernel (profile labels name the kernel that runs)
     bool lazy_identity = false; // initialize_identity(): the arrays do not exist yet
 
     void initialization_check()
@@ -193,7 +194,7 @@ class CSR_Matrix
         materialize();
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
-        fdd::ProfileScope prof(sell ? "sell_kernel<EpiAxpby>" : plan_kind == 0 ? "csr_row_kernel<EpiAxpby>" : "csr_block_kernel<EpiAxpby>", algorithmic_bytes(beta != 0.0));
+        fdd::ProfileScope prof(sell ? "sell_kernel<EpiAxpby>" : plan_kind == 0 ? "csr_row_kernel<EpiAxpby>" : (plan_pipelined ? "csr_short_pipelined_kernel<EpiAxpby>" : "csr_block_kernel<EpiAxpby>"), algorithmic_bytes(beta != 0.0));
         FDD_CALL(fdd_csr_plan_matvec(plan, y.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), x.as<double>(), alpha, beta, fdd::dev().stream));
     }
 
@@ -203,7 +204,7 @@ class CSR_Matrix
         materialize();
         if ((num_rows == 0) or (num_cols == 0)) return;
         initialization_check();
-        fdd::ProfileScope prof(sell ? "sell_kernel<EpiAxpby>" : plan_kind == 0 ? "csr_row_kernel<EpiAxpby>" : "csr_block_kernel<EpiAxpby>", algorithmic_bytes(beta != 0.0));
+        fdd::ProfileScope prof(sell ? "sell_kernel<EpiAxpby>" : plan_kind == 0 ? "csr_row_kernel<EpiAxpby>" : (plan_pipelined ? "csr_short_pipelined_kernel<EpiAxpby>" : "csr_block_kernel<EpiAxpby>"), algorithmic_bytes(beta != 0.0));
         FDD_CALL(fdd_csr_plan_matvec_to(plan, y.as<double>(), y_in.as<double>(), ptr.as<int>(), col.as<int>(), val.as<double>(), x.as<double>(), alpha, beta, fdd::dev().stream));
     }
 
@@ -272,6 +273,11 @@ class CSR_Matrix
         if (plan) FDD_CALL(fdd_csr_plan_destroy(plan));
         FDD_CALL(fdd_csr_plan_create(&plan, ptr_hst.data(), num_rows, num_cols, num_nnz));
         FDD_CALL(fdd_csr_plan_kind(plan, &plan_kind));
+        {
+            int pipelined = 0;
+            FDD_CALL(fdd_csr_plan_pipelined(plan, &pipelined));
+            plan_pipelined = pipelined != 0;
+        }
         FDD_CALL(fdd_csr_plan_set_unit_values(plan, unit_values ? 1 : 0));
         // short, even rows (AMG levels, interpolators): a sliced-ELL copy the SpMV entries then run on
         sell = 0;
@@ -377,7 +383,7 @@ class CSR_Matrix
         const double bytes = 4.0 * rows + frac * num_nnz * (4.0 + (mode != 2 ? 8.0 : 0.0) + (mode != 1 ? 8.0 : 0.0) + ((point_mask and mode != 1) ? 8.0 : 0.0)) +
                              ((node_weight and mode != 2) ? 8.0 * rows : 0.0) + ((t or mode != 0) ? 8.0 * rows : 0.0);
         const char *key = (plan_kind == 0) ? (mode == 0 ? "dssum_kernel<fused>" : mode == 1 ? "dssum_kernel<gather>" : "dssum_kernel<scatter>")
-                                           : (mode == 0 ? "dssum_block_kernel<fused>" : mode == 1 ? "dssum_block_kernel<gather>" : "dssum_block_kernel<scatter>");
+                                           : (mode == 0 ? "dssum_block_kernel<fused>" : mode == 1 ? ((plan_pipelined and not node_weight) ? "csr_short_pipelined_kernel<gather>" : "dssum_block_kernel<gather>") : "dssum_block_kernel<scatter>");
         fdd::ProfileScope prof(key, bytes);
         FDD_CALL(fdd_csr_plan_dssum(plan, out, t, ptr.as<int>(), col.as<int>(), u, node_weight, point_mask, row_lo, row_hi, mode, fdd::dev().stream));
     }
@@ -386,7 +392,7 @@ class CSR_Matrix
     void gather_f32(float *t, const float *u, int row_lo, int row_hi)
     {
         if (row_hi <= row_lo or num_nnz == 0) return;
-        fdd::ProfileScope prof("gather_block_f32_kernel", 8.0 * (row_hi - row_lo) + 8.0 * num_nnz * ((double)(row_hi - row_lo) / std::max(num_rows, 1)));
+        fdd::ProfileScope prof((plan_pipelined ? "csr_short_pipelined_kernel<gather, f32>" : "gather_block_f32_kernel"), 8.0 * (row_hi - row_lo) + 8.0 * num_nnz * ((double)(row_hi - row_lo) / std::max(num_rows, 1)));
         FDD_CALL(fdd_csr_plan_gather_f32(plan, t, ptr.as<int>(), col.as<int>(), u, row_lo, row_hi, fdd::dev().stream));
     }
 
