@@ -593,12 +593,12 @@ def run(args, rank, world, max_over_ranks, comm_label):
         m = e * N + 1
         if 27 * m**3 >= 2**31:  # int32 non-zero count (csr_matrix.tpp:132-134): larger node grids use SURVEY's 225^3
             m = 225
-        us, nbytes, nnz = H.spmv_stencil_time(m, 10)
+        us, nbytes, nnz = H.spmv_stencil_time(m, 40)  # 40 launches (32 ms): the average over 10 moved by 3 % from run to run on one box
         spmv["27-point stencil, %d^3 rows" % m] = {"frac_moved_of_hbm_peak": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "GBps_moved": nbytes / (us * 1e-6) / 1e9, "bytes_moved": nbytes, "avg_us": us, "nnz": nnz,
                                                   "kernel": "csr_block_kernel<EpiPlain>"}
     for which, label in ((0, "Q (scatter, 1 nnz/row)"), (1, "Qt (gather, 1-8 nnz/row)")):
         us, nbytes = ctypes.c_double(), ctypes.c_double()
-        lib.host().call("fddh_problem_spmv_time", prob.h, which, 20, ctypes.byref(us), ctypes.byref(nbytes))
+        lib.host().call("fddh_problem_spmv_time", prob.h, which, 100, ctypes.byref(us), ctypes.byref(nbytes))
         # These two matrices are boolean with one entry per point, and the plan knows: the value array (and for Q the row
         # pointers, ptr[i] = i) are not read.  bytes_moved is what the kernels read and write (index 4 B + vector entries
         # 8 B, + 4 B row pointers for Qt) and is the figure to hold against the HBM peak; SURVEY 8(d)'s CSR formula
