@@ -260,6 +260,13 @@ class Hierarchy
     }
     fdd::memory &solution32() { return levels[0].u32; }
 
+    // subdomain.hpp:236 (swept by run.py:154): a captured graph belongs to one cycle count
+    void set_num_vcycles(int v)
+    {
+        if (v != num_vcycles) destroy_graphs();
+        num_vcycles = v;
+    }
+
     // 32 needs the fused sequence with a Chebyshev order of at least 2; a captured graph belongs to one precision
     bool set_precision(int bits)
     {

@@ -1022,6 +1022,23 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
             // stiffness, gather, V-cycle)
             if (p->subdomain and not p->subdomain->set_precision(value)) return fail("preconditioner_precision is 64 or 32 (32: 3-D regions on the dof-space inner solve, Chebyshev order >= 2)");
         }
+        else if (s == "amg_num_vcycles")
+        {
+            // subdomain.hpp:236 `num_vcycles` (run.py:154 rewrites the line and rebuilds; here a run-time switch)
+            if (!p->subdomain) return fail("problem was created without a Subdomain");
+            if (value < 1 || value > 16) return fail("amg_num_vcycles must lie in 1..16");
+            p->subdomain->num_vcycles = value;
+            p->subdomain->amg_hierarchy.set_num_vcycles(value);
+        }
+        else if (s == "amg_cheby_order")
+        {
+            // subdomain.hpp:237 `cheby_order` (run.py:155; clamped to 1..4 by subdomain.tpp:3477-3478).  The smoother's
+            // coefficients are computed when the hierarchy is built: set it before (fddh_problem_amg_build / first solve)
+            if (!p->subdomain) return fail("problem was created without a Subdomain");
+            if (value < 1 || value > 4) return fail("amg_cheby_order must lie in 1..4 (subdomain.tpp:3477-3478)");
+            if (p->subdomain->amg_hierarchy.ready() && value != p->subdomain->cheby_order) return fail("amg_cheby_order must be set before the hierarchy is built");
+            p->subdomain->cheby_order = value;
+        }
         else if (s == "amg_precision")
         {
             // AMG/config.hpp:4 `Float`: 64 (double) or 32 (float)

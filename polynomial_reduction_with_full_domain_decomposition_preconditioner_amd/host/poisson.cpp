@@ -22,6 +22,14 @@
  *                        (Subdomain::use_preconditioner = false; the
  *                        reference's default is true, subdomain.hpp:231,
  *                        and so is this driver's); --amg says it explicitly
+ *     --inner K          inner Krylov steps per preconditioner application
+ *                        (subdomain.hpp:229-230 num_vectors = max_iterations;
+ *                        run.py:151-152 sweeps 1, 2, 4, 8; default 4)
+ *     --inner-solver fcg|gmres   domain.hpp:116 preconditioner_type (run.py:150)
+ *     --vcycles V        subdomain.hpp:236 num_vcycles (run.py:153)
+ *     --cheby C          subdomain.hpp:237 cheby_order, 1..4 (run.py:154)
+ *     --float            the preconditioner in single precision
+ *                        (config.hpp:19-20 PTYPE / AMG/config.hpp:4 Float; run.py:156)
  *     --block-local      more than one rank: every rank keeps its own
  *                        elements only (no neighbour rings, no superdomain:
  *                        block-Jacobi).  The overlap arguments then have no
@@ -145,6 +153,7 @@ int main(int argc, char *argv[])
     int block_local = 0;
     const char *write_dir = nullptr;
     double kershaw_eps = 1.0;
+    int inner_steps = 0, inner_solver = -1, vcycles = 0, cheby = 0, single = 0;
     for (int a = 6; a < argc; a++)
     {
         if (!strcmp(argv[a], "--box") && a + 3 < argc)
@@ -154,6 +163,16 @@ int main(int argc, char *argv[])
             box[2] = atoi(argv[a + 3]);
             a += 3;
         }
+        else if (!strcmp(argv[a], "--inner") && a + 1 < argc)
+            inner_steps = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--inner-solver") && a + 1 < argc)
+            inner_solver = !strcmp(argv[++a], "fcg") ? 0 : 1;
+        else if (!strcmp(argv[a], "--vcycles") && a + 1 < argc)
+            vcycles = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--cheby") && a + 1 < argc)
+            cheby = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--float"))
+            single = 1;
         else if (!strcmp(argv[a], "--kershaw") && a + 1 < argc)
             kershaw_eps = atof(argv[++a]);
         else if (!strcmp(argv[a], "--solver") && a + 1 < argc)
@@ -215,6 +234,14 @@ int main(int argc, char *argv[])
         if (fddh_problem_create_dir_ex(&problem, directory, poly_degree, poly_reduction, subdomain_overlap, superdomain_overlap, flags)) die("fddh_problem_create_dir_ex");
     }
     if (with_subdomain && fddh_problem_set_flag(problem, "sub_use_preconditioner", use_amg)) die("fddh_problem_set_flag");
+    // the parameters run.py:150-156 sweeps by rewriting header lines and rebuilding: run-time switches here
+    if (with_subdomain)
+    {
+        if (cheby > 0 && fddh_problem_set_flag(problem, "amg_cheby_order", cheby)) die("amg_cheby_order");
+        if (vcycles > 0 && fddh_problem_set_flag(problem, "amg_num_vcycles", vcycles)) die("amg_num_vcycles");
+        if (single && fddh_problem_set_flag(problem, "preconditioner_precision", 32)) die("preconditioner_precision");
+        if ((inner_steps > 0 || inner_solver >= 0) && fddh_problem_set_options(problem, -1, NAN, -1, -1, inner_solver, inner_steps > 0 ? inner_steps : -1, inner_steps > 0 ? inner_steps : -1, -1)) die("fddh_problem_set_options");
+    }
 
     long long info[FDDH_INFO_COUNT];
     fddh_problem_info(problem, info, FDDH_INFO_COUNT);

@@ -66,7 +66,7 @@ def check_amg_f32(p, N, red):
         o32.close()
 
 
-def check_amg(p, N, red, outer_solve=True, builder="scipy"):
+def check_amg(p, N, red, outer_solve=True, builder="scipy", cheby_order=2, num_vcycles=1):
     meshes = [S.ArrayMesh.from_problem(p, lvl) for lvl in range(p.info["num_levels"])]
     sd = S.OracleSubdomain(None, N, red, meshes=meshes)
     W = S.OracleWorld([meshes[0]], N)
@@ -86,8 +86,11 @@ def check_amg(p, N, red, outer_solve=True, builder="scipy"):
             levels = S.low_order_hierarchy(meshes[0], dof, nd)
         else:
             # the host layer's own FEM matrix + smoothed-aggregation hierarchy (host/low_order.hpp)
+            # the reference's sweep parameters (subdomain.hpp:236-237, rewritten by run.py:153-155) as run-time switches
+            p.set_flag("amg_cheby_order", cheby_order)
+            p.set_flag("amg_num_vcycles", num_vcycles)
             assert p.amg_build(coarsest_size=40) >= 2
-            levels = p.amg_levels()
+            levels = p.amg_levels(cheby_order)
         assert len(levels) >= 2 and levels[0]["A"].shape[0] == nd and levels[-1]["P"] is None
         # the oracle's copy: level 0 renumbered (same values, same Chebyshev data), coarse levels shared
         import scipy.sparse as sp
@@ -101,7 +104,7 @@ def check_amg(p, N, red, outer_solve=True, builder="scipy"):
         olevels = [fine] + levels[1:]
         if builder == "scipy":
             p.amg_attach(levels)
-        sd.attach_amg(olevels)
+        sd.attach_amg(olevels, cheby_order=cheby_order, num_vcycles=num_vcycles)
 
         # one application of the V-cycle preconditioner
         r = S.seeded_uniform(p.n, 5) - 0.5

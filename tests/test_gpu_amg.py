@@ -12,6 +12,7 @@ import pytest
 import amg_checks
 import support as S
 from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import host_api as H
+from polynomial_reduction_with_full_domain_decomposition_preconditioner_amd import lib
 
 pytestmark = pytest.mark.gpu
 
@@ -113,5 +114,25 @@ def test_amg_with_the_host_layers_own_hierarchy(own_stream, E, N, red):
     try:
         its = amg_checks.check_amg(p, N, red, builder="product")
         assert its is not None and its <= 8
+    finally:
+        p.close()
+
+
+@pytest.mark.parametrize("cheby_order,num_vcycles", [(1, 1), (2, 2), (3, 1), (4, 2)])
+def test_reference_sweep_parameters_as_run_time_switches(own_stream, cheby_order, num_vcycles):
+    """The parameters the reference's harness sweeps by rewriting header lines and rebuilding (run.py:150-156: subdomain.hpp:236
+    `num_vcycles`, :237 `cheby_order`, clamped to 1..4 by subdomain.tpp:3477-3478) as run-time switches of the host layer
+    (`amg_num_vcycles`, `amg_cheby_order`; `poisson --vcycles / --cheby`): the V-cycle with them against the oracle's with the
+    same hierarchy, the inner solves and the outer solve iteration for iteration; the order cannot change under a built
+    hierarchy (its coefficients are the hierarchy's)."""
+    p = make_problem((4, 4, 4), 3, 2)
+    try:
+        its = amg_checks.check_amg(p, 3, 2, builder="product", cheby_order=cheby_order, num_vcycles=num_vcycles)
+        assert its is not None and its <= 10
+        with pytest.raises(lib.FddError):
+            p.set_flag("amg_cheby_order", 1 if cheby_order != 1 else 2)
+        p.set_flag("amg_num_vcycles", 1)  # any time: the captured graph is dropped
+        with pytest.raises(lib.FddError):
+            p.set_flag("amg_num_vcycles", 0)
     finally:
         p.close()
