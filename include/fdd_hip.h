@@ -250,6 +250,9 @@ int fdd_amg_dot(double *out, double *ws, const double *x, const double *y, int s
 /* sequence; vectors are read once)                                      */
 /* ------------------------------------------------------------------ */
 #define FDD_MULTI_MAX 8
+/* doubles per result slot of one Arnoldi step on the device: (j + 1) projections and the norm behind them, j < FDD_MULTI_MAX
+ * (the inner solve runs up to FDD_MULTI_MAX steps per cycle: run.py:151-152 sweeps 1, 2, 4, 8) */
+#define FDD_GMRES_SLOT (FDD_MULTI_MAX + 2)
 /* out[i] = sum a*b[i]*w, i < m <= 8: the (j+1) weighted_inner_product launches of one
  * Arnoldi step (subdomain.tpp:4389-4394).  b is a HOST array of m device pointers. */
 int fdd_multi_weighted_inner_product(double *out, double *ws, const double *a, const double *const *b, int m, const double *w, int n, void *stream);

@@ -1102,7 +1102,7 @@ class Subdomain
                 else
                     operator_dofs_f32(sp.qa, *Wm[j], inv_dev + j);
 
-                double *slot = sc + (j & 1) * FDD_MULTI_MAX;
+                double *slot = sc + (j & 1) * FDD_GMRES_SLOT;
                 dot(slot, sp.qa, W.data(), inv_dev, j + 1);
                 {
                     fdd::ProfileScope prof("reduce_vec2_kernel<MultiAxpyNormF32>", 4.0 * nd * (j + 3));
@@ -1171,7 +1171,7 @@ class Subdomain
   private:
 
   public:
-    bool composite_dof_space() const { return is_composite and comp_dofs_ready and assembled_inner and device_bookkeeping and num_vectors + 2 <= FDD_MULTI_MAX; }
+    bool composite_dof_space() const { return is_composite and comp_dofs_ready and assembled_inner and device_bookkeeping and num_vectors <= FDD_MULTI_MAX; }
     int own_dofs() const { return is_composite ? comp.num_own_dofs : subdomain_operator.num_extended_dofs; }
 
     // z~ = M^-1 r for the node-space outer solve: r is the outer residual on the rank's own points (the degree tree
@@ -1515,7 +1515,7 @@ class Subdomain
         allocate_krylov_scalars(); // the point-space Krylov basis is allocated by the solvers that use it
 
         reduce_ws = fdd::dev().malloc<double>(fdd_reduce_workspace_doubles());
-        scalars = fdd::dev().malloc<double>(2 * FDD_MULTI_MAX);
+        scalars = fdd::dev().malloc<double>(2 * FDD_GMRES_SLOT);
 
         // the big boolean matrices' host mirrors are not needed after setup
         subdomain_operator.Q.release_host();
@@ -2082,7 +2082,7 @@ class Subdomain
     // 4 node passes per step instead of 3 + 2(j+1) + 1 SpMVs.
     bool can_restructure() const
     {
-        return not is_composite and subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0 and not use_preconditioner and not use_jacobi and num_vectors + 1 <= FDD_MULTI_MAX;
+        return not is_composite and subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0 and not use_preconditioner and not use_jacobi and num_vectors <= FDD_MULTI_MAX;
     }
 
     void gather_weighted(fdd::memory &t, fdd::memory &v)
@@ -2258,7 +2258,7 @@ class Subdomain
     bool can_assemble() const
     {
         if (is_composite) return false;
-        if (not(subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0 and num_vectors + 1 <= FDD_MULTI_MAX and dim == 3)) return false;
+        if (not(subdomain_operator.Qt.unit_values and QQt_int.is_identity and superdomain_operator.num_extended_dofs == 0 and num_vectors <= FDD_MULTI_MAX and dim == 3)) return false;
         for (auto &ll : subdomain_operator.level_lists)
             if (ll.poly_degree > 15) return false;
         return true;
@@ -2498,7 +2498,7 @@ class Subdomain
                 else
                     operator_dofs(qa, *Wm[j], inv_dev + j);
 
-                double *slot = sc + (j & 1) * FDD_MULTI_MAX;
+                double *slot = sc + (j & 1) * FDD_GMRES_SLOT;
                 dot_dofs(slot, qa, W.data(), inv_dev, j + 1);
                 {
                     fdd::ProfileScope prof("reduce_vec2_kernel<MultiAxpyNorm>", 8.0 * nd * (j + 3 + (nw ? 1 : 0)));
@@ -2566,7 +2566,7 @@ class Subdomain
     // the solve itself, dof vectors in and out (callers that already hold assembled data skip Qt / Q)
     void gmres_dofs(fdd::memory &ua, fdd::memory &fa, bool print_history = true, bool use_relative = false)
     {
-        if (device_bookkeeping and num_vectors + 2 <= FDD_MULTI_MAX)
+        if (device_bookkeeping and num_vectors <= FDD_MULTI_MAX)
         {
             gmres_dofs_device(ua, fa, print_history, use_relative);
             return;

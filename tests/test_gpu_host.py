@@ -320,12 +320,13 @@ def test_mesh_file_roundtrip(setup, tmp_path):
         q.close()
 
 
-@pytest.mark.parametrize("nv,mi", [(2, 5), (3, 7), (4, 9)])
+@pytest.mark.parametrize("nv,mi", [(2, 5), (3, 7), (4, 9), (1, 1), (7, 7), (8, 8), (8, 11)])
 @pytest.mark.parametrize("device_bookkeeping", [0, 1])
 def test_inner_gmres_restarts_and_stops_inside_a_cycle(setup, nv, mi, device_bookkeeping):
     """Inner GMRES(nv) with max_iterations not a multiple of nv: restart cycles (the residual is
     rebuilt from the dof-space solution) and a stop in the middle of the last cycle -- recorded by the
-    device-side bookkeeping while the remaining steps still run -- against the oracle's host loop."""
+    device-side bookkeeping while the remaining steps still run -- against the oracle's host loop.  nv = mi = 1, 2, 4, 8 are
+    the settings the reference's harness sweeps (run.py:151-152); 8 is the most the device path holds (FDD_MULTI_MAX)."""
     p = make_problem(E1, N1, RED1, True)
     sd = oracle_subdomain(p, N1, RED1)
     try:
