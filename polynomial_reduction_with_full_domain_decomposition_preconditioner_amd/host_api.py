@@ -174,13 +174,22 @@ def comm_torch_callbacks(on_gpu: bool = True, staged: bool = False) -> None:
 
     rank, size = dist.get_rank(), dist.get_world_size()
 
+    views = {}  # (pointer, length, dtype) -> tensor view: the solve's exchange buffers are the same few on every call
+
     def wrap(ptr, n, dtype):
+        key = (int(ptr or 0), int(n), dtype)
+        t = views.get(key)
+        if t is not None:
+            return t
         if on_gpu:
             typestr = {torch.float64: "<f8", torch.uint8: "|u1"}[dtype]
-            return torch.as_tensor(_DevView(ptr, (n,), typestr), device="cuda")
-        ctype = {torch.float64: ctypes.c_double, torch.uint8: ctypes.c_uint8}[dtype]
-        arr = np.ctypeslib.as_array((ctype * n).from_address(ptr))
-        return torch.from_numpy(arr)
+            t = torch.as_tensor(_DevView(ptr, (n,), typestr), device="cuda")
+        else:
+            ctype = {torch.float64: ctypes.c_double, torch.uint8: ctypes.c_uint8}[dtype]
+            t = torch.from_numpy(np.ctypeslib.as_array((ctype * n).from_address(ptr)))
+        if len(views) < 4096:
+            views[key] = t
+        return t
 
     def allreduce(op):
         def fn(ctx, buf, n):
