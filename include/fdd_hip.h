@@ -106,6 +106,11 @@ int fdd_csr_plan_set_unit_values(fdd_csr_plan *plan, int unit_values);
  * plan run on it from now on, same row sums in the same order.  A_ptr_host: host copy of the row pointers; A_ptr,
  * A_col, A_val: the device arrays (A_val double, or float on a plan of fdd_csr_plan_create_f32). */
 int fdd_csr_plan_attach_sell(fdd_csr_plan *plan, const int *A_ptr_host, const int *A_ptr, const int *A_col, const void *A_val, double max_padding, int *attached, void *stream);
+/* What the attach made: slices of 64 rows (0: none) and how many of them store their columns in the compact form -- entry k of
+ * a slice's 64 rows as one base (the smallest of the 64 columns) + a 16-bit offset per row, possible wherever the 64 columns
+ * of every slot lie within 65535 of each other (on the lattice-numbered AMG levels they lie within 63): 10 instead of 12
+ * bytes per entry, 6 instead of 8 in single precision; the same columns, values and order. */
+int fdd_csr_plan_sell_info(const fdd_csr_plan *plan, int *slices, int *compact_slices);
 /* weight may be NULL (multiply) or a device vector of num_rows (multiply_weight) */
 int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *A_ptr, const int *A_col, const double *A_val, const double *u, const double *weight, void *stream);
 

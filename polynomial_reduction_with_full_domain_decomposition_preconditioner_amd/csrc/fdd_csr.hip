@@ -911,29 +911,31 @@ __global__ __launch_bounds__(kBlock) void fold_partials_kernel(double *out, cons
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSellSlice = FDD_WAVE;
 
-template <typename T, typename Epi>
-__global__ __launch_bounds__(kBlock) void sell_kernel(T *__restrict__ y, const int *__restrict__ slice_off, const int *__restrict__ slice_order, const int *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x, Epi epi, int num_rows, int num_slices)
+// Column readers of a slice.  Compact form (round 4): entry k of the 64 rows of a slice is stored as one wave-uniform base
+// (the smallest column of the 64) + a 16-bit offset per lane -- on the lattice-numbered AMG levels the 64 rows of a slice
+// read columns row + const in every slot, so the offsets are < 64 -- 10 instead of 12 bytes per entry (6 instead of 8 in
+// single precision); a slice with a slot whose columns spread over more than 65535 keeps 32-bit columns.
+struct SellCols32
 {
-    const int turn = blockIdx.x * (kBlock / kSellSlice) + threadIdx.x / kSellSlice;
-    if (turn >= num_slices) return;
-    // slices are visited widest first when their widths differ much (a few slices of long rows -- the interface and
-    // superdomain rows of a composite's low-order operator -- would otherwise finish long after everything else)
-    const int slice = slice_order ? slice_order[turn] : turn;
-    const int lane = threadIdx.x & (kSellSlice - 1);
-    const int row = slice * kSellSlice + lane;
-    const int off = slice_off[slice];
-    const int width = (slice_off[slice + 1] - off) / kSellSlice;
-    const int rs = (row < num_rows) ? row : num_rows - 1;
-    const typename Epi::Opnd opnd = epi.operand(rs, y); // requested with the first entries
-    const int *c = col + off + lane;
-    const T *v = val + off + lane;
+    const int *c;
+    __device__ __forceinline__ int at(int k) const { return __builtin_nontemporal_load(c + k * kSellSlice); }
+};
+struct SellCols16
+{
+    const unsigned short *c;
+    const int *base; // wave-uniform address: scalar loads
+    __device__ __forceinline__ int at(int k) const { return base[k] + (int)__builtin_nontemporal_load(c + k * kSellSlice); }
+};
+
+template <typename T, typename Cols>
+__device__ __forceinline__ T sell_row_sum(const Cols cols, const T *__restrict__ v, const T *__restrict__ x, int width)
+{
     T acc = T(0);
     int k = 0;
     for (; k + 4 <= width; k += 4)
     {
         // four entries in flight per lane; the sum stays in column order
-        const int c0 = __builtin_nontemporal_load(c + (k + 0) * kSellSlice), c1 = __builtin_nontemporal_load(c + (k + 1) * kSellSlice);
-        const int c2 = __builtin_nontemporal_load(c + (k + 2) * kSellSlice), c3 = __builtin_nontemporal_load(c + (k + 3) * kSellSlice);
+        const int c0 = cols.at(k + 0), c1 = cols.at(k + 1), c2 = cols.at(k + 2), c3 = cols.at(k + 3);
         const T v0 = __builtin_nontemporal_load(v + (k + 0) * kSellSlice), v1 = __builtin_nontemporal_load(v + (k + 1) * kSellSlice);
         const T v2 = __builtin_nontemporal_load(v + (k + 2) * kSellSlice), v3 = __builtin_nontemporal_load(v + (k + 3) * kSellSlice);
         const T x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
@@ -942,13 +944,52 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(T *__restrict__ y, const i
         acc += v2 * x2;
         acc += v3 * x3;
     }
-    for (; k < width; k++) acc += __builtin_nontemporal_load(v + k * kSellSlice) * x[__builtin_nontemporal_load(c + k * kSellSlice)];
+    // the last one to three entries (the slice's width is wave-uniform) in flight together as well: a level-0 row of 7
+    // entries is two round trips, not four
+    const int rem = width - k;
+    if (rem > 0)
+    {
+        // no branches around the loads (a join would wait for everything in flight): entries past the end re-read the last one
+        const int k1 = min(k + 1, width - 1), k2 = min(k + 2, width - 1);
+        const int c0 = cols.at(k), c1 = cols.at(k1), c2 = cols.at(k2);
+        const T v0 = __builtin_nontemporal_load(v + k * kSellSlice), v1 = __builtin_nontemporal_load(v + k1 * kSellSlice), v2 = __builtin_nontemporal_load(v + k2 * kSellSlice);
+        const T x0 = x[c0], x1 = x[c1], x2 = x[c2];
+        acc += v0 * x0;
+        const T a1 = acc + v1 * x1;
+        acc = (rem > 1) ? a1 : acc;
+        const T a2 = acc + v2 * x2;
+        acc = (rem > 2) ? a2 : acc;
+    }
+    return acc;
+}
+
+template <typename T, typename Epi>
+__global__ __launch_bounds__(kBlock) void sell_kernel(T *__restrict__ y, const int *__restrict__ slice_off, const int *__restrict__ slice_order, const int *__restrict__ col, const T *__restrict__ val, const T *__restrict__ x, Epi epi, int num_rows, int num_slices,
+                                                      const unsigned short *__restrict__ col16, const int *__restrict__ slot_base, const int *__restrict__ wide_off)
+{
+    const int turn = blockIdx.x * (kBlock / kSellSlice) + threadIdx.x / kSellSlice;
+    if (turn >= num_slices) return;
+    // slices are visited widest first when their widths differ much (a few slices of long rows -- the interface and
+    // superdomain rows of a composite's low-order operator -- would otherwise finish long after everything else)
+    const int slice = __builtin_amdgcn_readfirstlane(slice_order ? slice_order[turn] : turn);
+    const int lane = threadIdx.x & (kSellSlice - 1);
+    const int row = slice * kSellSlice + lane;
+    const int off = slice_off[slice];
+    const int width = (slice_off[slice + 1] - off) / kSellSlice;
+    const int rs = (row < num_rows) ? row : num_rows - 1;
+    const typename Epi::Opnd opnd = epi.operand(rs, y); // requested with the first entries
+    const T *v = val + off + lane;
+    T acc;
+    const int woff = col16 ? wide_off[slice] : 0;
+    if (col16 != nullptr && woff < 0)
+        acc = sell_row_sum<T>(SellCols16{col16 + off + lane, slot_base + off / kSellSlice}, v, x, width);
+    else
+        acc = sell_row_sum<T>(SellCols32{col + (col16 ? woff : off) + lane}, v, x, width);
     if (row < num_rows) y[row] = epi.finish(acc, opnd, row);
 }
 
-// CSR -> sliced ELL on the device: one wavefront per slice
-template <typename T>
-__global__ __launch_bounds__(kBlock) void sell_fill_kernel(int *__restrict__ scol, T *__restrict__ sval, const int *__restrict__ slice_off, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const T *__restrict__ A_val, int num_rows, int num_slices)
+// which slices can take the compact column form: every slot's 64 columns within 65535 of the smallest
+__global__ __launch_bounds__(kBlock) void sell_probe_kernel(int *__restrict__ wide, const int *__restrict__ slice_off, const int *__restrict__ A_ptr, const int *__restrict__ A_col, int num_rows, int num_slices)
 {
     const int slice = blockIdx.x * (kBlock / kSellSlice) + threadIdx.x / kSellSlice;
     if (slice >= num_slices) return;
@@ -958,11 +999,55 @@ __global__ __launch_bounds__(kBlock) void sell_fill_kernel(int *__restrict__ sco
     const int width = (slice_off[slice + 1] - off) / kSellSlice;
     const int p0 = (row < num_rows) ? A_ptr[row] : 0;
     const int len = (row < num_rows) ? A_ptr[row + 1] - p0 : 0;
-    // padding repeats a column the row already reads (any valid column of the matrix for an empty row) with value 0
-    const int pad_col = (len > 0) ? A_col[p0] : 0;
+    const int pad_col = (len > 0) ? A_col[p0 + len - 1] : -1;
+    int too_wide = 0;
     for (int k = 0; k < width; k++)
     {
-        scol[off + k * kSellSlice + lane] = (k < len) ? A_col[p0 + k] : pad_col;
+        const int c = (k < len) ? A_col[p0 + k] : pad_col;
+        int lo = (c >= 0) ? c : 0x7fffffff, hi = c;
+        for (int d = kSellSlice / 2; d > 0; d >>= 1)
+        {
+            lo = min(lo, __shfl_xor(lo, d));
+            hi = max(hi, __shfl_xor(hi, d));
+        }
+        if (hi >= 0 && hi - lo > 65535) too_wide = 1;
+    }
+    if (lane == 0) wide[slice] = too_wide;
+}
+
+// CSR -> sliced ELL on the device: one wavefront per slice.  col16 != nullptr: the compact column form where wide_off[slice] < 0,
+// 32-bit columns at scol + wide_off[slice] otherwise (scol then holds the wide slices only)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sell_fill_kernel(int *__restrict__ scol, T *__restrict__ sval, const int *__restrict__ slice_off, const int *__restrict__ A_ptr, const int *__restrict__ A_col, const T *__restrict__ A_val, int num_rows, int num_slices,
+                                                           unsigned short *__restrict__ col16, int *__restrict__ slot_base, const int *__restrict__ wide_off)
+{
+    const int slice = blockIdx.x * (kBlock / kSellSlice) + threadIdx.x / kSellSlice;
+    if (slice >= num_slices) return;
+    const int lane = threadIdx.x & (kSellSlice - 1);
+    const int row = slice * kSellSlice + lane;
+    const int off = slice_off[slice];
+    const int width = (slice_off[slice + 1] - off) / kSellSlice;
+    const int p0 = (row < num_rows) ? A_ptr[row] : 0;
+    const int len = (row < num_rows) ? A_ptr[row + 1] - p0 : 0;
+    // padding repeats a column the row already reads -- its last: in the padded (late) slots the neighbouring rows read their
+    // last columns too, which keeps a slot's columns close together -- with value 0; an empty row takes the slot's smallest
+    // column of the other rows (column 0 where all are empty)
+    const int pad_col = (len > 0) ? A_col[p0 + len - 1] : -1;
+    const int woff = col16 ? wide_off[slice] : off;
+    for (int k = 0; k < width; k++)
+    {
+        int c = (k < len) ? A_col[p0 + k] : pad_col;
+        int lo = (c >= 0) ? c : 0x7fffffff;
+        for (int d = kSellSlice / 2; d > 0; d >>= 1) lo = min(lo, __shfl_xor(lo, d));
+        if (lo == 0x7fffffff) lo = 0;
+        if (c < 0) c = lo;
+        if (col16 != nullptr && woff < 0)
+        {
+            col16[off + k * kSellSlice + lane] = (unsigned short)(c - lo);
+            if (lane == 0) slot_base[off / kSellSlice + k] = lo;
+        }
+        else
+            scol[woff + k * kSellSlice + lane] = c;
         sval[off + k * kSellSlice + lane] = (k < len) ? A_val[p0 + k] : T(0);
     }
 }
@@ -992,6 +1077,11 @@ struct fdd_csr_plan
     void *sell_val_dev = nullptr;
     int *sell_order_dev = nullptr; // slices by decreasing width (nullptr: widths are even, natural order)
     long long sell_entries = 0;
+    // compact column form: 16-bit offsets from a per-(slice, slot) base; sell_col_dev then holds the wide slices' columns only
+    unsigned short *sell_col16_dev = nullptr;
+    int *sell_slot_base_dev = nullptr; // sell_entries / 64
+    int *sell_wide_off_dev = nullptr;  // per slice: -1 = compact, else its offset in sell_col_dev
+    int sell_compact_slices = 0;
 };
 
 // y[rows of blocks first..last) in [row_lo, row_hi)] = epi(A x) on a short-row plan: the persistent pipelined kernel.
@@ -1030,7 +1120,8 @@ static int sell_launch(const fdd_csr_plan *plan, T *y, const T *x, const Epi &ep
 {
     const int per_block = kBlock / kSellSlice;
     const dim3 grid((plan->sell_slices + per_block - 1) / per_block), block(kBlock);
-    hipLaunchKernelGGL((sell_kernel<T, Epi>), grid, block, 0, fdd_stream(stream), y, plan->sell_off_dev, plan->sell_order_dev, plan->sell_col_dev, (const T *)plan->sell_val_dev, x, epi, plan->num_rows, plan->sell_slices);
+    hipLaunchKernelGGL((sell_kernel<T, Epi>), grid, block, 0, fdd_stream(stream), y, plan->sell_off_dev, plan->sell_order_dev, plan->sell_col_dev, (const T *)plan->sell_val_dev, x, epi, plan->num_rows, plan->sell_slices,
+                       plan->sell_col16_dev, plan->sell_slot_base_dev, plan->sell_wide_off_dev);
     FDD_LAUNCH_CHECK();
     return 0;
 }
@@ -1247,6 +1338,9 @@ int fdd_csr_plan_destroy(fdd_csr_plan *plan)
     if (plan->sell_col_dev) (void)hipFree(plan->sell_col_dev);
     if (plan->sell_val_dev) (void)hipFree(plan->sell_val_dev);
     if (plan->sell_order_dev) (void)hipFree(plan->sell_order_dev);
+    if (plan->sell_col16_dev) (void)hipFree(plan->sell_col16_dev);
+    if (plan->sell_slot_base_dev) (void)hipFree(plan->sell_slot_base_dev);
+    if (plan->sell_wide_off_dev) (void)hipFree(plan->sell_wide_off_dev);
     delete plan;
     return 0;
 }
@@ -1295,34 +1389,93 @@ int fdd_csr_plan_attach_sell(fdd_csr_plan *plan, const int *A_ptr_host, const in
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return width[a] > width[b]; });
     }
     const size_t vb = (size_t)plan->value_bytes;
+    const int per_block = kBlock / kSellSlice;
+    const dim3 grid((slices + per_block - 1) / per_block), block(kBlock);
+    auto release = [&]() {
+        if (plan->sell_order_dev) (void)hipFree(plan->sell_order_dev);
+        if (plan->sell_off_dev) (void)hipFree(plan->sell_off_dev);
+        if (plan->sell_col_dev) (void)hipFree(plan->sell_col_dev);
+        if (plan->sell_val_dev) (void)hipFree(plan->sell_val_dev);
+        if (plan->sell_col16_dev) (void)hipFree(plan->sell_col16_dev);
+        if (plan->sell_slot_base_dev) (void)hipFree(plan->sell_slot_base_dev);
+        if (plan->sell_wide_off_dev) (void)hipFree(plan->sell_wide_off_dev);
+        plan->sell_order_dev = plan->sell_off_dev = plan->sell_col_dev = plan->sell_slot_base_dev = plan->sell_wide_off_dev = nullptr;
+        plan->sell_val_dev = nullptr;
+        plan->sell_col16_dev = nullptr;
+        plan->sell_compact_slices = 0;
+    };
     hipError_t err = hipMalloc((void **)&plan->sell_off_dev, off.size() * sizeof(int));
-    if (err == hipSuccess) err = hipMalloc((void **)&plan->sell_col_dev, (size_t)total * sizeof(int));
-    if (err == hipSuccess) err = hipMalloc(&plan->sell_val_dev, (size_t)total * vb);
     if (err == hipSuccess) err = upload_table(plan->sell_off_dev, off.data(), off.size() * sizeof(int));
+    // compact column form (16-bit offsets from a per-slot base) for the slices whose slots allow it
+    std::vector<int> wide_off;
+    long long wide_total = total;
+    int compact = 0;
+    if (err == hipSuccess && fdd_env_int("FDD_TUNE_CSR_SELL_COL16", 1))
+    {
+        std::vector<int> wide(slices, 1);
+        err = hipMalloc((void **)&plan->sell_wide_off_dev, (size_t)slices * sizeof(int));
+        if (err == hipSuccess)
+        {
+            hipLaunchKernelGGL(sell_probe_kernel, grid, block, 0, fdd_stream(stream), plan->sell_wide_off_dev, plan->sell_off_dev, A_ptr, A_col, n, slices);
+            err = hipGetLastError();
+        }
+        if (err == hipSuccess) err = hipMemcpyAsync(wide.data(), plan->sell_wide_off_dev, (size_t)slices * sizeof(int), hipMemcpyDeviceToHost, fdd_stream(stream));
+        if (err == hipSuccess) err = hipStreamSynchronize(fdd_stream(stream));
+        if (err == hipSuccess)
+        {
+            wide_off.assign(slices, -1);
+            wide_total = 0;
+            for (int s = 0; s < slices; s++)
+                if (wide[s])
+                {
+                    wide_off[s] = (int)wide_total;
+                    wide_total += off[s + 1] - off[s];
+                }
+                else
+                    compact++;
+            if (compact == 0)
+            {
+                (void)hipFree(plan->sell_wide_off_dev);
+                plan->sell_wide_off_dev = nullptr;
+                wide_total = total;
+            }
+            else
+                err = upload_table(plan->sell_wide_off_dev, wide_off.data(), (size_t)slices * sizeof(int));
+        }
+    }
+    if (err == hipSuccess) err = hipMalloc((void **)&plan->sell_col_dev, (size_t)std::max<long long>(wide_total, 1) * sizeof(int));
+    if (err == hipSuccess && compact > 0) err = hipMalloc((void **)&plan->sell_col16_dev, (size_t)total * sizeof(unsigned short));
+    if (err == hipSuccess && compact > 0) err = hipMalloc((void **)&plan->sell_slot_base_dev, (size_t)(total / kSellSlice) * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&plan->sell_val_dev, (size_t)total * vb);
     if (err == hipSuccess && !order.empty()) err = hipMalloc((void **)&plan->sell_order_dev, order.size() * sizeof(int));
     if (err == hipSuccess && !order.empty()) err = upload_table(plan->sell_order_dev, order.data(), order.size() * sizeof(int));
     if (err != hipSuccess)
     {
         fdd_set_error("fdd_csr_plan_attach_sell: %s", hipGetErrorString(err));
-        if (plan->sell_order_dev) (void)hipFree(plan->sell_order_dev);
-        plan->sell_order_dev = nullptr;
-        if (plan->sell_off_dev) (void)hipFree(plan->sell_off_dev);
-        if (plan->sell_col_dev) (void)hipFree(plan->sell_col_dev);
-        if (plan->sell_val_dev) (void)hipFree(plan->sell_val_dev);
-        plan->sell_off_dev = plan->sell_col_dev = nullptr;
-        plan->sell_val_dev = nullptr;
+        release();
         return (int)err;
     }
-    const int per_block = kBlock / kSellSlice;
-    const dim3 grid((slices + per_block - 1) / per_block), block(kBlock);
     if (vb == 8)
-        hipLaunchKernelGGL((sell_fill_kernel<double>), grid, block, 0, fdd_stream(stream), plan->sell_col_dev, (double *)plan->sell_val_dev, plan->sell_off_dev, A_ptr, A_col, (const double *)A_val, n, slices);
+        hipLaunchKernelGGL((sell_fill_kernel<double>), grid, block, 0, fdd_stream(stream), plan->sell_col_dev, (double *)plan->sell_val_dev, plan->sell_off_dev, A_ptr, A_col, (const double *)A_val, n, slices, plan->sell_col16_dev, plan->sell_slot_base_dev,
+                           plan->sell_wide_off_dev);
     else
-        hipLaunchKernelGGL((sell_fill_kernel<float>), grid, block, 0, fdd_stream(stream), plan->sell_col_dev, (float *)plan->sell_val_dev, plan->sell_off_dev, A_ptr, A_col, (const float *)A_val, n, slices);
+        hipLaunchKernelGGL((sell_fill_kernel<float>), grid, block, 0, fdd_stream(stream), plan->sell_col_dev, (float *)plan->sell_val_dev, plan->sell_off_dev, A_ptr, A_col, (const float *)A_val, n, slices, plan->sell_col16_dev, plan->sell_slot_base_dev,
+                           plan->sell_wide_off_dev);
     FDD_LAUNCH_CHECK();
+    plan->sell_compact_slices = compact;
     plan->sell_entries = total;
     plan->sell_slices = slices; // last: the SpMV entries switch over
     *attached = 1;
+    return 0;
+}
+
+// what fdd_csr_plan_attach_sell made: slices of 64 rows (0: no sliced-ELL copy) and how many of them carry the compact
+// column form (16-bit offsets from a per-slot base: 10 instead of 12 bytes per entry)
+int fdd_csr_plan_sell_info(const fdd_csr_plan *plan, int *slices, int *compact_slices)
+{
+    FDD_REQUIRE(plan != nullptr && slices != nullptr && compact_slices != nullptr);
+    *slices = plan->sell_slices;
+    *compact_slices = plan->sell_compact_slices;
     return 0;
 }
 

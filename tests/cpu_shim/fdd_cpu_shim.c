@@ -80,6 +80,7 @@ int fdd_csr_plan_destroy(fdd_csr_plan *plan) { free(plan); return 0; }
 int fdd_csr_plan_num_blocks(const fdd_csr_plan *plan, int *nb) { (void)plan; *nb = 0; return 0; }
 int fdd_csr_plan_kind(const fdd_csr_plan *plan, int *kind) { (void)plan; *kind = 0; return 0; }
 int fdd_csr_plan_pipelined(const fdd_csr_plan *plan, int *pipelined) { (void)plan; *pipelined = 0; return 0; }
+int fdd_csr_plan_sell_info(const fdd_csr_plan *plan, int *slices, int *compact_slices) { (void)plan; *slices = 0; *compact_slices = 0; return 0; }
 int fdd_csr_plan_set_unit_values(fdd_csr_plan *plan, int unit) { (void)plan; (void)unit; return 0; }
 int fdd_csr_plan_attach_sell(fdd_csr_plan *plan, const int *ph, const int *p, const int *c, const void *v, double mp, int *attached, void *s) { (void)plan; (void)ph; (void)p; (void)c; (void)v; (void)mp; (void)s; *attached = 0; return 0; }
 int fdd_csr_plan_multiply(const fdd_csr_plan *plan, double *Au, const int *p, const int *c, const double *v, const double *u, const double *w, void *s)

@@ -462,6 +462,93 @@ def test_sell_with_a_few_wide_slices(gpu):
     run_csr_case(gpu, ptr, col, val, ncols, expect_kind=1)
 
 
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("shape", ["lattice", "lattice15", "far_columns", "mixed"])
+def test_sell_compact_columns(gpu, shape, precision):
+    """The sliced-ELL copy's compact column form (a wave-uniform base per slot + a 16-bit offset per row) where a slice's
+    slots allow it, 32-bit columns in the other slices of the same matrix: the bits of the 32-bit form
+    (FDD_TUNE_CSR_SELL_COL16=0), the row-block kernel's values to rounding, in double and in single precision; row
+    lengths 7 / 15 / 1-9 exercise every tail (0-3 entries after the groups of four), the ragged last slice and empty rows."""
+    import os
+
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(230)
+    if shape in ("lattice", "lattice15"):
+        m = 47  # 103 823 rows: columns of a slice spread over 2*47*47 + 64 << 65536, but the matrix has more than 65536 columns
+        T = sp.diags([1.0, -2.0, 1.0], [-1, 0, 1], shape=(m, m))
+        I = sp.eye(m)
+        A = sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(I, sp.kron(I, T))
+        if shape == "lattice15":
+            A = A + 0.25 * sp.kron(sp.kron(T, T), I) + 0.125 * sp.kron(I, sp.kron(T, T))
+        A = A.tocsr()
+        A.sort_indices()
+        ptr, col = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+        rows = cols = A.shape[0]
+        expect = "all"
+    else:
+        rows, cols = 40000 + 37, 400000
+        lens = rng.integers(1, 10, rows)
+        lens[777] = 0
+        lens[64 * 100 : 64 * 101] = 0  # a slice of empty rows
+        ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        near = ((np.repeat(np.arange(rows, dtype=np.int64), lens) * cols) // rows + rng.integers(0, 30000, int(ptr[-1]))).clip(0, cols - 1)
+        far = rng.integers(0, cols, int(ptr[-1]))
+        if shape == "far_columns":
+            pick, expect = far, "few"
+        else:
+            pick, expect = np.where(np.repeat(np.arange(rows) % 2048 < 1024, lens), near, far), "some"
+        col = np.concatenate([np.sort(pick[ptr[r] : ptr[r + 1]]) for r in range(rows)]).astype(np.int32)
+    nnz = int(ptr[-1])
+    ft = np.float64 if precision == 64 else np.float32
+    tt = torch.float64 if precision == 64 else torch.float32
+    val = rng.uniform(-1, 1, nnz).astype(ft)
+    x, y0 = rng.uniform(-1, 1, cols).astype(ft), rng.uniform(-1, 1, rows).astype(ft)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    dp, dc, dv, dx = t(ptr), t(col), t(val), t(x)
+    create = "fdd_csr_plan_create" if precision == 64 else "fdd_csr_plan_create_f32"
+
+    def run(plan, alpha, beta):
+        y = t(y0) if (beta != 0.0 and precision == 64) else torch.full((rows,), float("nan"), dtype=tt, device=gpu)
+        if precision == 64:
+            k("fdd_csr_plan_matvec", plan, y, dp, dc, dv, dx, alpha, beta)
+        else:
+            k("fdd_csr_plan_matvec_to_f32", plan, y, t(y0) if beta != 0.0 else None, dp, dc, dv, dx, alpha, beta)
+        return host(y)
+
+    plans, results = {}, {}
+    try:
+        for form in ("blocks", "col32", "col16"):
+            plans[form] = vp()
+            lib.hip().call(create, ctypes.byref(plans[form]), vp(ptr.ctypes.data), rows, cols, nnz)
+            if form != "blocks":
+                os.environ["FDD_TUNE_CSR_SELL_COL16"] = "0" if form == "col32" else "1"
+                attached = ctypes.c_int(0)
+                k("fdd_csr_plan_attach_sell", plans[form], vp(ptr.ctypes.data), dp, dc, dv, ctypes.c_double(2.5), ctypes.byref(attached))
+                assert attached.value == 1, form
+                slices, compact = ctypes.c_int(-1), ctypes.c_int(-1)
+                lib.hip().call("fdd_csr_plan_sell_info", plans[form], ctypes.byref(slices), ctypes.byref(compact))
+                assert slices.value == (rows + 63) // 64
+                if form == "col32":
+                    assert compact.value == 0
+                elif expect == "all":
+                    assert compact.value == slices.value
+                elif expect == "some":
+                    assert slices.value // 3 < compact.value < slices.value
+                else:
+                    assert compact.value < slices.value // 10
+            results[form] = [run(plans[form], a, b) for a, b in ((1.0, 0.0), (-1.0, 1.0), (0.5, -2.0))]
+        for got, want, blocks in zip(results["col16"], results["col32"], results["blocks"]):
+            assert np.isfinite(got).all() and np.array_equal(got, want), (shape, precision)
+            # the row-block kernel adds a wide row's products with several lanes (the entry stands in for cusparseSpMV,
+            # whose order is undefined): same values to rounding
+            assert np.allclose(want, blocks, rtol=1e-12 if precision == 64 else 1e-4, atol=1e-13 if precision == 64 else 1e-5), (shape, precision)
+    finally:
+        os.environ.pop("FDD_TUNE_CSR_SELL_COL16", None)
+        for plan in plans.values():
+            lib.hip().call("fdd_csr_plan_destroy", plan)
+
+
 def test_csr_empty_matrix(gpu):
     ptr = np.zeros(11, np.int32)
     run_csr_case(gpu, ptr, np.zeros(0, np.int32), np.zeros(0), 7, expect_kind=0)
