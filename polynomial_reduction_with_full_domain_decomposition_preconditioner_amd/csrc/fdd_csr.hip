@@ -927,39 +927,45 @@ struct SellCols16
     __device__ __forceinline__ int at(int k) const { return base[k] + (int)__builtin_nontemporal_load(c + k * kSellSlice); }
 };
 
+// B entries of the lane's row in flight together: B column and B value loads, then the B gathers, then the sum in column
+// order.  FULL = false: only the first `count` (wave-uniform, >= 1) exist; the others re-read the last one (no branch around a
+// load: a join would wait for everything in flight) and are left out of the sum by a select.
+template <int B, bool FULL, typename T, typename Cols>
+__device__ __forceinline__ void sell_batch(T &acc, const Cols cols, const T *__restrict__ v, const T *__restrict__ x, int k, int count)
+{
+    int c[B];
+    T a[B], xv[B];
+#pragma unroll
+    for (int i = 0; i < B; i++)
+    {
+        const int ki = FULL ? k + i : min(k + i, k + count - 1);
+        c[i] = cols.at(ki);
+        a[i] = __builtin_nontemporal_load(v + ki * kSellSlice);
+    }
+#pragma unroll
+    for (int i = 0; i < B; i++) xv[i] = x[c[i]];
+#pragma unroll
+    for (int i = 0; i < B; i++)
+    {
+        const T t = acc + a[i] * xv[i];
+        acc = (FULL || i < count) ? t : acc;
+    }
+}
+
+// A wave's time on a slice is a chain of dependent round trips (slice bounds -> columns -> gathers -> store) and a CU holds
+// 32 waves: what counts is how few trips a row takes, not its bytes -- groups of eight entries (a level-0 row of 7 entries is
+// one trip through columns and gathers; four per group, then one by one: three)
 template <typename T, typename Cols>
 __device__ __forceinline__ T sell_row_sum(const Cols cols, const T *__restrict__ v, const T *__restrict__ x, int width)
 {
     T acc = T(0);
     int k = 0;
-    for (; k + 4 <= width; k += 4)
-    {
-        // four entries in flight per lane; the sum stays in column order
-        const int c0 = cols.at(k + 0), c1 = cols.at(k + 1), c2 = cols.at(k + 2), c3 = cols.at(k + 3);
-        const T v0 = __builtin_nontemporal_load(v + (k + 0) * kSellSlice), v1 = __builtin_nontemporal_load(v + (k + 1) * kSellSlice);
-        const T v2 = __builtin_nontemporal_load(v + (k + 2) * kSellSlice), v3 = __builtin_nontemporal_load(v + (k + 3) * kSellSlice);
-        const T x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-        acc += v0 * x0;
-        acc += v1 * x1;
-        acc += v2 * x2;
-        acc += v3 * x3;
-    }
-    // the last one to three entries (the slice's width is wave-uniform) in flight together as well: a level-0 row of 7
-    // entries is two round trips, not four
+    for (; k + 8 <= width; k += 8) sell_batch<8, true>(acc, cols, v, x, k, 8);
     const int rem = width - k;
-    if (rem > 0)
-    {
-        // no branches around the loads (a join would wait for everything in flight): entries past the end re-read the last one
-        const int k1 = min(k + 1, width - 1), k2 = min(k + 2, width - 1);
-        const int c0 = cols.at(k), c1 = cols.at(k1), c2 = cols.at(k2);
-        const T v0 = __builtin_nontemporal_load(v + k * kSellSlice), v1 = __builtin_nontemporal_load(v + k1 * kSellSlice), v2 = __builtin_nontemporal_load(v + k2 * kSellSlice);
-        const T x0 = x[c0], x1 = x[c1], x2 = x[c2];
-        acc += v0 * x0;
-        const T a1 = acc + v1 * x1;
-        acc = (rem > 1) ? a1 : acc;
-        const T a2 = acc + v2 * x2;
-        acc = (rem > 2) ? a2 : acc;
-    }
+    if (rem > 4)
+        sell_batch<8, false>(acc, cols, v, x, k, rem);
+    else if (rem > 0)
+        sell_batch<4, false>(acc, cols, v, x, k, rem);
     return acc;
 }
 

@@ -3,6 +3,7 @@
 
   rocprof_summary.py stats <dir> <out.md> "<title>"     # --kernel-trace --stats run
   rocprof_summary.py pmc <fetch_dir> <write_dir> <out.json> [name-substring ...]
+  rocprof_summary.py bygrid <dir> <out.md> "<title>"    # --kernel-trace run: launches grouped by (kernel, grid size)
 
 PMC units follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B, so it is
@@ -37,6 +38,23 @@ def stats(d, out, title):
         fh.write("# %s\n\n| kernel | calls | total ms | avg us | %% |\n|---|---|---|---|---|\n" % title)
         for r in rows:
             fh.write("| `%s` | %s | %.2f | %.1f | %s |\n" % (short(r["Name"]), r["Calls"], int(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+
+
+def bygrid(d, out, title):
+    """One template instance serves matrices of very different size (the AMG levels): group its launches by grid size."""
+    acc = {}
+    for r in csv.DictReader(open(find(d, "_kernel_trace.csv"))):
+        key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1))
+        a = acc.setdefault(key, [0, 0.0])
+        a[0] += 1
+        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    total = sum(a[1] for a in acc.values())
+    with open(out, "w") as fh:
+        fh.write("# %s\n\n| kernel | workgroups | calls | total ms | avg us | %% |\n|---|---|---|---|---|---|\n" % title)
+        for (name, grid), (n, us) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            if us < 0.002 * total:
+                continue
+            fh.write("| `%s` | %d | %d | %.2f | %.1f | %.2f |\n" % (name, grid, n, us / 1e3, us / n, 100.0 * us / total))
 
 
 def per_kernel(d, counter):
@@ -74,5 +92,7 @@ def pmc(fetch_dir, write_dir, out, filters):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "bygrid":
+        bygrid(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5:])
