@@ -232,6 +232,24 @@ int fdd_amg_smooth_residual_matvec(const fdd_csr_plan *plan, double *work, doubl
 int fdd_amg_smooth_polynomial_matvec(const fdd_csr_plan *plan, double *work_out, const int *A_ptr, const int *A_col, const double *A_val, const double *work_in, const double *Sr, const double *D_val, double coef, void *stream);
 int fdd_amg_smooth_update_matvec(const fdd_csr_plan *plan, double *u, const int *A_ptr, const int *A_col, const double *A_val, const double *work_in, const double *Sr, const double *D_val, double coef, void *stream);
 int fdd_amg_smooth_start(double *work, double *Sr, const double *f, const double *D_val, double coef, int size, void *stream);
+
+/* ---- matrix-free grid transfer of a geometric AMG level (csrc/fdd_transfer.hip) ------------------------------------
+ * Replaces the two SpMVs with the interpolator of a level whose coarse grid is a coarsened GLL lattice (u += P e and
+ * f_c = P^T v: the role of P_fem / R_fem, subdomain.tpp:3526-3545, 4064-4068, 4097-4101) where that interpolator is
+ * multi-linear in the elements' reference coordinates: the same n x m table of 1-D weights in every element and direction
+ * (host/low_order.hpp: geometric_level).  n lattice nodes per direction and element, m kept ones; fine node i sits between
+ * kept nodes lo[i] <= hi[i] with weights wl[i] and 1 - wl[i] (lo == hi: a kept node).  lo, hi, wl: HOST arrays of n.
+ *   owner_dof[num_elements * n^3]   the fine dof of a lattice point where the point is the first of its dof, -1 elsewhere
+ *   coarse_dof[num_elements * m^3]  the coarse dof of an element's kept node (x fastest), -1 on a Dirichlet node
+ * prolong: u[dof] += interpolated coarse value, every fine dof once.  restrict: partial[e * m^3 + t] = the element's own
+ * weighted sum for its kept node t; the caller adds the partial sums of a coarse dof (a boolean gather over coarse_dof's
+ * transpose: fdd_csr_plan_multiply).  The CSR interpolator's operator with its sums in another order: equal to rounding.
+ * 3-D; n = 8 and n = 16 are built (fdd_lattice_supported), others are refused. */
+int fdd_lattice_supported(int n, int m, int *supported);
+int fdd_lattice_prolong(double *u, const double *coarse, const int *owner_dof, const int *coarse_dof, int n, int m, const int *lo, const int *hi, const double *wl, long long num_elements, void *stream);
+int fdd_lattice_prolong_f32(float *u, const float *coarse, const int *owner_dof, const int *coarse_dof, int n, int m, const int *lo, const int *hi, const double *wl, long long num_elements, void *stream);
+int fdd_lattice_restrict(double *partial, const double *fine, const int *owner_dof, int n, int m, const int *lo, const int *hi, const double *wl, long long num_elements, void *stream);
+int fdd_lattice_restrict_f32(float *partial, const float *fine, const int *owner_dof, int n, int m, const int *lo, const int *hi, const double *wl, long long num_elements, void *stream);
 /* Float = float (AMG/config.hpp:4, run.py:157): the V-cycle on f32 values and vectors.  Only the fused sequence is
  * provided (SpMV + fused smoother + set/start); casts at the V-cycle's ends: fdd_sub_copy_f32_f64 / _f64_f32.
  * Plans for these entries come from fdd_csr_plan_create_f32 (row blocks whatever the row lengths); the fp64

@@ -205,6 +205,10 @@ int fddh_problem_amg_apply(fddh_problem *p, const double *r, double *z);
  * subdomain.tpp:3383-3549), and attach it.  coarsest_size / strength <= 0 take the defaults (400 rows, 0.08). */
 int fddh_problem_amg_build(fddh_problem *p, int coarsest_size, double strength, int smooth_prolongator, int verbose, int *num_levels);
 int fddh_problem_amg_level_info(const fddh_problem *p, int level, int *n, int *nnz_A, int *n_coarse, int *nnz_P);
+/* 1 where the interpolator of `level` (to level + 1) is applied matrix-free: a geometric level of fddh_problem_amg_build's own
+ * hierarchy on a conforming 3-D region with 8 or 16 lattice nodes per direction (fdd_lattice_prolong / _restrict,
+ * include/fdd_hip.h), and the flag "amg_matrix_free_transfer" (default 1) on; 0: two SpMVs with the CSR interpolator */
+int fddh_problem_amg_level_transfer(const fddh_problem *p, int level, int *matrix_free);
 int fddh_problem_amg_level_arrays(const fddh_problem *p, int level, int *A_ptr, int *A_col, double *A_val, double *D_val, double *coefs, int *P_ptr, int *P_col, double *P_val);
 
 /* Domain operations on host vectors of num_local_points */

@@ -26,13 +26,33 @@
 
 #include "config.hpp"
 #include "csr_matrix.hpp"
+#include "low_order.hpp"
 
 namespace amg
 {
 
+// matrix-free form of a geometric level's interpolator (fdd_lattice_prolong / _restrict, csrc/fdd_transfer.hip): the maps
+// of low_order::Transfer on the device, the element-local partial sums of the restriction and the boolean gather that adds
+// the partial sums of a coarse dof
+struct LatticeTransfer
+{
+    bool active = false;
+    int n = 0, m = 0;
+    std::vector<int> lo, hi;
+    std::vector<double> wl;
+    long long num_elements = 0;
+    fdd::memory owner_dof, coarse_dof, partial, partial32;
+    CSR_Matrix<double> gather; // coarse dofs x kept nodes of all elements
+    fdd::memory gather_val32;
+    fdd_csr_plan *gather_plan32 = nullptr;
+    double prolong_bytes(int n_fine, int n_coarse, int vb) const { return 4.0 * (double)num_elements * n * n * n + 2.0 * vb * n_fine + (4.0 + vb) * (double)num_elements * m * m * m + 0.0 * n_coarse; }
+    double restrict_bytes(int n_fine, int vb) const { return 4.0 * (double)num_elements * n * n * n + 1.0 * vb * n_fine + 1.0 * vb * (double)num_elements * m * m * m; }
+};
+
 struct Level
 {
     int n = 0;
+    LatticeTransfer T;
     CSR_Matrix<double> A;
     CSR_Matrix<double> P; // n x n_coarse
     CSR_Matrix<double> R; // P^T
@@ -122,13 +142,29 @@ class Hierarchy
                 if (l > 0 and not smoother_writes_u) FDD_CALL(fdd_amg_vector_set_to_value(L.u.as<double>(), 0.0, L.n, s));
                 smooth(l, l > 0 or iter == 0);
                 L.A.matvec_to(L.v, L.f, L.u, -1.0, 1.0); // v = f - A u
-                L.R.matvec(levels[l + 1].f, L.v, 1.0, 0.0);
+                if (L.T.active and matrix_free_transfer)
+                {
+                    {
+                        fdd::ProfileScope prof("lattice_restrict_kernel", L.T.restrict_bytes(L.n, 8));
+                        FDD_CALL(fdd_lattice_restrict(L.T.partial.as<double>(), L.v.as<double>(), L.T.owner_dof.as<int>(), L.T.n, L.T.m, L.T.lo.data(), L.T.hi.data(), L.T.wl.data(), L.T.num_elements, s));
+                    }
+                    L.T.gather.matvec(levels[l + 1].f, L.T.partial, 1.0, 0.0);
+                }
+                else
+                    L.R.matvec(levels[l + 1].f, L.v, 1.0, 0.0);
             }
             Level &C = levels[nl - 1];
             coarse_inverse.matvec(C.u, C.f, 1.0, 0.0); // hypre_GaussElimSolve's role (:4084)
             for (int l = nl - 1; l > 0; l--)
             {
-                levels[l - 1].P.matvec(levels[l - 1].u, levels[l].u, 1.0, 1.0); // u_{l-1} += P u_l
+                Level &F = levels[l - 1];
+                if (F.T.active and matrix_free_transfer)
+                {
+                    fdd::ProfileScope prof("lattice_prolong_kernel", F.T.prolong_bytes(F.n, levels[l].n, 8));
+                    FDD_CALL(fdd_lattice_prolong(F.u.as<double>(), levels[l].u.as<double>(), F.T.owner_dof.as<int>(), F.T.coarse_dof.as<int>(), F.T.n, F.T.m, F.T.lo.data(), F.T.hi.data(), F.T.wl.data(), F.T.num_elements, s));
+                }
+                else
+                    F.P.matvec(F.u, levels[l].u, 1.0, 1.0); // u_{l-1} += P u_l
                 smooth(l - 1);
             }
         }
@@ -174,6 +210,12 @@ class Hierarchy
                 L.R_val32 = to_f32(L.R.val_hst);
                 blocked_plan(&L.P_plan32, L.P, L.P_val32);
                 blocked_plan(&L.R_plan32, L.R, L.R_val32);
+            }
+            if (L.T.active)
+            {
+                L.T.partial32 = fdd::dev().malloc<float>((size_t)L.T.gather.num_cols);
+                L.T.gather_val32 = to_f32(L.T.gather.val_hst);
+                blocked_plan(&L.T.gather_plan32, L.T.gather, L.T.gather_val32);
             }
             L.D_val32 = to_f32(L.D_hst);
             for (fdd::memory *m : {&L.f32, &L.u32, &L.r32, &L.v32, &L.work32}) *m = fdd::dev().malloc<float>(L.n);
@@ -226,13 +268,29 @@ class Hierarchy
                 Level &L = levels[l];
                 smooth32(l, l > 0 or iter == 0);
                 matvec32(L.A_plan32, L.A, L.A_val32, L.v32, &L.f32, L.u32, -1.0f, 1.0f);
-                matvec32(L.R_plan32, L.R, L.R_val32, levels[l + 1].f32, nullptr, L.v32, 1.0f, 0.0f);
+                if (L.T.active and matrix_free_transfer)
+                {
+                    {
+                        fdd::ProfileScope prof("lattice_restrict_kernel<f32>", L.T.restrict_bytes(L.n, 4));
+                        FDD_CALL(fdd_lattice_restrict_f32(L.T.partial32.as<float>(), L.v32.as<float>(), L.T.owner_dof.as<int>(), L.T.n, L.T.m, L.T.lo.data(), L.T.hi.data(), L.T.wl.data(), L.T.num_elements, s));
+                    }
+                    matvec32(L.T.gather_plan32, L.T.gather, L.T.gather_val32, levels[l + 1].f32, nullptr, L.T.partial32, 1.0f, 0.0f);
+                }
+                else
+                    matvec32(L.R_plan32, L.R, L.R_val32, levels[l + 1].f32, nullptr, L.v32, 1.0f, 0.0f);
             }
             Level &C = levels[nl - 1];
             matvec32(coarse_plan32, coarse_inverse, coarse_inverse_val32, C.u32, nullptr, C.f32, 1.0f, 0.0f);
             for (int l = nl - 1; l > 0; l--)
             {
-                matvec32(levels[l - 1].P_plan32, levels[l - 1].P, levels[l - 1].P_val32, levels[l - 1].u32, nullptr, levels[l].u32, 1.0f, 1.0f);
+                Level &F = levels[l - 1];
+                if (F.T.active and matrix_free_transfer)
+                {
+                    fdd::ProfileScope prof("lattice_prolong_kernel<f32>", F.T.prolong_bytes(F.n, levels[l].n, 4));
+                    FDD_CALL(fdd_lattice_prolong_f32(F.u32.as<float>(), levels[l].u32.as<float>(), F.T.owner_dof.as<int>(), F.T.coarse_dof.as<int>(), F.T.n, F.T.m, F.T.lo.data(), F.T.hi.data(), F.T.wl.data(), F.T.num_elements, s));
+                }
+                else
+                    matvec32(F.P_plan32, F.P, F.P_val32, F.u32, &F.u32, levels[l].u32, 1.0f, 1.0f);
                 smooth32(l - 1, false);
             }
         }
@@ -259,6 +317,55 @@ class Hierarchy
         return levels[0].f32;
     }
     fdd::memory &solution32() { return levels[0].u32; }
+
+    // the interpolator of a geometric level applied matrix-free where the hierarchy's builder handed its maps over
+    // (set_lattice_transfer); false: the CSR interpolator and its transpose, as on every other level.  The same operator
+    // with its sums in another order: equal to rounding
+    bool matrix_free_transfer = true;
+    void set_matrix_free_transfer(bool on)
+    {
+        if (on != matrix_free_transfer) destroy_graphs();
+        matrix_free_transfer = on;
+    }
+
+    // level l's interpolator IS the lattice interpolation these maps describe (low_order::geometric_level)
+    void set_lattice_transfer(size_t l, fdd::low_order::Transfer &&t)
+    {
+        static const int env = getenv("FDD_TUNE_AMG_MATRIX_FREE_TRANSFER") ? atoi(getenv("FDD_TUNE_AMG_MATRIX_FREE_TRANSFER")) : 1; // development override
+        int supported = 0;
+        if (not t.active() or l >= levels.size() or not env) return;
+        FDD_CALL(fdd_lattice_supported(t.n, t.m, &supported));
+        if (not supported) return;
+        Level &L = levels[l];
+        LatticeTransfer &T = L.T;
+        const long long mc = (long long)t.m * t.m * t.m, kept = t.num_elements * mc;
+        const int nc = L.P.num_cols;
+        if (kept >= (1LL << 31) or (long long)t.coarse_dof.size() != kept) return;
+        T.n = t.n;
+        T.m = t.m;
+        T.lo = std::move(t.lo);
+        T.hi = std::move(t.hi);
+        T.wl = std::move(t.wl);
+        T.num_elements = t.num_elements;
+        T.owner_dof = fdd::dev().malloc<int>(t.owner_dof.size());
+        T.owner_dof.copyFrom(t.owner_dof.data(), t.owner_dof.size() * sizeof(int));
+        T.coarse_dof = fdd::dev().malloc<int>(t.coarse_dof.size());
+        T.coarse_dof.copyFrom(t.coarse_dof.data(), t.coarse_dof.size() * sizeof(int));
+        T.partial = fdd::dev().malloc<double>((size_t)kept);
+        // coarse dof -> the kept nodes it sits on, in ascending (element, node) order: the boolean gather of the restriction
+        std::vector<int> ptr((size_t)nc + 1, 0), col, fill;
+        for (long long q = 0; q < kept; q++)
+            if (t.coarse_dof[(size_t)q] >= 0) ptr[(size_t)t.coarse_dof[(size_t)q] + 1]++;
+        for (int c = 0; c < nc; c++) ptr[(size_t)c + 1] += ptr[(size_t)c];
+        col.resize((size_t)ptr[(size_t)nc]);
+        fill.assign(ptr.begin(), ptr.end() - 1);
+        for (long long q = 0; q < kept; q++)
+            if (t.coarse_dof[(size_t)q] >= 0) col[(size_t)fill[(size_t)t.coarse_dof[(size_t)q]]++] = (int)q;
+        std::vector<double> ones(col.size(), 1.0);
+        T.gather.assemble_from_csr(nc, (int)kept, ptr.data(), col.data(), ones.data());
+        T.active = true;
+        destroy_graphs();
+    }
 
     // subdomain.hpp:236 (swept by run.py:154): a captured graph belongs to one cycle count
     void set_num_vcycles(int v)

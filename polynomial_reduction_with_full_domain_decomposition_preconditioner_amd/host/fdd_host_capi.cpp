@@ -1016,6 +1016,12 @@ int fddh_problem_set_flag(fddh_problem *p, const char *name, int value)
         {
             if (p->subdomain) p->subdomain->amg_hierarchy.fused_smoother = value != 0;
         }
+        else if (s == "amg_matrix_free_transfer")
+        {
+            // the interpolator of a geometric level applied from the lattice's weight table (fdd_lattice_prolong / _restrict)
+            // instead of as two SpMVs; 0: the CSR interpolator on every level (the same operator, sums in the CSR order)
+            if (p->subdomain) p->subdomain->amg_hierarchy.set_matrix_free_transfer(value != 0);
+        }
         else if (s == "preconditioner_precision")
         {
             // the reference's PTYPE = Float (config.hpp:19-20): 64 or 32 for the whole inner solve (Krylov vectors, element
@@ -1149,6 +1155,23 @@ int fddh_problem_amg_level_info(const fddh_problem *p, int level, int *n, int *n
         if (nnz_A) *nnz_A = lv[level].A.num_nnz;
         if (n_coarse) *n_coarse = lv[level].P.num_cols;
         if (nnz_P) *nnz_P = lv[level].P.num_nnz;
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return fail("%s", e.what());
+    }
+}
+
+int fddh_problem_amg_level_transfer(const fddh_problem *p, int level, int *matrix_free)
+{
+    try
+    {
+        if (int rc = rank_check(p)) return rc;
+        if (!p || !p->subdomain || !matrix_free) return fail("no Subdomain");
+        const auto &H = p->subdomain->amg_hierarchy;
+        if (level < 0 || level >= (int)H.levels.size()) return fail("the hierarchy has %d levels", (int)H.levels.size());
+        *matrix_free = (H.levels[level].T.active && H.matrix_free_transfer) ? 1 : 0;
         return 0;
     }
     catch (const std::exception &e)

@@ -486,10 +486,25 @@ struct Options
                                        // N = 7): measured, not the default
 };
 
+// What a matrix-free application of a geometric level's interpolator needs (fdd_lattice_prolong / _restrict): filled by
+// geometric_level where every lattice point is a conforming dof's or a Dirichlet point (no hanging rows, no dofs outside
+// the lattice: a rank's own conforming region), 3-D
+struct Transfer
+{
+    int n = 0, m = 0;        // lattice nodes per direction and element: fine, kept
+    std::vector<int> lo, hi; // fine node i between kept nodes lo[i] <= hi[i]
+    std::vector<double> wl;  // weight of lo[i] (hi[i]: 1 - wl[i])
+    long long num_elements = 0;
+    std::vector<int> owner_dof;  // per fine lattice point: its dof where the point is the dof's first, -1 elsewhere
+    std::vector<int> coarse_dof; // per kept node of every element: its coarse dof, -1 on a Dirichlet node
+    bool active() const { return n > 0; }
+};
+
 struct Level
 {
     HostCSR A, P; // P empty on the coarsest level
     std::vector<double> D, coefs;
+    Transfer transfer; // active: P is this lattice interpolation
 };
 
 // entries below drop * (largest magnitude of the row) removed, the others scaled so that the row keeps its sum
@@ -675,7 +690,7 @@ inline std::vector<int> coarse_nodes(int n, const std::vector<double> &ref)
 // One geometric level: interpolator P (dofs x coarse dofs) and the coarse lattice.  Coarse dofs = the dofs sitting on
 // kept lattice nodes, plus every dof that is not a conforming lattice dof at all (lower-degree ring elements, superdomain
 // dofs of a composite: carried through unchanged), numbered in the order of the fine dofs.
-inline HostCSR geometric_level(const Lattice &fine, int num_dofs, Lattice &coarse)
+inline HostCSR geometric_level(const Lattice &fine, int num_dofs, Lattice &coarse, Transfer *transfer = nullptr)
 {
     const int dim = fine.dim, n = fine.n;
     const std::vector<int> keep = coarse_nodes(n, fine.ref);
@@ -871,6 +886,40 @@ inline HostCSR geometric_level(const Lattice &fine, int num_dofs, Lattice &coars
                 }
             }
     });
+    // the maps of the matrix-free form, where this interpolator is nothing but the lattice interpolation
+    if (transfer != nullptr)
+    {
+        *transfer = Transfer();
+        bool plain = (dim == 3) and total < (1LL << 31);
+        for (int d = 0; plain and d < num_dofs; d++) plain = first[d] >= 0;
+        for (long long q = 0; plain and q < total; q++)
+        {
+            const int len = fine.rows.ptr[q + 1] - fine.rows.ptr[q];
+            plain = len == 0 or (len == 1 and fine.rows.val[fine.rows.ptr[q]] == 1.0);
+        }
+        for (long long q = 0; plain and q < R.rows; q++)
+        {
+            const int len = R.ptr[q + 1] - R.ptr[q];
+            plain = len == 0 or (len == 1 and R.val[R.ptr[q]] == 1.0);
+        }
+        if (plain)
+        {
+            Transfer &T = *transfer;
+            T.n = n;
+            T.m = m;
+            T.lo = lo;
+            T.hi = hi;
+            T.wl = wl;
+            T.num_elements = fine.num_elements;
+            T.owner_dof.assign((size_t)total, -1);
+            for (int d = 0; d < num_dofs; d++) T.owner_dof[(size_t)first[d]] = d;
+            T.coarse_dof.assign((size_t)R.rows, -1);
+            parallel_ranges(R.rows, range_parts(R.rows), [&](long long q0, long long q1, int) {
+                for (long long q = q0; q < q1; q++)
+                    if (R.ptr[q + 1] > R.ptr[q]) T.coarse_dof[(size_t)q] = R.col[R.ptr[q]];
+            });
+        }
+    }
     return P;
 }
 
@@ -920,7 +969,7 @@ inline std::vector<Level> build(HostCSR A0, const Options &o, bool verbose = fal
         {
             geometric_done++;
             Lattice next;
-            P = geometric_level(lattice, n, next);
+            P = geometric_level(lattice, n, next, &L.transfer);
             lattice = std::move(next);
             if (verbose) printf("low_order: level %d coarsened on the lattice: %d -> %d rows, %d nodes per direction and element left\n", l, n, P.cols, lattice.n);
         }

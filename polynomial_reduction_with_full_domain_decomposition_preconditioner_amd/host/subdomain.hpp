@@ -1373,6 +1373,7 @@ class Subdomain
             if (coarsest) L.P = fdd::low_order::HostCSR();
             const int n = L.A.rows, nc = L.P.cols;
             amg_hierarchy.add_level_adopt(n, std::move(L.A.ptr), std::move(L.A.col), std::move(L.A.val), L.D.data(), L.coefs.data(), nc, std::move(L.P.ptr), std::move(L.P.col), std::move(L.P.val));
+            amg_hierarchy.set_lattice_transfer(l, std::move(L.transfer)); // a geometric level: its interpolator is applied matrix-free
             lv[l] = fdd::low_order::Level(); // free the host copy as we go
         }
         if (verbose) printf("low_order: FEM matrix %.2f s, hierarchy %.2f s, levels to the device %.2f s (%d host threads)\n", t1 - t0, t2 - t1, clock() - t2, fdd::low_order::host_threads());

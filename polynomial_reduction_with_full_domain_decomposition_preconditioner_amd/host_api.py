@@ -528,6 +528,12 @@ class Problem:
         _H().call("fddh_problem_amg_build", self.h, int(coarsest_size), float(strength), int(smooth_prolongator), int(verbose), ctypes.byref(nl))
         return nl.value
 
+    def amg_level_transfer(self, level):
+        """True where the interpolator of `level` is applied matrix-free (fdd_lattice_prolong / _restrict)."""
+        flag = ctypes.c_int(0)
+        _H().call("fddh_problem_amg_level_transfer", self.h, int(level), ctypes.byref(flag))
+        return bool(flag.value)
+
     def amg_levels(self, cheby_order=2):
         """The attached hierarchy as scipy matrices (finest first), as amg_attach takes it."""
         import scipy.sparse as sp

@@ -112,6 +112,27 @@ def check_amg(p, N, red, outer_solve=True, builder="scipy", cheby_order=2, num_v
         oz = sd.low_order_preconditioner(r)
         assert np.abs(oz).max() > 0
         assert np.abs(z - oz).max() <= 1e-11 * np.abs(oz).max()
+        if builder != "scipy":
+            # a geometric level of 8 (or 16) lattice nodes per direction on a conforming 3-D region applies its interpolator
+            # matrix-free (fdd_lattice_prolong / _restrict); the CSR interpolator gives the same cycle to rounding
+            matrix_free = p.amg_level_transfer(0)
+            assert matrix_free == (N in (7, 15) and meshes[0].dim == 3), (N, matrix_free)
+            if matrix_free:
+                p.set_flag("amg_matrix_free_transfer", 0)
+                assert not p.amg_level_transfer(0)
+                z_csr = p.amg_apply(r)
+                p.set_flag("amg_matrix_free_transfer", 1)
+                assert np.abs(z - z_csr).max() <= 1e-13 * np.abs(z_csr).max()
+                assert np.array_equal(p.amg_apply(r), z)
+                for bits in (32, 64):
+                    p.set_flag("amg_precision", bits)
+                    if bits == 32:
+                        z32 = p.amg_apply(r)
+                        p.set_flag("amg_matrix_free_transfer", 0)
+                        z32_csr = p.amg_apply(r)
+                        p.set_flag("amg_matrix_free_transfer", 1)
+                        assert np.abs(z32 - z32_csr).max() <= 2e-5 * np.abs(z32_csr).max()
+                        assert np.abs(z32 - z).max() <= 1e-4 * np.abs(z).max() and not np.array_equal(z32, z)
         # points without a dof get nothing; the operator is positive on assembled data
         assert np.all(z[dof < 0] == 0.0)
         assert float(np.dot(sd.dssum(r), z)) > 0.0

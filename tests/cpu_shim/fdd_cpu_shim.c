@@ -653,6 +653,62 @@ int fdd_csr_plan_matvec_to(const fdd_csr_plan *plan, double *y, const double *y_
 }
 
 /* fused smoother entries: the unfused oracle pieces in sequence */
+/* matrix-free lattice transfer (csrc/fdd_transfer.hip): plain loops over elements, lattice points and corners */
+int fdd_lattice_supported(int n, int m, int *supported) { *supported = ((n == 8 || n == 16) && m >= 2 && m <= n / 2 + 1) ? 1 : 0; return 0; }
+#define SHIM_LATTICE(NAME_P, NAME_R, T)                                                                                                   \
+    int NAME_P(T *u, const T *coarse, const int *owner_dof, const int *coarse_dof, int n, int m, const int *lo, const int *hi, const double *wl, long long E, void *s) \
+    {                                                                                                                                     \
+        (void)s;                                                                                                                          \
+        REQ(n >= 2 && n <= 16 && m >= 2 && m <= n);                                                                                        \
+        const long long np = (long long)n * n * n, mc = (long long)m * m * m;                                                             \
+        for (long long e = 0; e < E; e++)                                                                                                 \
+            for (int k = 0; k < n; k++)                                                                                                   \
+                for (int j = 0; j < n; j++)                                                                                               \
+                    for (int i = 0; i < n; i++)                                                                                           \
+                    {                                                                                                                     \
+                        const int d = owner_dof[e * np + ((long long)k * n + j) * n + i];                                                 \
+                        if (d < 0) continue;                                                                                              \
+                        T sum = 0;                                                                                                        \
+                        for (int corner = 0; corner < 8; corner++)                                                                        \
+                        {                                                                                                                 \
+                            const int sx = corner & 1, sy = (corner >> 1) & 1, sz = corner >> 2;                                          \
+                            if ((sx && lo[i] == hi[i]) || (sy && lo[j] == hi[j]) || (sz && lo[k] == hi[k])) continue;                       \
+                            const int a = sx ? hi[i] : lo[i], b = sy ? hi[j] : lo[j], c = sz ? hi[k] : lo[k];                             \
+                            const T w = (T)(sx ? 1.0 - wl[i] : wl[i]) * (T)(sy ? 1.0 - wl[j] : wl[j]) * (T)(sz ? 1.0 - wl[k] : wl[k]);      \
+                            const int cd = coarse_dof[e * mc + ((long long)c * m + b) * m + a];                                           \
+                            if (cd >= 0) sum += w * coarse[cd];                                                                           \
+                        }                                                                                                                 \
+                        u[d] += sum;                                                                                                      \
+                    }                                                                                                                     \
+        return 0;                                                                                                                         \
+    }                                                                                                                                     \
+    int NAME_R(T *partial, const T *fine, const int *owner_dof, int n, int m, const int *lo, const int *hi, const double *wl, long long E, void *s) \
+    {                                                                                                                                     \
+        (void)s;                                                                                                                          \
+        REQ(n >= 2 && n <= 16 && m >= 2 && m <= n);                                                                                        \
+        const long long np = (long long)n * n * n, mc = (long long)m * m * m;                                                             \
+        for (long long t = 0; t < E * mc; t++) partial[t] = 0;                                                                            \
+        for (long long e = 0; e < E; e++)                                                                                                 \
+            for (int k = 0; k < n; k++)                                                                                                   \
+                for (int j = 0; j < n; j++)                                                                                               \
+                    for (int i = 0; i < n; i++)                                                                                           \
+                    {                                                                                                                     \
+                        const int d = owner_dof[e * np + ((long long)k * n + j) * n + i];                                                 \
+                        if (d < 0) continue;                                                                                              \
+                        for (int corner = 0; corner < 8; corner++)                                                                        \
+                        {                                                                                                                 \
+                            const int sx = corner & 1, sy = (corner >> 1) & 1, sz = corner >> 2;                                          \
+                            if ((sx && lo[i] == hi[i]) || (sy && lo[j] == hi[j]) || (sz && lo[k] == hi[k])) continue;                       \
+                            const int a = sx ? hi[i] : lo[i], b = sy ? hi[j] : lo[j], c = sz ? hi[k] : lo[k];                             \
+                            const T w = (T)(sx ? 1.0 - wl[i] : wl[i]) * (T)(sy ? 1.0 - wl[j] : wl[j]) * (T)(sz ? 1.0 - wl[k] : wl[k]);      \
+                            partial[e * mc + ((long long)c * m + b) * m + a] += w * fine[d];                                              \
+                        }                                                                                                                 \
+                    }                                                                                                                     \
+        return 0;                                                                                                                         \
+    }
+SHIM_LATTICE(fdd_lattice_prolong, fdd_lattice_restrict, double)
+SHIM_LATTICE(fdd_lattice_prolong_f32, fdd_lattice_restrict_f32, float)
+
 int fdd_amg_smooth_start(double *work, double *Sr, const double *f, const double *D, double coef, int n, void *s)
 {
     (void)s;

@@ -106,7 +106,7 @@ def test_errors(own_stream):
         p.close()
 
 
-@pytest.mark.parametrize("E,N,red", [((4, 4, 4), 3, 2), ((3, 2, 2), 6, 2)])
+@pytest.mark.parametrize("E,N,red", [((4, 4, 4), 3, 2), ((3, 2, 2), 6, 2), ((3, 2, 2), 7, 2)])
 def test_amg_with_the_host_layers_own_hierarchy(own_stream, E, N, red):
     """Low-order FEM matrix + smoothed-aggregation hierarchy built by host/low_order.hpp,
     V-cycle on the GPU (one hipGraph), against the oracle fed with the same arrays."""

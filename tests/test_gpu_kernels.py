@@ -549,6 +549,78 @@ def test_sell_compact_columns(gpu, shape, precision):
             lib.hip().call("fdd_csr_plan_destroy", plan)
 
 
+@pytest.mark.parametrize("precision", [64, 32])
+@pytest.mark.parametrize("n,keep,E", [(8, (0, 3, 4, 7), 37), (8, (0, 2, 5, 7), 1), (16, (0, 2, 4, 7, 8, 11, 13, 15), 9), (16, (0, 15), 5), (8, (0, 1, 2, 3, 7), 6)])
+def test_lattice_transfer_equals_the_csr_interpolator(gpu, n, keep, E, precision):
+    """fdd_lattice_prolong / fdd_lattice_restrict (the matrix-free interpolator of a geometric AMG level, host/low_order.hpp
+    geometric_level) against the same operator as a scipy CSR matrix built entry by entry from the weight table: random
+    ownership (later occurrences and Dirichlet points own nothing), coarse nodes shared between elements or without a
+    dof; uneven and minimal kept sets, a single element, a workgroup's ragged last elements."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(300 + n + E)
+    m = len(keep)
+    ref = np.sort(np.concatenate([[-1.0, 1.0], rng.uniform(-0.95, 0.95, n - 2)]))
+    pos = {k: a for a, k in enumerate(keep)}
+    lo, hi, wl = np.zeros(n, np.int32), np.zeros(n, np.int32), np.ones(n)
+    a = 0
+    for i in range(n):
+        if i in pos:
+            lo[i] = hi[i] = a = pos[i]
+            continue
+        lo[i], hi[i] = a, a + 1
+        wl[i] = (ref[keep[a + 1]] - ref[i]) / (ref[keep[a + 1]] - ref[keep[a]])
+    np3, mc = n**3, m**3
+    owns = rng.uniform(size=E * np3) < 0.8
+    nfine = int(owns.sum())
+    owner = np.full(E * np3, -1, np.int32)
+    owner[owns] = rng.permutation(nfine).astype(np.int32)
+    nc = max(E * mc // 2, 3)
+    coarse = rng.integers(0, nc, E * mc).astype(np.int32)
+    coarse[rng.uniform(size=E * mc) < 0.1] = -1
+    # the operator entry by entry: owned point (e, i, j, k) -> the kept nodes around it
+    pts = np.nonzero(owns)[0]
+    e, v = pts // np3, pts % np3
+    ii, jj, kk = v % n, (v // n) % n, v // (n * n)
+    rows, kept_node, wts = [], [], []
+    for corner in range(8):
+        sx, sy, sz = corner & 1, (corner >> 1) & 1, corner >> 2
+        ok = ~((sx & (lo[ii] == hi[ii])) | (sy & (lo[jj] == hi[jj])) | (sz & (lo[kk] == hi[kk]))).astype(bool)
+        ca, cb, cc = np.where(sx, hi[ii], lo[ii]), np.where(sy, hi[jj], lo[jj]), np.where(sz, hi[kk], lo[kk])
+        w = np.where(sx, 1 - wl[ii], wl[ii]) * np.where(sy, 1 - wl[jj], wl[jj]) * np.where(sz, 1 - wl[kk], wl[kk])
+        rows.append(owner[pts][ok])
+        kept_node.append((e * mc + (cc * m + cb) * m + ca)[ok])
+        wts.append(w[ok])
+    rows, kept_node, wts = np.concatenate(rows), np.concatenate(kept_node), np.concatenate(wts)
+    S_el = sp.csr_matrix((wts, (kept_node, rows)), shape=(E * mc, nfine))  # element-local restriction
+    has = coarse[kept_node] >= 0
+    P = sp.csr_matrix((wts[has], (rows[has], coarse[kept_node][has])), shape=(nfine, nc))
+    assert np.allclose(np.asarray(S_el.sum(axis=0)).ravel(), 1.0)  # a partition of unity: the weights of a fine point add up to 1
+    ft, tt = (np.float64, torch.float64) if precision == 64 else (np.float32, torch.float32)
+    tol = 1e-13 if precision == 64 else 2e-6
+    u0, ec, fine = (rng.uniform(-1, 1, sz).astype(ft) for sz in (nfine, nc, nfine))
+    t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(gpu)
+    suffix = "" if precision == 64 else "_f32"
+    vpi = lambda arr: vp(arr.ctypes.data)
+    supported = ctypes.c_int(0)
+    lib.hip().call("fdd_lattice_supported", n, m, ctypes.byref(supported))
+    assert supported.value == 1
+    du = t(u0)
+    k("fdd_lattice_prolong" + suffix, du, t(ec), t(owner), t(coarse), n, m, vpi(lo), vpi(hi), vpi(wl), ctypes.c_longlong(E))
+    want = u0.astype(np.float64) + P @ ec.astype(np.float64)
+    assert np.abs(host(du) - want).max() <= tol * max(np.abs(want).max(), 1.0)
+    partial = torch.full((E * mc,), float("nan"), dtype=tt, device=gpu)
+    k("fdd_lattice_restrict" + suffix, partial, t(fine), t(owner), n, m, vpi(lo), vpi(hi), vpi(wl), ctypes.c_longlong(E))
+    want = S_el @ fine.astype(np.float64)
+    assert np.abs(host(partial) - want).max() <= tol * max(np.abs(want).max(), 1.0) * n
+    # zero elements: nothing is launched; an unsupported lattice is refused
+    k("fdd_lattice_prolong" + suffix, du, t(ec), t(owner), t(coarse), n, m, vpi(lo), vpi(hi), vpi(wl), ctypes.c_longlong(0))
+    lib.hip().call("fdd_lattice_supported", 6, 3, ctypes.byref(supported))
+    assert supported.value == 0
+    with pytest.raises(lib.FddError):
+        k("fdd_lattice_prolong" + suffix, du, t(ec), t(owner), t(coarse), 6, 3, vpi(lo), vpi(hi), vpi(wl), ctypes.c_longlong(1))
+
+
 def test_csr_empty_matrix(gpu):
     ptr = np.zeros(11, np.int32)
     run_csr_case(gpu, ptr, np.zeros(0, np.int32), np.zeros(0), 7, expect_kind=0)
