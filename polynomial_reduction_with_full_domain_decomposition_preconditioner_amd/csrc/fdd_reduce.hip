@@ -95,11 +95,25 @@ __global__ __launch_bounds__(kBlock) void reduce_final_kernel(double *out, const
     const int lane = threadIdx.x & (FDD_WAVE - 1);
     const int wave = threadIdx.x / FDD_WAVE;
 
+    // every partial this lane folds is requested before the first one is added (one round trip to the partials the
+    // previous launch left in memory instead of one per partial); the sums and their order are those of the plain loop
+    constexpr int kPer = FDD_REDUCE_MAX_BLOCKS / kBlock;
+    double v[NV][kPer];
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+#pragma unroll
+        for (int i = 0; i < kPer; i++)
+        {
+            const int b = threadIdx.x + i * kBlock;
+            v[k][i] = ws[(b < nblocks ? b : 0) + k * FDD_REDUCE_MAX_BLOCKS];
+        }
 #pragma unroll
     for (int k = 0; k < NV; k++)
     {
         double x = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += kBlock) x += ws[b + k * FDD_REDUCE_MAX_BLOCKS];
+#pragma unroll
+        for (int i = 0; i < kPer; i++)
+            if (threadIdx.x + i * kBlock < nblocks) x += v[k][i];
         x = wave_sum(x);
         if (lane == 0) s[k][wave] = x;
     }
