@@ -96,6 +96,7 @@ def parse():
     ap.add_argument("--no-kershaw", action="store_true", help="skip the `kershaw` leg (a second problem on the deformed mesh)")
     ap.add_argument("--print-launch", action="store_true", help="print the launcher command `--gpus N` would start (JSON list) and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flag", action="append", default=[], metavar="NAME=VALUE", help="launch-sequence switch of the host layer (fddh_problem_set_flag) applied to every problem of the run, for A/B runs on one box: e.g. --flag fused_arnoldi_step=0")
     ap.add_argument("--cpu-sample-elements", type=int, default=None, help="elements per direction and rank of the CPU baseline's sample (default: the workload itself up to degree 7 -- 32 = config C2 --, 16 beyond: as many points)")
     ap.add_argument("--cpu-sample-steps", type=int, default=3, help="outer PCG iterations of the sample (one rank at C2: about 6 s each on the box's host)")
     return ap.parse_args()
@@ -359,8 +360,13 @@ def run(args, rank, world, max_over_ranks, comm_label):
         failure code so that the launcher tears the job down, instead of moving on to a mismatched collective."""
         try:
             if args.mesh == "kershaw":
-                return H.Problem.kershaw(E, P, N, args.reduction, args.eps, with_subdomain=not args.no_precond, block_local=block_local, force_composite=args.force_composite and world == 1)
-            return H.Problem.box(E, P, N, args.reduction, with_subdomain=not args.no_precond, block_local=block_local, force_composite=args.force_composite and world == 1)
+                made = H.Problem.kershaw(E, P, N, args.reduction, args.eps, with_subdomain=not args.no_precond, block_local=block_local, force_composite=args.force_composite and world == 1)
+            else:
+                made = H.Problem.box(E, P, N, args.reduction, with_subdomain=not args.no_precond, block_local=block_local, force_composite=args.force_composite and world == 1)
+            for item in args.flag:
+                name, _, value = item.partition("=")
+                made.set_flag(name, int(value))
+            return made
         except Exception as exc:
             print("bench.py rank %d: problem setup failed: %s" % (rank, exc), file=sys.stderr, flush=True)
             os._exit(1)
