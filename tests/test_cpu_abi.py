@@ -115,13 +115,13 @@ def test_bench_launches_its_own_ranks():
 
     bench = os.path.join(S.ROOT, "bench.py")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "5", "--comm", "rccl", "--print-launch"], capture_output=True, text=True, env=env, timeout=120)
+    out = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "5", "--comm", "rccl", "--flag", "early_gamma=0", "--print-launch"], capture_output=True, text=True, env=env, timeout=120)
     assert out.returncode == 0, out.stderr
     cmd = json.loads(out.stdout.strip().splitlines()[-1])
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--standalone"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
     assert "127.0.0.1" in cmd and "--nnodes=1" in cmd and not any("master-port" in c for c in cmd)  # no port number is passed around
     tail = cmd[cmd.index(bench):]
-    assert tail == [bench, "--gpus", "8", "--steps", "5", "--comm", "rccl"]  # --print-launch itself is not passed on
+    assert tail == [bench, "--gpus", "8", "--steps", "5", "--comm", "rccl", "--flag", "early_gamma=0"]  # --print-launch itself is not passed on; the A/B switches reach every rank
     src = open(bench).read()
     launch = src[src.index("def launch_ranks(args):"):src.index("class _ThreadRanks")]
     assert "subprocess.run(" in launch and "exec" not in launch.replace("never an exec", "")  # a child process, never an exec
